@@ -1,0 +1,227 @@
+/*
+ * yolo2_hip.h -- C-ABI of libyolo2hip.so: the MI355X (gfx950) drop-in for the
+ * device half of AlexeyAB/yolo2_light's inference hot path.
+ *
+ * Plain C, plain pointers and sizes only.  Every entry point names the
+ * reference interface it replaces (paths relative to the reference tree).
+ * The reference has no plugin registry: its back-end boundary is the
+ * `network_predict_*` family (src/additionally.h:907-969) plus the one-time
+ * model-prep passes the caller runs before it (src/main.c:160-171).  A
+ * maintainer binds this library with the ~60-line adaptor shown in
+ * INTEGRATION.md (`network_predict_hip(network, float*)`), built WITHOUT
+ * -DGPU so `layer`/`network` keep their CPU layout.
+ *
+ * All functions return 0 on success and a negative code on failure unless
+ * stated otherwise; yl_last_error() returns a thread-local message.  Nothing
+ * here falls back to a CPU implementation: device entry points fail with
+ * YL_ERR_DEVICE when no gfx950 device/kernels are available.
+ */
+#ifndef YOLO2_HIP_H
+#define YOLO2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YL_OK            0
+#define YL_ERR_ARG      -1
+#define YL_ERR_IO       -2
+#define YL_ERR_CFG      -3
+#define YL_ERR_DEVICE   -4
+#define YL_ERR_UNSUPPORTED -5
+#define YL_ERR_STATE    -6
+
+/* numeric values == reference LAYER_TYPE (src/additionally.h:376-403) so an
+ * adaptor can pass `l.type` straight through */
+enum {
+    YL_CONVOLUTIONAL = 0, YL_MAXPOOL = 3, YL_ROUTE = 8, YL_SHORTCUT = 13,
+    YL_REGION = 21, YL_YOLO = 22, YL_UPSAMPLE = 23, YL_REORG = 24, YL_BLANK = 25
+};
+/* numeric values == reference ACTIVATION (src/additionally.h:68-70) */
+enum { YL_LOGISTIC = 0, YL_LINEAR = 3, YL_LEAKY = 7 };
+
+typedef struct yl_network yl_network;   /* opaque; owns host model + all device memory */
+
+/* One layer as the reference's `layer` (src/additionally.h:409-684) describes
+ * it, reduced to the fields the hot path reads.  Host pointers are only read
+ * during yl_network_create_from_desc (a snapshot is taken). */
+typedef struct yl_layer_desc {
+    int type;                 /* l.type */
+    int activation;           /* l.activation */
+    int batch, w, h, c;       /* l.batch, l.w, l.h, l.c */
+    int n;                    /* conv: filters; route: #inputs; yolo/region: #anchors of this head */
+    int size, stride, pad;    /* l.size, l.stride, l.pad */
+    int out_w, out_h, out_c;  /* l.out_w, l.out_h, l.out_c */
+    int outputs, inputs;      /* l.outputs, l.inputs (per image) */
+    int batch_normalize;      /* 0 once yolov2_fuse_conv_batchnorm has run */
+    int xnor;                 /* l.xnor */
+    int index;                /* shortcut: absolute index of the `from` layer (l.index) */
+    const int *input_layers;  /* route: l.input_layers[n] */
+    const int *input_sizes;   /* route: l.input_sizes[n]  */
+    int classes, coords, total, softmax;   /* yolo / region */
+    const int *mask;          /* yolo: l.mask[n] */
+    const float *anchors;     /* yolo: l.biases[2*total]; region: l.biases[2*n] */
+    float scale;              /* upsample: l.scale */
+    const float *weights;     /* conv: l.weights[n*c*size*size] */
+    const float *biases;      /* conv: l.biases[n] */
+    const float *scales, *rolling_mean, *rolling_variance;   /* conv BN (NULL if fused) */
+    const int8_t *weights_int8;        /* conv: l.weights_int8 (NULL -> computed by yl_network_quantize) */
+    float input_quant_multipler;       /* l.input_quant_multipler  */
+    float weights_quant_multipler;     /* l.weights_quant_multipler */
+    const float *mean_arr;             /* conv xnor: l.mean_arr[n] (NULL -> computed) */
+    float *output;            /* host l.output[batch*outputs]: filled by yl_network_predict for
+                                 YOLO/REGION layers and the last layer, like the reference GPU
+                                 path does (src/yolov2_forward_network_gpu.cu:404-419,438,570) */
+} yl_layer_desc;
+
+/* thread-local human-readable message of the last failure */
+const char *yl_last_error(void);
+
+/* number of visible HIP devices (0 when there is no GPU); replaces nothing,
+ * the reference selects the device with `-i` -> cuda_set_device (src/main.c:653-661) */
+int yl_device_count(void);
+
+/* ------------------------------------------------------------------ *
+ *  Host-side model build (L1 of the reference).  When the reference's
+ *  own parser is the caller, use yl_network_create_from_desc instead.
+ * ------------------------------------------------------------------ */
+
+/* parse_network_cfg(filename, batch, quantized)       src/additionally.c:3955 */
+int yl_network_create_from_cfg(const char *cfg_path, int batch, int quantized, yl_network **out);
+
+/* Build from already-parsed (and possibly already-prepared) reference layers:
+ * what the adaptor in INTEGRATION.md calls after main.c:160-171 has run.
+ * input_calibration = net.input_calibration (src/additionally.c:3870-3885). */
+int yl_network_create_from_desc(const yl_layer_desc *layers, int n_layers,
+                                int batch, int w, int h, int c, int quantized,
+                                const float *input_calibration, int input_calibration_size,
+                                yl_network **out);
+
+/* load_weights_upto_cpu(&net, filename, net.n)        src/additionally.c:3491 */
+int yl_network_load_weights(yl_network *net, const char *weights_path);
+
+/* yolov2_fuse_conv_batchnorm(net)                     src/additionally.c:67 */
+int yl_network_fuse_conv_batchnorm(yl_network *net);
+
+/* calculate_binary_weights(net)                       src/additionally.c:306 */
+int yl_network_calculate_binary_weights(yl_network *net);
+
+/* quantinization_and_get_multipliers(net)             src/yolov2_forward_network_quantized.c:1402 */
+int yl_network_quantize(yl_network *net);
+
+/* free_network(net)                                   src/additionally.c:2054 */
+void yl_network_destroy(yl_network *net);
+
+/* ---- introspection (used by the parity tests and bench.py) ---- */
+int yl_network_num_layers(const yl_network *net);
+int yl_network_batch(const yl_network *net);
+/* dims[3] = {w, h, c} of the network input */
+int yl_network_input_dims(const yl_network *net, int *dims);
+/* info[24]: type, batch, w, h, c, n, size, stride, pad, out_w, out_h, out_c,
+ *           outputs, inputs, activation, xnor, quantized(int8 used), index,
+ *           classes, coords, total, softmax, reserved, batch_normalize */
+int yl_network_layer_info(const yl_network *net, int i, int *info);
+/* borrowed host pointers to the prepared parameters of conv layer i (NULL if absent) */
+const float  *yl_network_layer_weights(const yl_network *net, int i);
+const float  *yl_network_layer_biases(const yl_network *net, int i);
+const int8_t *yl_network_layer_weights_int8(const yl_network *net, int i);
+const float  *yl_network_layer_mean_arr(const yl_network *net, int i);
+/* mult[2] = {input_quant_multipler, weights_quant_multipler} */
+int yl_network_layer_quant_multipliers(const yl_network *net, int i, float *mult);
+/* per-image FLOPs of the conv layers: sum 2*n*size^2*c*out_h*out_w (src/additionally.c:2903) */
+double yl_network_flops_per_image(const yl_network *net);
+
+/* ------------------------------------------------------------------ *
+ *  Device side (replaces L3 device variant + L2 device kernels + the
+ *  device half of L0 of the reference).
+ * ------------------------------------------------------------------ */
+
+/* Upload parameters and plan all activation buffers in HBM on `device`.
+ * Replaces cuda_set_device + cuda_make_array/push_convolutional_layer calls
+ * scattered through make_*_layer / fuse / binary_align_weights
+ * (src/gpu.cu:97-266, src/additionally.c:92-96,281-299,2819-2881) and
+ * init_gpu_int8x4 (src/yolov2_forward_network_gpu.cu). */
+int yl_network_to_device(yl_network *net, int device);
+
+/* float *network_predict_gpu_cudnn[_quantized](network net, float *input)
+ *                                         src/yolov2_forward_network_gpu.cu:547,576
+ * Same contract as network_predict_cpu (src/yolov2_forward_network.c:632):
+ * `input` = host float[batch*c*h*w] CHW in [0,1]; returns a borrowed host
+ * pointer to the last layer's output (NULL on failure); as a side effect the
+ * host outputs of every YOLO/REGION layer are populated so that
+ * get_network_boxes (src/additionally.c:4403) works unchanged.  Whether the
+ * FP32, INT8 or XNOR convolution runs for a layer follows the reference CPU
+ * rules (src/yolov2_forward_network_quantized.c:1036, src/yolov2_forward_network.c:116). */
+float *yl_network_predict(yl_network *net, const float *input);
+
+/* forward_network_gpu_cudnn(net, state)    src/yolov2_forward_network_gpu.cu:443
+ * `input_dev` = device float[batch*c*h*w] already resident in HBM.  Asynchronous
+ * on the network's stream (see yl_network_set_stream); no host copies. */
+int yl_network_forward(yl_network *net, const float *input_dev);
+
+/* HIP stream (hipStream_t as void*) the network launches on; NULL = its own stream. */
+int yl_network_set_stream(yl_network *net, void *hip_stream);
+/* block until everything queued by this network has finished (cudaDeviceSynchronize analogue) */
+int yl_network_synchronize(yl_network *net);
+
+/* cuda_pull_array(l.output_gpu, l.output, n)           src/gpu.cu:254
+ * copies batch*outputs floats of layer i to dst_host (synchronous). */
+int yl_network_layer_output(yl_network *net, int i, float *dst_host);
+/* device pointer of layer i's output [batch][out_c][out_h][out_w] (borrowed) */
+const float *yl_network_layer_output_dev(const yl_network *net, int i);
+/* device pointer of the network input staging buffer (net.input_state_gpu, src/additionally.c:4060) */
+float *yl_network_input_dev(yl_network *net);
+
+/* XNOR parity hook: integer match-count tensor of XNOR conv layer i from the
+ * last forward (the `count` of gemm_nn_custom_bin_mean_transposed,
+ * src/additionally.c:1504-1534, before `(2*count-K)*mean`).  Enabled by
+ * yl_network_set_debug(net, 1) BEFORE yl_network_to_device. dst = int32[batch*outputs]. */
+int yl_network_set_debug(yl_network *net, int on);
+int yl_network_layer_xnor_counts(yl_network *net, int i, int32_t *dst_host);
+/* INT8 parity hook: the int16-clamped accumulator of INT8 conv layer i
+ * (`output_q`, src/yolov2_forward_network_quantized.c:550,486). dst = int32[batch*outputs]. */
+int yl_network_layer_int8_acc(yl_network *net, int i, int32_t *dst_host);
+
+/* Per-layer device timing with HIP events on the network's stream:
+ * runs `iters` forwards, ms_per_layer[n_layers] = average ms of each layer's
+ * kernels, *total_ms = average ms of a whole forward (events around the pass).
+ * (The reference only has clock() around predict, src/main.c:197,220.) */
+int yl_network_profile(yl_network *net, const float *input_dev, int iters,
+                       float *ms_per_layer, float *total_ms);
+
+/* ------------------------------------------------------------------ *
+ *  Detections (L4).  The reference decodes batch item 0 only
+ *  (src/additionally.c:4213,4338); `image` selects the batch item.
+ * ------------------------------------------------------------------ */
+
+/* get_network_boxes(&net, w, h, thresh, hier, map=0, relative, &num, letter)
+ *   + do_nms_sort(dets, num, classes, nms)   src/additionally.c:4403, src/box.c:296
+ * computed on the HOST from the YOLO/REGION outputs pulled by yl_network_predict
+ * (or yl_network_pull_heads).  rows[max_rows][6+classes]:
+ *   x y w h objectness sort_class prob[classes].  Returns the number of
+ * detections the reference would return (may exceed max_rows), <0 on error. */
+int yl_network_get_boxes(yl_network *net, int image, int w, int h, float thresh,
+                         int relative, int letter, float nms,
+                         float *rows, int max_rows, int *classes_out);
+
+/* D2H of every YOLO/REGION layer output (what src/yolov2_forward_network_gpu.cu:438
+ * does per YOLO layer) after a yl_network_forward. */
+int yl_network_pull_heads(yl_network *net);
+
+/* On-device detection compaction (new): threshold test
+ * `objectness > thresh` (src/additionally.c:4341) and box decode
+ * (get_yolo_box :4317 / get_region_box_cpu src/yolov2_forward_network.c:653)
+ * executed on the GPU into a fixed-capacity record buffer that an RCCL gather
+ * can ship: records_dev[batch][cap][6+classes] floats (same row layout as
+ * yl_network_get_boxes, boxes relative to the network input, no NMS) and
+ * counts_dev[batch] ints.  Asynchronous on the network's stream. */
+int yl_network_compact_detections(yl_network *net, float thresh, int cap,
+                                  float *records_dev, int *counts_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO2_HIP_H */

@@ -1,0 +1,214 @@
+"""Shared test helpers: oracle bindings, a python network walker that runs the
+oracle restatement layer by layer, seeded inputs, comparison helpers.
+
+Everything here is test infrastructure; the product never imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import refbind  # noqa: E402
+from yolo2_light_amd import Network, weights, zoo  # noqa: E402
+
+ORACLE_SO = os.path.join(ROOT, "oracle", "liboracle.so")
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+_fp = C.POINTER(C.c_float)
+_i8p = C.POINTER(C.c_int8)
+_i32p = C.POINTER(C.c_int32)
+
+# layer type / activation codes (== reference enums)
+CONV, MAXPOOL, ROUTE, SHORTCUT, REGION, YOLO, UPSAMPLE, REORG = 0, 3, 8, 13, 21, 22, 23, 24
+CONV_F32, CONV_INT8, CONV_XNOR = 0, 1, 2
+
+
+def _build_oracle() -> None:
+    src = os.path.join(ROOT, "oracle", "yolo2_oracle.c")
+    if os.path.exists(ORACLE_SO) and os.path.getmtime(ORACLE_SO) >= os.path.getmtime(src):
+        return
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"],
+                          stdout=subprocess.DEVNULL)
+
+
+def oracle_lib() -> C.CDLL:
+    _build_oracle()
+    lib = C.CDLL(ORACLE_SO)
+    i = C.c_int
+    lib.oracle_conv_f32.argtypes = [_fp, _fp, _fp, _fp] + [i] * 9
+    lib.oracle_conv_int8.argtypes = [_fp, _i8p, _fp, _fp, _i32p] + [i] * 9 + [C.c_float, C.c_float]
+    lib.oracle_conv_xnor.argtypes = [_fp, _fp, _fp, _fp, _fp, _i32p] + [i] * 6
+    lib.oracle_maxpool.argtypes = [_fp, _fp] + [i] * 9
+    lib.oracle_shortcut.argtypes = [_fp, _fp, _fp] + [i] * 8
+    lib.oracle_upsample.argtypes = [_fp, _fp] + [i] * 5 + [C.c_float]
+    lib.oracle_yolo.argtypes = [_fp, _fp] + [i] * 4
+    lib.oracle_region.argtypes = [_fp, _fp] + [i] * 6
+    lib.oracle_reorg.argtypes = [_fp, _fp] + [i] * 5
+    lib.oracle_fuse_bn.argtypes = [_fp, _fp, _fp, _fp, _fp, i, i]
+    lib.oracle_binary_mean.argtypes = [_fp, i, i, _fp]
+    lib.oracle_quantize_weights.argtypes = [_fp, C.c_size_t, _i8p]
+    lib.oracle_quantize_weights.restype = C.c_float
+    for name in ("oracle_conv_f32", "oracle_conv_int8", "oracle_conv_xnor", "oracle_maxpool", "oracle_shortcut",
+                 "oracle_upsample", "oracle_yolo", "oracle_region", "oracle_reorg", "oracle_fuse_bn",
+                 "oracle_binary_mean"):
+        getattr(lib, name).restype = None
+    return lib
+
+
+def fp(a: np.ndarray):
+    return a.ctypes.data_as(_fp)
+
+
+# ---------------------------------------------------------------------------
+# model fixtures
+# ---------------------------------------------------------------------------
+_WORK = None
+
+
+def workdir() -> str:
+    global _WORK
+    if _WORK is None:
+        _WORK = tempfile.mkdtemp(prefix="yl_tests_")
+    return _WORK
+
+
+_MODEL_CACHE = {}
+
+
+def model_files(name: str, width: int, height: int, seed: int = 1):
+    """(cfg_path, weights_path) of a generated cfg + synthetic weights."""
+    key = (name, width, height, seed)
+    if key not in _MODEL_CACHE:
+        cfg = zoo.write_cfg(name, workdir(), width, height)
+        wpath = os.path.join(workdir(), "%s-%dx%d-s%d.weights" % (name, width, height, seed))
+        with open(cfg) as f:
+            weights.write_synthetic_weights(f.read(), wpath, seed=seed)
+        _MODEL_CACHE[key] = (cfg, wpath)
+    return _MODEL_CACHE[key]
+
+
+def seeded_input(batch: int, c: int, h: int, w: int, seed: int = 2222222) -> np.ndarray:
+    """U[0,1) images, seed echoing srand(2222222) (src/main.c:165)."""
+    rng = np.random.default_rng(seed)
+    return rng.random((batch, c, h, w), dtype=np.float32)
+
+
+# ---------------------------------------------------------------------------
+# oracle network walker
+# ---------------------------------------------------------------------------
+class OracleNet:
+    """Runs the C restatement layer by layer over the topology/parameters of a
+    host-side `Network` (whose parser and prep passes are pinned separately
+    against the reference in tests/test_host_prep.py)."""
+
+    def __init__(self, net: Network, olib: C.CDLL):
+        self.net = net
+        self.o = olib
+        self.infos = net.layers()
+        self.outputs = [None] * net.n
+        self.int8_acc = {}
+        self.xnor_counts = {}
+        # route inputs are not exposed through layer_info: recover from the cfg walker in tests
+        self.route_inputs = {}
+
+    def set_route_inputs(self, cfg_text: str) -> None:
+        secs = zoo.parse_sections(cfg_text)[1:]
+        for i, (typ, o) in enumerate(secs):
+            if typ == "route":
+                ids = [int(x) for x in o["layers"].split(",")]
+                self.route_inputs[i] = [j + i if j < 0 else j for j in ids]
+
+    def forward(self, x: np.ndarray, stop_after: int = None) -> None:
+        net, o = self.net, self.o
+        B = net.batch
+        cur = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+        for i, li in enumerate(self.infos):
+            out = np.zeros(B * li["outputs"], dtype=np.float32)
+            t = li["type"]
+            if t == CONV:
+                wts = net.layer_weights(i)
+                bias = net.layer_biases(i)
+                mode = li["conv_mode"]
+                if mode == CONV_F32:
+                    o.oracle_conv_f32(fp(cur), fp(wts), fp(bias), fp(out), B, li["c"], li["h"], li["w"], li["n"],
+                                      li["size"], li["stride"], li["pad"], li["activation"])
+                elif mode == CONV_INT8:
+                    wq = net.layer_weights_int8(i)
+                    im, wm = net.layer_quant_multipliers(i)
+                    acc = np.zeros(B * li["outputs"], dtype=np.int32)
+                    o.oracle_conv_int8(fp(cur), wq.ctypes.data_as(_i8p), fp(bias), fp(out),
+                                       acc.ctypes.data_as(_i32p), B, li["c"], li["h"], li["w"], li["n"],
+                                       li["size"], li["stride"], li["pad"], li["activation"], im, wm)
+                    self.int8_acc[i] = acc
+                else:
+                    mean = net.layer_mean_arr(i)
+                    cnt = np.zeros(B * li["outputs"], dtype=np.int32)
+                    o.oracle_conv_xnor(fp(cur), fp(wts), fp(mean), fp(bias), fp(out), cnt.ctypes.data_as(_i32p),
+                                       B, li["c"], li["h"], li["w"], li["n"], li["activation"])
+                    self.xnor_counts[i] = cnt
+            elif t == MAXPOOL:
+                o.oracle_maxpool(fp(cur), fp(out), li["size"], li["w"], li["h"], li["out_w"], li["out_h"], li["c"],
+                                 li["pad"], li["stride"], B)
+            elif t == ROUTE:
+                ids = self.route_inputs[i]
+                out2 = out.reshape(B, li["outputs"])
+                off = 0
+                for j in ids:
+                    sz = self.infos[j]["outputs"]
+                    out2[:, off:off + sz] = self.outputs[j].reshape(B, sz)
+                    off += sz
+                out = out2.reshape(-1)
+            elif t == SHORTCUT:
+                add = self.outputs[li["index"]]
+                o.oracle_shortcut(fp(cur), fp(add), fp(out), B, li["w"], li["h"], li["c"], li["out_w"], li["out_h"],
+                                  li["out_c"], li["activation"])
+            elif t == UPSAMPLE:
+                o.oracle_upsample(fp(cur), fp(out), B, li["c"], li["h"], li["w"], li["stride"], 1.0)
+            elif t == YOLO:
+                o.oracle_yolo(fp(cur), fp(out), B, li["n"], li["classes"], li["w"] * li["h"])
+            elif t == REGION:
+                o.oracle_region(fp(cur), fp(out), B, li["n"], li["classes"], li["coords"], li["w"] * li["h"],
+                                li["softmax"])
+            elif t == REORG:
+                o.oracle_reorg(fp(cur), fp(out), B, li["out_c"], li["out_h"], li["out_w"], li["stride"])
+            else:
+                raise NotImplementedError("oracle walker: layer type %d" % t)
+            self.outputs[i] = out
+            cur = out
+            if stop_after is not None and i >= stop_after:
+                break
+
+
+# ---------------------------------------------------------------------------
+# comparisons
+# ---------------------------------------------------------------------------
+FP32_RTOL = 1e-4      # north_star: "within 1e-4 rel for FP32"
+
+
+def fp32_close(got: np.ndarray, ref: np.ndarray, rtol: float = FP32_RTOL):
+    """|got-ref| <= rtol*|ref| + rtol*RMS(ref): relative tolerance with an absolute
+    floor tied to the layer's own scale for cancellation-limited elements.
+    Returns (ok, max_err_over_allowed, worst_index)."""
+    got = np.asarray(got, dtype=np.float64).reshape(-1)
+    ref = np.asarray(ref, dtype=np.float64).reshape(-1)
+    rms = float(np.sqrt(np.mean(ref * ref))) if ref.size else 0.0
+    allowed = rtol * np.abs(ref) + rtol * max(rms, 1e-30)
+    err = np.abs(got - ref)
+    ratio = err / allowed
+    worst = int(np.argmax(ratio)) if ratio.size else 0
+    return bool(np.all(np.isfinite(got)) and (ratio.size == 0 or ratio[worst] <= 1.0)), \
+        float(ratio[worst]) if ratio.size else 0.0, worst
+
+
+def have_gpu() -> bool:
+    from yolo2_light_amd._lib import lib
+    return lib.yl_device_count() > 0

@@ -1,0 +1,63 @@
+"""Pin the oracle restatement (oracle/yolo2_oracle.c) bit-for-bit against the
+reference's own CPU path (oracle/_ref/libyolo2ref.so = unmodified reference
+sources, golden build flags) on whole networks, every layer.
+
+The reference ships no golden vectors, so this -- together with
+tests/golden fixtures generated from the same library -- is what makes the
+oracle trustworthy.  Skipped only if oracle/_ref was never built.
+"""
+import numpy as np
+import pytest
+
+import common
+from common import OracleNet, Network, refbind
+
+pytestmark = pytest.mark.skipif(not refbind.available(), reason="oracle/_ref not built (needs /root/reference once)")
+
+CASES = [
+    # name, width, height, batch, quantized
+    ("yolov3-tiny", 96, 96, 2, 0),
+    ("yolov3-tiny", 64, 96, 1, 1),
+    ("yolov3", 64, 64, 2, 0),
+    ("yolov3", 64, 64, 1, 1),
+    ("tiny-yolo-xnor", 96, 96, 2, 0),
+    ("tiny-yolo-xnor", 160, 128, 1, 0),
+]
+
+
+@pytest.mark.parametrize("name,width,height,batch,quantized", CASES)
+def test_oracle_matches_reference_every_layer(olib, name, width, height, batch, quantized):
+    cfg, wts = common.model_files(name, width, height)
+    ref = refbind.RefNetwork(cfg, wts, batch, quantized)
+    net = Network.load(cfg, wts, batch, quantized)
+    x = common.seeded_input(batch, 3, height, width)
+    ref.predict(x)
+    on = OracleNet(net, olib)
+    on.set_route_inputs(open(cfg).read())
+    on.forward(x)
+    assert ref.n == net.n
+    for i in range(net.n):
+        a = on.outputs[i]
+        b = ref.layer_output(i)
+        assert a.shape == b.shape
+        # bit-exact: the restatement must be the same arithmetic, not merely close
+        same = np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        if not same:
+            bad = np.flatnonzero(a.view(np.uint32) != b.view(np.uint32))
+            raise AssertionError("layer %d (%s): %d/%d values differ, first idx %d: oracle %r ref %r" % (
+                i, net.layer_info(i), bad.size, a.size, bad[0], a[bad[0]], b[bad[0]]))
+
+
+def test_maxpool_op_pin(olib):
+    rng = np.random.default_rng(7)
+    for size, stride, w, h in [(2, 2, 8, 6), (2, 1, 13, 13), (5, 1, 9, 7), (9, 1, 13, 13), (13, 1, 13, 13), (3, 2, 11, 9)]:
+        pad = size - 1
+        ow, oh = (w + pad - size) // stride + 1, (h + pad - size) // stride + 1
+        c, b = 3, 2
+        x = rng.standard_normal(b * c * h * w).astype(np.float32)
+        a = np.zeros(b * c * oh * ow, dtype=np.float32)
+        r = np.zeros_like(a)
+        olib.oracle_maxpool(common.fp(x), common.fp(a), size, w, h, ow, oh, c, pad, stride, b)
+        rl = refbind._bind(refbind.GOLD)
+        rl.ref_maxpool(common.fp(x), common.fp(r), size, w, h, ow, oh, c, pad, stride, b)
+        assert np.array_equal(a, r), (size, stride)

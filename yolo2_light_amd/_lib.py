@@ -1,0 +1,112 @@
+"""ctypes binding of libyolo2hip.so (the C-ABI declared in include/yolo2_hip.h).
+
+There is deliberately no fallback: if the shared library is missing the import
+fails loudly, and every device call raises when HIP reports an error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolo2hip.so")
+
+
+class YoloHipError(RuntimeError):
+    pass
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C yolo2_light_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    return C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+
+lib = _load()
+
+c_float_p = C.POINTER(C.c_float)
+c_int_p = C.POINTER(C.c_int)
+c_int8_p = C.POINTER(C.c_int8)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class LayerDesc(C.Structure):
+    """struct yl_layer_desc (include/yolo2_hip.h)."""
+    _fields_ = [
+        ("type", C.c_int), ("activation", C.c_int),
+        ("batch", C.c_int), ("w", C.c_int), ("h", C.c_int), ("c", C.c_int),
+        ("n", C.c_int), ("size", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
+        ("out_w", C.c_int), ("out_h", C.c_int), ("out_c", C.c_int),
+        ("outputs", C.c_int), ("inputs", C.c_int),
+        ("batch_normalize", C.c_int), ("xnor", C.c_int), ("index", C.c_int),
+        ("input_layers", c_int_p), ("input_sizes", c_int_p),
+        ("classes", C.c_int), ("coords", C.c_int), ("total", C.c_int), ("softmax", C.c_int),
+        ("mask", c_int_p), ("anchors", c_float_p), ("scale", C.c_float),
+        ("weights", c_float_p), ("biases", c_float_p),
+        ("scales", c_float_p), ("rolling_mean", c_float_p), ("rolling_variance", c_float_p),
+        ("weights_int8", c_int8_p),
+        ("input_quant_multipler", C.c_float), ("weights_quant_multipler", C.c_float),
+        ("mean_arr", c_float_p),
+        ("output", c_float_p),
+    ]
+
+
+_vp = C.c_void_p
+
+_SIGS = {
+    "yl_last_error": (C.c_char_p, []),
+    "yl_device_count": (C.c_int, []),
+    "yl_network_create_from_cfg": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "yl_network_create_from_desc": (C.c_int, [C.POINTER(LayerDesc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, c_float_p, C.c_int, C.POINTER(_vp)]),
+    "yl_network_load_weights": (C.c_int, [_vp, C.c_char_p]),
+    "yl_network_fuse_conv_batchnorm": (C.c_int, [_vp]),
+    "yl_network_calculate_binary_weights": (C.c_int, [_vp]),
+    "yl_network_quantize": (C.c_int, [_vp]),
+    "yl_network_destroy": (None, [_vp]),
+    "yl_network_num_layers": (C.c_int, [_vp]),
+    "yl_network_batch": (C.c_int, [_vp]),
+    "yl_network_input_dims": (C.c_int, [_vp, c_int_p]),
+    "yl_network_layer_info": (C.c_int, [_vp, C.c_int, c_int_p]),
+    "yl_network_layer_weights": (c_float_p, [_vp, C.c_int]),
+    "yl_network_layer_biases": (c_float_p, [_vp, C.c_int]),
+    "yl_network_layer_weights_int8": (c_int8_p, [_vp, C.c_int]),
+    "yl_network_layer_mean_arr": (c_float_p, [_vp, C.c_int]),
+    "yl_network_layer_quant_multipliers": (C.c_int, [_vp, C.c_int, c_float_p]),
+    "yl_network_flops_per_image": (C.c_double, [_vp]),
+    "yl_network_to_device": (C.c_int, [_vp, C.c_int]),
+    "yl_network_predict": (c_float_p, [_vp, c_float_p]),
+    "yl_network_forward": (C.c_int, [_vp, _vp]),
+    "yl_network_set_stream": (C.c_int, [_vp, _vp]),
+    "yl_network_synchronize": (C.c_int, [_vp]),
+    "yl_network_layer_output": (C.c_int, [_vp, C.c_int, c_float_p]),
+    "yl_network_layer_output_dev": (_vp, [_vp, C.c_int]),
+    "yl_network_input_dev": (_vp, [_vp]),
+    "yl_network_set_debug": (C.c_int, [_vp, C.c_int]),
+    "yl_network_layer_xnor_counts": (C.c_int, [_vp, C.c_int, c_int32_p]),
+    "yl_network_layer_int8_acc": (C.c_int, [_vp, C.c_int, c_int32_p]),
+    "yl_network_profile": (C.c_int, [_vp, _vp, C.c_int, c_float_p, c_float_p]),
+    "yl_network_get_boxes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_float,
+                                       c_float_p, C.c_int, c_int_p]),
+    "yl_network_pull_heads": (C.c_int, [_vp]),
+    "yl_network_compact_detections": (C.c_int, [_vp, C.c_float, C.c_int, _vp, _vp]),
+}
+
+# every symbol include/yolo2_hip.h declares (tests/test_abi.py cross-checks against the header)
+EXPORTED = tuple(_SIGS)
+
+for _name, (_res, _args) in _SIGS.items():
+    _fn = getattr(lib, _name)          # AttributeError here == missing export == hard failure
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error() -> str:
+    return (lib.yl_last_error() or b"").decode()
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise YoloHipError("%s failed (%d): %s" % (what, rc, last_error()))

@@ -1,0 +1,81 @@
+// kernels.h -- launch interfaces of the hand-written gfx950 kernels.
+// Every launcher is asynchronous on `stream` and returns hipError_t as int.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+
+namespace yl {
+
+// ---- K1: FP32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 ----
+struct ConvF32Args {
+    const float *in;      // [B][C][H][W]
+    const float *wt;      // k-major packed weights [Kpad][Mpad]
+    const float *bias;    // [M]
+    const float *add;     // optional residual, same shape as out (nullptr = none)
+    float *out;           // [B][M][OH][OW]
+    int B, C, H, W, M, OH, OW;
+    int K, Kpad, Mpad;
+    int size, stride, pad;
+    int act;              // YL_LINEAR / YL_LEAKY
+};
+int launch_conv_f32(const ConvF32Args &a, void *stream);
+// force a tile config (0 = heuristic): used by the tile sweep in bench/tests
+void conv_f32_force_tile(int cfg);
+const char *conv_f32_last_tile_name();
+
+// ---- K2: INT8 path ----
+// K2a: x_q = clamp_abs((int16)(x*mult), 127), FP32 NCHW -> int8 NHWC(Cpad)   (quantized.c:554-560)
+int launch_quantize_nhwc(const float *in, int8_t *out, int B, int C, int H, int W, int Cpad,
+                         float mult, void *stream);
+struct ConvI8Args {
+    const int8_t *in_q;   // [B][H][W][Cpad]
+    const int8_t *w_q;    // [Mpad][size*size][Cpad]
+    const float *bias;    // [M]
+    float *out;           // [B][M][OH][OW] fp32
+    int32_t *dbg;         // optional int16-clamped accumulators [B][M][OH][OW]
+    int B, Cpad, H, W, M, Mpad, OH, OW;
+    int size, stride, pad;
+    int act;
+    float alpha1;         // R_MULT / (in_mult * w_mult)   (quantized.c:596)
+};
+int launch_conv_i8(const ConvI8Args &a, void *stream);
+
+// ---- K3: XNOR path ----
+// K3a: sign bits of FP32 NCHW packed along channels -> [B][H][W][Cw] 64-bit words, bit = (x > 0)
+int launch_pack_sign_bits(const float *in, uint64_t *out, int B, int C, int H, int W, int Cw, void *stream);
+struct ConvXnorArgs {
+    const uint64_t *in_bits;  // [B][H][W][Cw]
+    const uint64_t *w_bits;   // [Mpad][9][Cw], channel-pad bits = 1
+    const float *mean;        // [M]
+    const float *bias;        // [M]
+    float *out;               // [B][M][H][W]
+    int32_t *dbg;             // optional match counts
+    int B, C, Cw, H, W, M, Mpad;
+    int act;
+};
+int launch_conv_xnor(const ConvXnorArgs &a, void *stream);
+
+// ---- K4..K9: small coalesced layers ----
+int launch_maxpool(const float *in, float *out, int B, int C, int H, int W, int OH, int OW,
+                   int size, int stride, int pad, void *stream);
+int launch_shortcut(const float *in, const float *add, float *out, int B,
+                    int w1, int h1, int c1,   // dims of `add`
+                    int w2, int h2, int c2,   // dims of in/out
+                    int act, void *stream);
+int launch_upsample(const float *in, float *out, int B, int C, int H, int W, int stride, float scale, void *stream);
+int launch_copy_rows(const float *src, float *dst, int rows, int row_elems, size_t src_stride, size_t dst_stride, void *stream);
+int launch_yolo(const float *in, float *out, int B, int n, int classes, int wh, void *stream);
+int launch_region(const float *in, float *out, int B, int n, int classes, int coords, int wh, int softmax, void *stream);
+int launch_reorg(const float *in, float *out, int B, int out_c, int out_h, int out_w, int stride, void *stream);
+
+// ---- K10: detection compaction ----
+struct HeadDesc {
+    const float *out;     // head layer output (device)
+    int type;             // YL_YOLO / YL_REGION
+    int w, h, n, classes, outputs;
+    float anchors_w[16], anchors_h[16];   // already selected through mask[]
+};
+int launch_compact(const HeadDesc *heads, int n_heads, int B, int netw, int neth, float thresh,
+                   int cap, int row_stride, float *records, int *counts, void *stream);
+
+}  // namespace yl

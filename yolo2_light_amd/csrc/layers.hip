@@ -1,0 +1,381 @@
+// layers.hip -- K4..K10: the small HBM-bound layers as simple coalesced gfx950
+// kernels (one output element per lane, consecutive lanes -> consecutive
+// addresses, grid-stride over a capped grid).
+//
+//   maxpool   forward_maxpool_layer_avx            src/additionally.c:1448-1482
+//   shortcut  forward_shortcut_layer_cpu/shortcut_cpu  src/yolov2_forward_network.c:444 / 410
+//   upsample  forward_upsample_layer_cpu/upsample_cpu  src/yolov2_forward_network.c:398 / 380
+//   route     forward_route_layer_cpu              src/yolov2_forward_network.c:318
+//   yolo      forward_yolo_layer_cpu               src/yolov2_forward_network.c:453
+//   region    forward_region_layer_cpu/softmax_cpu src/yolov2_forward_network.c:511 / 476
+//   reorg     forward_reorg_layer_cpu              src/yolov2_forward_network.c:337
+//   compact   yolo_num_detections/get_yolo_detections/get_yolo_box  src/additionally.c:4207/4328/4317
+//             get_region_boxes_cpu/get_region_box_cpu               src/yolov2_forward_network.c:664/653
+#include <hip/hip_runtime.h>
+#include <cfloat>
+
+#include "kernels.h"
+#include "../../include/yolo2_hip.h"
+
+namespace yl {
+
+static inline unsigned grid_for(size_t n, int block = 256)
+{
+    size_t g = (n + block - 1) / block;
+    const size_t cap = 256 * 16;          // 256 CUs x 16 workgroups, grid-stride beyond
+    if (g > cap) g = cap;
+    if (g == 0) g = 1;
+    return (unsigned)g;
+}
+
+// ---------------------------------------------------------------- maxpool
+__global__ __launch_bounds__(256) void maxpool_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                      size_t total, int C, int H, int W, int OH, int OW,
+                                                      int size, int stride, int off)
+{
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % OW);
+        size_t t = idx / OW;
+        const int i = (int)(t % OH);
+        t /= OH;                                   // t = k + C*b
+        const float *src = in + t * (size_t)H * W;
+        float mx = -FLT_MAX;
+        for (int n = 0; n < size; ++n) {
+            const int cur_h = off + i * stride + n;
+            for (int m = 0; m < size; ++m) {
+                const int cur_w = off + j * stride + m;
+                const bool valid = cur_h >= 0 && cur_h < H && cur_w >= 0 && cur_w < W;
+                const float val = valid ? src[(size_t)cur_h * W + cur_w] : -FLT_MAX;
+                mx = (val > mx) ? val : mx;
+            }
+        }
+        out[idx] = mx;
+    }
+}
+
+int launch_maxpool(const float *in, float *out, int B, int C, int H, int W, int OH, int OW,
+                   int size, int stride, int pad, void *stream)
+{
+    const size_t total = (size_t)B * C * OH * OW;
+    const int off = -pad / 2;                      // C integer division, SURVEY A4
+    hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       in, out, total, C, H, W, OH, OW, size, stride, off);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------- shortcut
+__device__ __forceinline__ float act_apply(float v, int act)
+{
+    if (act == YL_LEAKY) return (v > 0.f) ? v : (float)(.1 * (double)v);
+    if (act == YL_LOGISTIC) return (float)(1. / (1. + exp((double)(-v))));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void shortcut_same_kernel(const float4 *__restrict__ in, const float4 *__restrict__ add,
+                                                            float4 *__restrict__ out, size_t n4, int act)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 a = in[i], b = add[i];
+        float4 r;
+        r.x = act_apply(a.x + b.x, act); r.y = act_apply(a.y + b.y, act);
+        r.z = act_apply(a.z + b.z, act); r.w = act_apply(a.w + b.w, act);
+        out[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void shortcut_general_kernel(const float *__restrict__ in, const float *__restrict__ add,
+                                                               float *__restrict__ out, size_t total,
+                                                               int w1, int h1, int c1, int w2, int h2, int c2,
+                                                               int stride, int sample, int minw, int minh, int minc, int act)
+{
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % w2);
+        size_t t = idx / w2;
+        const int y = (int)(t % h2);
+        t /= h2;
+        const int k = (int)(t % c2);
+        const size_t b = t / c2;
+        float v = in[idx];
+        if (k < minc && (x % sample) == 0 && (y % sample) == 0) {
+            const int i = x / sample, j = y / sample;
+            if (i < minw && j < minh)
+                v = v + add[(size_t)i * stride + (size_t)w1 * ((size_t)j * stride + (size_t)h1 * (k + (size_t)c1 * b))];
+        }
+        out[idx] = act_apply(v, act);
+    }
+}
+
+int launch_shortcut(const float *in, const float *add, float *out, int B, int w1, int h1, int c1,
+                    int w2, int h2, int c2, int act, void *stream)
+{
+    const size_t total = (size_t)B * w2 * h2 * c2;
+    if (w1 == w2 && h1 == h2 && c1 == c2 && (total % 4) == 0) {
+        hipLaunchKernelGGL(shortcut_same_kernel, dim3(grid_for(total / 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const float4 *)in, (const float4 *)add, (float4 *)out, total / 4, act);
+    } else {
+        int stride = w1 / w2, sample = w2 / w1;
+        if (stride < 1) stride = 1;
+        if (sample < 1) sample = 1;
+        const int minw = w1 < w2 ? w1 : w2, minh = h1 < h2 ? h1 : h2, minc = c1 < c2 ? c1 : c2;
+        hipLaunchKernelGGL(shortcut_general_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           in, add, out, total, w1, h1, c1, w2, h2, c2, stride, sample, minw, minh, minc, act);
+    }
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------- upsample
+__global__ __launch_bounds__(256) void upsample_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                       size_t total, int H, int W, int stride, float scale)
+{
+    const int OW = W * stride, OH = H * stride;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % OW);
+        size_t t = idx / OW;
+        const int j = (int)(t % OH);
+        t /= OH;                                   // t = k + C*b
+        out[idx] = __fmul_rn(scale, in[t * (size_t)H * W + (size_t)(j / stride) * W + i / stride]);
+    }
+}
+
+int launch_upsample(const float *in, float *out, int B, int C, int H, int W, int stride, float scale, void *stream)
+{
+    const size_t total = (size_t)B * C * H * W * stride * stride;
+    hipLaunchKernelGGL(upsample_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       in, out, total, H, W, stride, scale);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------- route (row copies)
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                        int rows, int row_elems, size_t src_stride, size_t dst_stride)
+{
+    const size_t total = (size_t)rows * row_elems;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = idx / row_elems;
+        const size_t e = idx - r * row_elems;
+        dst[r * dst_stride + e] = src[r * src_stride + e];
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_rows4_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst,
+                                                         int rows, int row_elems4, size_t src_stride4, size_t dst_stride4)
+{
+    const size_t total = (size_t)rows * row_elems4;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = idx / row_elems4;
+        const size_t e = idx - r * row_elems4;
+        dst[r * dst_stride4 + e] = src[r * src_stride4 + e];
+    }
+}
+
+int launch_copy_rows(const float *src, float *dst, int rows, int row_elems, size_t src_stride, size_t dst_stride, void *stream)
+{
+    const bool v4 = (row_elems % 4 == 0) && (src_stride % 4 == 0) && (dst_stride % 4 == 0) &&
+                    (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
+    if (v4) {
+        const size_t total = (size_t)rows * (row_elems / 4);
+        hipLaunchKernelGGL(copy_rows4_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float4 *)src, (float4 *)dst, rows, row_elems / 4, src_stride / 4, dst_stride / 4);
+    } else {
+        const size_t total = (size_t)rows * row_elems;
+        hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           src, dst, rows, row_elems, src_stride, dst_stride);
+    }
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------- yolo
+// copy + logistic on entries {0,1} (x,y) and {4..4+classes} (obj, classes) of every anchor;
+// layout stays [B][n*(5+classes)][h][w]
+__global__ __launch_bounds__(256) void yolo_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                   size_t total, int per_anchor, int wh)
+{
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int entry = (int)((idx / wh) % per_anchor);
+        const float x = in[idx];
+        // logistic_activate: 1./(1. + exp(-x)) in double (src/additionally.h:84)
+        out[idx] = (entry == 2 || entry == 3) ? x : (float)(1. / (1. + exp((double)(-x))));
+    }
+}
+
+int launch_yolo(const float *in, float *out, int B, int n, int classes, int wh, void *stream)
+{
+    const int per_anchor = 4 + classes + 1;
+    const size_t total = (size_t)B * n * per_anchor * wh;
+    hipLaunchKernelGGL(yolo_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       in, out, total, per_anchor, wh);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------- region
+// one lane per (b, cell, anchor): CHW -> HWC flatten, logistic(obj) in float, softmax over classes
+__global__ __launch_bounds__(256) void region_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                     size_t total, int n, int classes, int coords, int wh, int softmax)
+{
+    const int size = coords + classes + 1;
+    const int layers = size * n;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int a = (int)(idx % n);                 // anchor
+        size_t t = idx / n;
+        const int cell = (int)(t % wh);
+        const size_t b = t / wh;
+        const float *src = in + b * (size_t)layers * wh + (size_t)(a * size) * wh + cell;   // channel c at src[c*wh]
+        float *dst = out + b * (size_t)layers * wh + (size_t)cell * layers + (size_t)a * size;
+        for (int c = 0; c < coords; ++c) dst[c] = src[(size_t)c * wh];
+        const float o = src[(size_t)coords * wh];
+        dst[coords] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-o)));
+        if (softmax) {
+            float largest = -FLT_MAX;
+            for (int c = 0; c < classes; ++c) {
+                const float v = src[(size_t)(coords + 1 + c) * wh];
+                if (v > largest) largest = v;
+            }
+            float sum = 0.f;
+            for (int c = 0; c < classes; ++c) {
+                // expf(input[i]/temp - largest/temp), temp = 1
+                const float e = expf(__fsub_rn(src[(size_t)(coords + 1 + c) * wh], largest));
+                sum = __fadd_rn(sum, e);
+                dst[coords + 1 + c] = e;
+            }
+            for (int c = 0; c < classes; ++c) dst[coords + 1 + c] = __fdiv_rn(dst[coords + 1 + c], sum);
+        } else {
+            for (int c = 0; c < classes; ++c) dst[coords + 1 + c] = src[(size_t)(coords + 1 + c) * wh];
+        }
+    }
+}
+
+int launch_region(const float *in, float *out, int B, int n, int classes, int coords, int wh, int softmax, void *stream)
+{
+    const size_t total = (size_t)B * wh * n;
+    hipLaunchKernelGGL(region_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       in, out, total, n, classes, coords, wh, softmax);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------- reorg
+__global__ __launch_bounds__(256) void reorg_kernel(const float *__restrict__ x, float *__restrict__ out,
+                                                    size_t total, int out_c, int out_h, int out_w, int stride)
+{
+    const int in_c = out_c / (stride * stride);
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % out_w);
+        size_t t = idx / out_w;
+        const int j = (int)(t % out_h);
+        t /= out_h;
+        const int k = (int)(t % out_c);
+        const size_t b = t / out_c;
+        const int c2 = k % in_c;
+        const int offset = k / in_c;
+        const int w2 = i * stride + offset % stride;
+        const int h2 = j * stride + offset / stride;
+        out[idx] = x[w2 + (size_t)out_w * stride * (h2 + (size_t)out_h * stride * (c2 + (size_t)in_c * b))];
+    }
+}
+
+int launch_reorg(const float *in, float *out, int B, int out_c, int out_h, int out_w, int stride, void *stream)
+{
+    const size_t total = (size_t)B * out_c * out_h * out_w;
+    hipLaunchKernelGGL(reorg_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       in, out, total, out_c, out_h, out_w, stride);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------- K10: detection compaction
+struct HeadsDev {
+    HeadDesc h[4];
+    int n_heads;
+};
+
+// one lane per (image, head, cell, anchor).  Record row (stride = 6 + classes):
+//   x y w h objectness sort_class(-1) prob[classes]
+// boxes are relative to the network input (== get_network_boxes(net, 1, 1, thresh, ., 0, relative=1, ., 0)).
+// Order inside an image is by atomic slot, i.e. NOT the reference's scan order: consumers sort or
+// treat the set as unordered (NMS re-sorts per class anyway, src/box.c:313).
+__global__ __launch_bounds__(256) void compact_kernel(HeadsDev hd, int B, int netw, int neth, float thresh,
+                                                      int cap, int row_stride, float *__restrict__ records,
+                                                      int *__restrict__ counts)
+{
+    for (int hi = 0; hi < hd.n_heads; ++hi) {
+        const HeadDesc &h = hd.h[hi];
+        const int wh = h.w * h.h;
+        const size_t total = (size_t)B * wh * h.n;
+        for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+             idx += (size_t)gridDim.x * blockDim.x) {
+            const int n = (int)(idx % h.n);
+            size_t t = idx / h.n;
+            const int cell = (int)(t % wh);
+            const int b = (int)(t / wh);
+            const int row = cell / h.w, col = cell % h.w;
+            const float *p = h.out + (size_t)b * h.outputs;
+            if (h.type == YL_YOLO) {
+                const float *e = p + (size_t)n * wh * (5 + h.classes) + cell;    // entry k at e[k*wh]
+                const float objectness = e[4 * (size_t)wh];
+                if (objectness > thresh) {
+                    const int slot = atomicAdd(&counts[b], 1);
+                    if (slot < cap) {
+                        float *r = records + ((size_t)b * cap + slot) * row_stride;
+                        r[0] = __fdiv_rn(__fadd_rn((float)col, e[0]), (float)h.w);
+                        r[1] = __fdiv_rn(__fadd_rn((float)row, e[(size_t)wh]), (float)h.h);
+                        r[2] = (float)(exp((double)e[2 * (size_t)wh]) * (double)h.anchors_w[n] / (double)netw);
+                        r[3] = (float)(exp((double)e[3 * (size_t)wh]) * (double)h.anchors_h[n] / (double)neth);
+                        r[4] = objectness;
+                        r[5] = -1.f;
+                        for (int j = 0; j < h.classes; ++j) {
+                            const float prob = __fmul_rn(objectness, e[(size_t)(5 + j) * wh]);
+                            r[6 + j] = (prob > thresh) ? prob : 0.f;
+                        }
+                    }
+                }
+            } else {    // REGION: flattened HWC rows, every (cell, anchor) is a detection
+                const int index = cell * h.n + n;
+                const float *e = p + (size_t)index * (h.classes + 5);
+                const float scale = e[4];
+                const int slot = atomicAdd(&counts[b], 1);
+                if (slot < cap) {
+                    float *r = records + ((size_t)b * cap + slot) * row_stride;
+                    const float lx = (float)(1. / (1. + exp((double)(-e[0]))));
+                    const float ly = (float)(1. / (1. + exp((double)(-e[1]))));
+                    r[0] = __fdiv_rn(__fadd_rn((float)col, lx), (float)h.w);
+                    r[1] = __fdiv_rn(__fadd_rn((float)row, ly), (float)h.h);
+                    r[2] = __fdiv_rn(__fmul_rn(expf(e[2]), h.anchors_w[n]), (float)h.w);
+                    r[3] = __fdiv_rn(__fmul_rn(expf(e[3]), h.anchors_h[n]), (float)h.h);
+                    r[4] = 1.f;
+                    r[5] = -1.f;
+                    for (int j = 0; j < h.classes; ++j) {
+                        const float prob = __fmul_rn(scale, e[5 + j]);
+                        r[6 + j] = (prob > thresh) ? prob : 0.f;
+                    }
+                }
+            }
+        }
+    }
+}
+
+int launch_compact(const HeadDesc *heads, int n_heads, int B, int netw, int neth, float thresh,
+                   int cap, int row_stride, float *records, int *counts, void *stream)
+{
+    if (n_heads > 4) return (int)hipErrorInvalidValue;
+    HeadsDev hd;
+    hd.n_heads = n_heads;
+    size_t mx = 1;
+    for (int i = 0; i < n_heads; ++i) {
+        hd.h[i] = heads[i];
+        const size_t t = (size_t)B * heads[i].w * heads[i].h * heads[i].n;
+        if (t > mx) mx = t;
+    }
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(int) * B, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(compact_kernel, dim3(grid_for(mx)), dim3(256), 0, (hipStream_t)stream,
+                       hd, B, netw, neth, thresh, cap, row_stride, records, counts);
+    return (int)hipGetLastError();
+}
+
+}  // namespace yl

@@ -1,0 +1,654 @@
+// runtime.hip -- device runtime + the C-ABI of libyolo2hip.so.
+//
+// Replaces the reference's device variant of L3 (forward_network_gpu_cudnn,
+// src/yolov2_forward_network_gpu.cu:443-491; network_predict_gpu_cudnn :547-573)
+// and the device half of L0 (cuda_make_array / cuda_push_array / cuda_pull_array,
+// src/gpu.cu:97-266).  Design: every layer output stays resident in HBM for the
+// whole forward (route/shortcut index arbitrary earlier layers; 288 GB makes
+// batch 64 at 608x608 a ~25 GB working set), all launches go to one HIP stream,
+// there is no host synchronisation inside a forward, and no CPU fallback: every
+// device entry point fails with YL_ERR_DEVICE when HIP reports an error.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "yl_internal.h"
+
+namespace yl {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+#define YL_HIP(expr)                                                                    \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));               \
+            return YL_ERR_DEVICE;                                                       \
+        }                                                                               \
+    } while (0)
+
+#define YL_LAUNCH(call, what)                                                           \
+    do {                                                                                \
+        int e_ = (call);                                                                \
+        if (e_ != 0) {                                                                  \
+            set_error(std::string(what) + ": " + hipGetErrorString((hipError_t)e_));    \
+            return YL_ERR_DEVICE;                                                       \
+        }                                                                               \
+    } while (0)
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static void free_device(Network &net)
+{
+    if (net.device >= 0) (void)hipSetDevice(net.device);
+    for (Layer &l : net.layers) {
+        if (l.d_output && !l.d_output_alias) (void)hipFree(l.d_output);
+        l.d_output = nullptr;
+        if (l.d_weights_t) (void)hipFree(l.d_weights_t);
+        if (l.d_biases) (void)hipFree(l.d_biases);
+        if (l.d_weights_i8) (void)hipFree(l.d_weights_i8);
+        if (l.d_weights_bits) (void)hipFree(l.d_weights_bits);
+        if (l.d_mean) (void)hipFree(l.d_mean);
+        if (l.d_debug) (void)hipFree(l.d_debug);
+        l.d_weights_t = nullptr; l.d_biases = nullptr; l.d_weights_i8 = nullptr;
+        l.d_weights_bits = nullptr; l.d_mean = nullptr; l.d_debug = nullptr;
+    }
+    if (net.d_input) (void)hipFree(net.d_input);
+    if (net.d_qbuf) (void)hipFree(net.d_qbuf);
+    if (net.d_bitbuf) (void)hipFree(net.d_bitbuf);
+    if (net.h_pinned) (void)hipHostFree(net.h_pinned);
+    net.d_input = nullptr; net.d_qbuf = nullptr; net.d_bitbuf = nullptr; net.h_pinned = nullptr;
+    for (void *e : net.layer_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
+    net.layer_events.clear();
+    if (net.ev0) (void)hipEventDestroy((hipEvent_t)net.ev0);
+    if (net.ev1) (void)hipEventDestroy((hipEvent_t)net.ev1);
+    net.ev0 = net.ev1 = nullptr;
+    if (net.own_stream && net.stream) (void)hipStreamDestroy((hipStream_t)net.stream);
+    net.stream = nullptr; net.own_stream = false;
+    net.on_device = false;
+}
+
+// ------------------------------------------------------------------ upload
+static int upload_conv(Network &net, Layer &l)
+{
+    const int K = l.size * l.size * l.c;
+    const int M = l.n;
+    YL_HIP(hipMalloc((void **)&l.d_biases, sizeof(float) * M));
+    YL_HIP(hipMemcpy(l.d_biases, l.biases.data(), sizeof(float) * M, hipMemcpyHostToDevice));
+    if (l.conv_mode == CONV_F32) {
+        if (l.xnor) {
+            set_error("xnor conv outside the 3x3/stride-1/pad-1 bit path (FP32 fallback on +-mean weights, "
+                      "src/yolov2_forward_network.c:40-50) is a next-tier row (SURVEY 8f-4)");
+            return YL_ERR_UNSUPPORTED;
+        }
+        // k-major panel layout [Kpad][Mpad], zero padded
+        l.Kpad = round_up(K, 16);
+        l.Mpad = round_up(M, 256);
+        std::vector<float> wt((size_t)l.Kpad * l.Mpad, 0.f);
+        for (int m = 0; m < M; ++m)
+            for (int k = 0; k < K; ++k) wt[(size_t)k * l.Mpad + m] = l.weights[(size_t)m * K + k];
+        YL_HIP(hipMalloc((void **)&l.d_weights_t, wt.size() * sizeof(float)));
+        YL_HIP(hipMemcpy(l.d_weights_t, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+    } else if (l.conv_mode == CONV_INT8) {
+        if (!l.quant_ready) { set_error("INT8 layer without yl_network_quantize()"); return YL_ERR_STATE; }
+        // channel-fastest [Mpad][taps][Cpad], zero padded; Cpad multiple of 16 (one MFMA k-group)
+        const int taps = l.size * l.size;
+        l.Cpad = round_up(l.c, 16);
+        l.Mpad = round_up(M, 128);
+        std::vector<int8_t> wq((size_t)l.Mpad * taps * l.Cpad, 0);
+        for (int m = 0; m < M; ++m)
+            for (int c = 0; c < l.c; ++c)
+                for (int t = 0; t < taps; ++t)
+                    wq[((size_t)m * taps + t) * l.Cpad + c] = l.weights_int8[((size_t)m * l.c + c) * taps + t];
+        YL_HIP(hipMalloc((void **)&l.d_weights_i8, wq.size()));
+        YL_HIP(hipMemcpy(l.d_weights_i8, wq.data(), wq.size(), hipMemcpyHostToDevice));
+        const size_t qb = (size_t)net.batch * l.h * l.w * l.Cpad;
+        if (qb > net.qbuf_bytes) net.qbuf_bytes = qb;
+    } else {   // CONV_XNOR
+        if (!l.xnor_ready) { set_error("XNOR layer without yl_network_calculate_binary_weights()"); return YL_ERR_STATE; }
+        // 64-bit sign words along channels: [Mpad][9][Cw]; bit = (w > 0) (src/additionally.c:123,1544);
+        // channel-pad bits are 1 in the weights and 0 in the activations so they never match.
+        l.Cw = (l.c + 63) / 64;
+        l.Mpad = round_up(M, 64);
+        std::vector<uint64_t> wb((size_t)l.Mpad * 9 * l.Cw, 0ull);
+        for (int m = 0; m < M; ++m)
+            for (int t = 0; t < 9; ++t)
+                for (int cw = 0; cw < l.Cw; ++cw) {
+                    uint64_t word = 0;
+                    for (int b = 0; b < 64; ++b) {
+                        const int c = cw * 64 + b;
+                        const bool bit = (c < l.c) ? (l.weights[((size_t)m * l.c + c) * 9 + t] > 0.f) : true;
+                        if (bit) word |= (1ull << b);
+                    }
+                    wb[((size_t)m * 9 + t) * l.Cw + cw] = word;
+                }
+        YL_HIP(hipMalloc((void **)&l.d_weights_bits, wb.size() * sizeof(uint64_t)));
+        YL_HIP(hipMemcpy(l.d_weights_bits, wb.data(), wb.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        YL_HIP(hipMalloc((void **)&l.d_mean, sizeof(float) * M));
+        YL_HIP(hipMemcpy(l.d_mean, l.mean_arr.data(), sizeof(float) * M, hipMemcpyHostToDevice));
+        const size_t bb = (size_t)net.batch * l.h * l.w * l.Cw * sizeof(uint64_t);
+        if (bb > net.bitbuf_bytes) net.bitbuf_bytes = bb;
+    }
+    if (net.debug && l.conv_mode != CONV_F32) {
+        YL_HIP(hipMalloc((void **)&l.d_debug, sizeof(int32_t) * (size_t)net.batch * l.outputs));
+    }
+    return YL_OK;
+}
+
+static int to_device(Network &net, int device)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        set_error("no HIP device visible (libyolo2hip has no CPU fallback)");
+        return YL_ERR_DEVICE;
+    }
+    if (device < 0 || device >= count) { set_error("device index out of range"); return YL_ERR_ARG; }
+    if (net.on_device) free_device(net);
+    net.device = device;
+    YL_HIP(hipSetDevice(device));
+    if (!net.stream) {
+        hipStream_t s;
+        YL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        net.stream = s; net.own_stream = true;
+    }
+    select_conv_modes(net);
+    net.qbuf_bytes = 0; net.bitbuf_bytes = 0;
+    const size_t in_elems = (size_t)net.batch * net.c * net.h * net.w;
+    YL_HIP(hipMalloc((void **)&net.d_input, in_elems * sizeof(float)));
+    net.pinned_bytes = in_elems * sizeof(float);
+    YL_HIP(hipHostMalloc(&net.h_pinned, net.pinned_bytes, hipHostMallocDefault));
+
+    for (size_t i = 0; i < net.layers.size(); ++i) {
+        Layer &l = net.layers[i];
+        const size_t out_elems = (size_t)net.batch * l.outputs;
+        if (l.type == YL_ROUTE && l.n == 1) {
+            l.d_output = net.layers[l.input_layers[0]].d_output;     // pure alias, no copy
+            l.d_output_alias = true;
+        } else {
+            l.d_output_alias = false;
+            YL_HIP(hipMalloc((void **)&l.d_output, out_elems * sizeof(float)));
+        }
+        if (l.type == YL_CONVOLUTIONAL) {
+            int rc = upload_conv(net, l);
+            if (rc != YL_OK) return rc;
+        }
+        const bool is_head = (l.type == YL_YOLO || l.type == YL_REGION);
+        if ((is_head || i + 1 == net.layers.size()) && !l.host_output) {
+            l.host_output_own.assign(out_elems, 0.f);
+            l.host_output = l.host_output_own.data();
+        }
+    }
+    if (net.qbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_qbuf, net.qbuf_bytes));
+    if (net.bitbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_bitbuf, net.bitbuf_bytes));
+    hipEvent_t e0, e1;
+    YL_HIP(hipEventCreate(&e0));
+    YL_HIP(hipEventCreate(&e1));
+    net.ev0 = e0; net.ev1 = e1;
+    net.on_device = true;
+    return YL_OK;
+}
+
+// ------------------------------------------------------------------ forward
+static int forward_layer(Network &net, size_t i, const float *input)
+{
+    Layer &l = net.layers[i];
+    void *s = net.stream;
+    const int B = net.batch;
+    switch (l.type) {
+    case YL_CONVOLUTIONAL: {
+        if (l.conv_mode == CONV_F32) {
+            ConvF32Args a;
+            a.in = input; a.wt = l.d_weights_t; a.bias = l.d_biases; a.add = nullptr; a.out = l.d_output;
+            a.B = B; a.C = l.c; a.H = l.h; a.W = l.w; a.M = l.n; a.OH = l.out_h; a.OW = l.out_w;
+            a.K = l.size * l.size * l.c; a.Kpad = l.Kpad; a.Mpad = l.Mpad;
+            a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
+            YL_LAUNCH(launch_conv_f32(a, s), "conv_f32");
+        } else if (l.conv_mode == CONV_INT8) {
+            YL_LAUNCH(launch_quantize_nhwc(input, net.d_qbuf, B, l.c, l.h, l.w, l.Cpad, l.input_quant_multipler, s),
+                      "quantize_nhwc");
+            ConvI8Args a;
+            a.in_q = net.d_qbuf; a.w_q = l.d_weights_i8; a.bias = l.d_biases; a.out = l.d_output; a.dbg = l.d_debug;
+            a.B = B; a.Cpad = l.Cpad; a.H = l.h; a.W = l.w; a.M = l.n; a.Mpad = l.Mpad; a.OH = l.out_h; a.OW = l.out_w;
+            a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
+            // float ALPHA1 = R_MULT / (l.input_quant_multipler * l.weights_quant_multipler);  (quantized.c:596)
+            a.alpha1 = 32 / (l.input_quant_multipler * l.weights_quant_multipler);
+            YL_LAUNCH(launch_conv_i8(a, s), "conv_i8");
+        } else {
+            YL_LAUNCH(launch_pack_sign_bits(input, net.d_bitbuf, B, l.c, l.h, l.w, l.Cw, s), "pack_sign_bits");
+            ConvXnorArgs a;
+            a.in_bits = net.d_bitbuf; a.w_bits = l.d_weights_bits; a.mean = l.d_mean; a.bias = l.d_biases;
+            a.out = l.d_output; a.dbg = l.d_debug;
+            a.B = B; a.C = l.c; a.Cw = l.Cw; a.H = l.h; a.W = l.w; a.M = l.n; a.Mpad = l.Mpad; a.act = l.activation;
+            YL_LAUNCH(launch_conv_xnor(a, s), "conv_xnor");
+        }
+        break;
+    }
+    case YL_MAXPOOL:
+        YL_LAUNCH(launch_maxpool(input, l.d_output, B, l.c, l.h, l.w, l.out_h, l.out_w, l.size, l.stride, l.pad, s), "maxpool");
+        break;
+    case YL_ROUTE: {
+        if (l.d_output_alias) break;
+        size_t offset = 0;
+        for (int k = 0; k < l.n; ++k) {
+            const Layer &src = net.layers[l.input_layers[k]];
+            YL_LAUNCH(launch_copy_rows(src.d_output, l.d_output + offset, B, l.input_sizes[k],
+                                       (size_t)l.input_sizes[k], (size_t)l.outputs, s), "route");
+            offset += l.input_sizes[k];
+        }
+        break;
+    }
+    case YL_SHORTCUT:
+        YL_LAUNCH(launch_shortcut(input, net.layers[l.index].d_output, l.d_output, B, l.w, l.h, l.c,
+                                  l.out_w, l.out_h, l.out_c, l.activation, s), "shortcut");
+        break;
+    case YL_UPSAMPLE:
+        YL_LAUNCH(launch_upsample(input, l.d_output, B, l.c, l.h, l.w, l.stride, l.scale, s), "upsample");
+        break;
+    case YL_YOLO:
+        YL_LAUNCH(launch_yolo(input, l.d_output, B, l.n, l.classes, l.w * l.h, s), "yolo");
+        break;
+    case YL_REGION:
+        YL_LAUNCH(launch_region(input, l.d_output, B, l.n, l.classes, l.coords, l.w * l.h, l.softmax, s), "region");
+        break;
+    case YL_REORG:
+        YL_LAUNCH(launch_reorg(input, l.d_output, B, l.out_c, l.out_h, l.out_w, l.stride, s), "reorg");
+        break;
+    default:
+        set_error("layer type has no device kernel");
+        return YL_ERR_UNSUPPORTED;
+    }
+    return YL_OK;
+}
+
+static int forward(Network &net, const float *input_dev, bool timed)
+{
+    if (!net.on_device) { set_error("network not on device: call yl_network_to_device first"); return YL_ERR_STATE; }
+    YL_HIP(hipSetDevice(net.device));
+    const float *input = input_dev;
+    for (size_t i = 0; i < net.layers.size(); ++i) {
+        if (timed) YL_HIP(hipEventRecord((hipEvent_t)net.layer_events[i], (hipStream_t)net.stream));
+        int rc = forward_layer(net, i, input);
+        if (rc != YL_OK) return rc;
+        input = net.layers[i].d_output;
+    }
+    if (timed) YL_HIP(hipEventRecord((hipEvent_t)net.layer_events[net.layers.size()], (hipStream_t)net.stream));
+    return YL_OK;
+}
+
+static int pull_heads(Network &net, bool also_last)
+{
+    for (size_t i = 0; i < net.layers.size(); ++i) {
+        Layer &l = net.layers[i];
+        const bool is_head = (l.type == YL_YOLO || l.type == YL_REGION);
+        if (!(is_head || (also_last && i + 1 == net.layers.size()))) continue;
+        if (!l.host_output) continue;
+        YL_HIP(hipMemcpyAsync(l.host_output, l.d_output, sizeof(float) * (size_t)net.batch * l.outputs,
+                              hipMemcpyDeviceToHost, (hipStream_t)net.stream));
+    }
+    YL_HIP(hipStreamSynchronize((hipStream_t)net.stream));
+    return YL_OK;
+}
+
+}  // namespace yl
+
+// ====================================================================== C-ABI
+using namespace yl;
+
+extern "C" {
+
+const char *yl_last_error(void) { return g_err.c_str(); }
+
+int yl_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int yl_network_create_from_cfg(const char *cfg_path, int batch, int quantized, yl_network **out)
+{
+    if (!cfg_path || !out) { set_error("null argument"); return YL_ERR_ARG; }
+    yl_network *n = new yl_network();
+    int rc = parse_cfg_file(cfg_path, batch, quantized, n->net);
+    if (rc != YL_OK) { delete n; return rc; }
+    *out = n;
+    return YL_OK;
+}
+
+int yl_network_create_from_desc(const yl_layer_desc *layers, int n_layers, int batch, int w, int h, int c,
+                                int quantized, const float *input_calibration, int input_calibration_size,
+                                yl_network **out)
+{
+    if (!layers || n_layers <= 0 || !out || batch <= 0) { set_error("bad argument"); return YL_ERR_ARG; }
+    yl_network *n = new yl_network();
+    Network &net = n->net;
+    net.batch = batch; net.w = w; net.h = h; net.c = c; net.quantized = quantized;
+    if (input_calibration && input_calibration_size > 0)
+        net.input_calibration.assign(input_calibration, input_calibration + input_calibration_size);
+    for (int i = 0; i < n_layers; ++i) {
+        const yl_layer_desc &d = layers[i];
+        Layer l;
+        l.type = d.type; l.activation = d.activation;
+        l.batch = batch; l.w = d.w; l.h = d.h; l.c = d.c; l.n = d.n;
+        l.size = d.size; l.stride = d.stride; l.pad = d.pad;
+        l.out_w = d.out_w; l.out_h = d.out_h; l.out_c = d.out_c;
+        l.outputs = d.outputs; l.inputs = d.inputs;
+        l.batch_normalize = d.batch_normalize; l.xnor = d.xnor; l.index = d.index;
+        l.classes = d.classes; l.coords = d.coords ? d.coords : 4; l.total = d.total; l.softmax = d.softmax;
+        l.scale = d.scale;
+        l.host_output = d.output;
+        switch (d.type) {
+        case YL_CONVOLUTIONAL: {
+            if (!d.weights || !d.biases) { delete n; set_error("conv layer without weights/biases"); return YL_ERR_ARG; }
+            const size_t nw = (size_t)d.n * d.c * d.size * d.size;
+            l.weights.assign(d.weights, d.weights + nw);
+            l.biases.assign(d.biases, d.biases + d.n);
+            if (d.batch_normalize) {
+                if (!d.scales || !d.rolling_mean || !d.rolling_variance) { delete n; set_error("BN layer without statistics"); return YL_ERR_ARG; }
+                l.scales.assign(d.scales, d.scales + d.n);
+                l.rolling_mean.assign(d.rolling_mean, d.rolling_mean + d.n);
+                l.rolling_variance.assign(d.rolling_variance, d.rolling_variance + d.n);
+            }
+            if (d.weights_int8) {
+                l.weights_int8.assign(d.weights_int8, d.weights_int8 + nw);
+                l.input_quant_multipler = d.input_quant_multipler;
+                l.weights_quant_multipler = d.weights_quant_multipler;
+                l.quant_ready = true;
+            }
+            if (d.mean_arr) { l.mean_arr.assign(d.mean_arr, d.mean_arr + d.n); l.xnor_ready = true; }
+            break;
+        }
+        case YL_ROUTE:
+            if (!d.input_layers || !d.input_sizes || d.n <= 0) { delete n; set_error("route without inputs"); return YL_ERR_ARG; }
+            l.input_layers.assign(d.input_layers, d.input_layers + d.n);
+            l.input_sizes.assign(d.input_sizes, d.input_sizes + d.n);
+            for (int k = 0; k < d.n; ++k)
+                if (d.input_layers[k] < 0 || d.input_layers[k] >= i) { delete n; set_error("route index out of range"); return YL_ERR_ARG; }
+            break;
+        case YL_SHORTCUT:
+            if (d.index < 0 || d.index >= i) { delete n; set_error("shortcut index out of range"); return YL_ERR_ARG; }
+            break;
+        case YL_YOLO:
+            if (!d.mask || !d.anchors) { delete n; set_error("yolo layer without mask/anchors"); return YL_ERR_ARG; }
+            l.mask.assign(d.mask, d.mask + d.n);
+            l.anchors.assign(d.anchors, d.anchors + (size_t)2 * d.total);
+            break;
+        case YL_REGION:
+            if (!d.anchors) { delete n; set_error("region layer without anchors"); return YL_ERR_ARG; }
+            l.anchors.assign(d.anchors, d.anchors + (size_t)2 * d.n);
+            l.total = d.n;
+            break;
+        case YL_MAXPOOL: case YL_UPSAMPLE: case YL_REORG:
+            break;
+        default:
+            delete n;
+            set_error("layer type is not on the hot path");
+            return YL_ERR_UNSUPPORTED;
+        }
+        net.layers.push_back(std::move(l));
+    }
+    net.weights_loaded = true;
+    select_conv_modes(net);
+    *out = n;
+    return YL_OK;
+}
+
+int yl_network_load_weights(yl_network *net, const char *weights_path)
+{
+    if (!net || !weights_path) { set_error("null argument"); return YL_ERR_ARG; }
+    return load_weights_file(net->net, weights_path);
+}
+
+int yl_network_fuse_conv_batchnorm(yl_network *net)
+{
+    if (!net) { set_error("null argument"); return YL_ERR_ARG; }
+    fuse_conv_batchnorm(net->net);
+    return YL_OK;
+}
+
+int yl_network_calculate_binary_weights(yl_network *net)
+{
+    if (!net) { set_error("null argument"); return YL_ERR_ARG; }
+    calculate_binary_weights(net->net);
+    return YL_OK;
+}
+
+int yl_network_quantize(yl_network *net)
+{
+    if (!net) { set_error("null argument"); return YL_ERR_ARG; }
+    quantize_network(net->net);
+    return YL_OK;
+}
+
+void yl_network_destroy(yl_network *net)
+{
+    if (!net) return;
+    if (net->net.on_device || net->net.stream) free_device(net->net);
+    delete net;
+}
+
+int yl_network_num_layers(const yl_network *net) { return net ? (int)net->net.layers.size() : YL_ERR_ARG; }
+int yl_network_batch(const yl_network *net) { return net ? net->net.batch : YL_ERR_ARG; }
+
+int yl_network_input_dims(const yl_network *net, int *dims)
+{
+    if (!net || !dims) { set_error("null argument"); return YL_ERR_ARG; }
+    dims[0] = net->net.w; dims[1] = net->net.h; dims[2] = net->net.c;
+    return YL_OK;
+}
+
+#define YL_LAYER_OR(ret)                                                                \
+    if (!net || i < 0 || i >= (int)net->net.layers.size()) { set_error("bad layer index"); return ret; } \
+    const Layer &l = net->net.layers[i];
+
+int yl_network_layer_info(const yl_network *net, int i, int *info)
+{
+    YL_LAYER_OR(YL_ERR_ARG)
+    if (!info) { set_error("null argument"); return YL_ERR_ARG; }
+    info[0] = l.type; info[1] = l.batch; info[2] = l.w; info[3] = l.h; info[4] = l.c; info[5] = l.n;
+    info[6] = l.size; info[7] = l.stride; info[8] = l.pad; info[9] = l.out_w; info[10] = l.out_h;
+    info[11] = l.out_c; info[12] = l.outputs; info[13] = l.inputs; info[14] = l.activation;
+    info[15] = l.xnor; info[16] = (l.type == YL_CONVOLUTIONAL && l.conv_mode == CONV_INT8) ? 1 : 0;
+    info[17] = l.index; info[18] = l.classes; info[19] = l.coords; info[20] = l.total;
+    info[21] = l.softmax; info[22] = (l.type == YL_CONVOLUTIONAL) ? l.conv_mode : 0; info[23] = l.batch_normalize;
+    return YL_OK;
+}
+
+const float *yl_network_layer_weights(const yl_network *net, int i) { YL_LAYER_OR(nullptr) return l.weights.empty() ? nullptr : l.weights.data(); }
+const float *yl_network_layer_biases(const yl_network *net, int i) { YL_LAYER_OR(nullptr) return l.biases.empty() ? nullptr : l.biases.data(); }
+const int8_t *yl_network_layer_weights_int8(const yl_network *net, int i) { YL_LAYER_OR(nullptr) return l.weights_int8.empty() ? nullptr : l.weights_int8.data(); }
+const float *yl_network_layer_mean_arr(const yl_network *net, int i) { YL_LAYER_OR(nullptr) return l.mean_arr.empty() ? nullptr : l.mean_arr.data(); }
+
+int yl_network_layer_quant_multipliers(const yl_network *net, int i, float *mult)
+{
+    YL_LAYER_OR(YL_ERR_ARG)
+    if (!mult) { set_error("null argument"); return YL_ERR_ARG; }
+    mult[0] = l.input_quant_multipler; mult[1] = l.weights_quant_multipler;
+    return YL_OK;
+}
+
+double yl_network_flops_per_image(const yl_network *net)
+{
+    if (!net) return 0.0;
+    double f = 0.0;
+    for (const Layer &l : net->net.layers)
+        if (l.type == YL_CONVOLUTIONAL) f += 2.0 * l.n * l.size * l.size * l.c * (double)l.out_h * l.out_w;
+    return f;
+}
+
+int yl_network_set_debug(yl_network *net, int on)
+{
+    if (!net) { set_error("null argument"); return YL_ERR_ARG; }
+    if (net->net.on_device) { set_error("set_debug must precede to_device"); return YL_ERR_STATE; }
+    net->net.debug = on != 0;
+    return YL_OK;
+}
+
+int yl_network_to_device(yl_network *net, int device)
+{
+    if (!net) { set_error("null argument"); return YL_ERR_ARG; }
+    int rc = to_device(net->net, device);
+    if (rc != YL_OK) free_device(net->net);
+    return rc;
+}
+
+int yl_network_set_stream(yl_network *net, void *hip_stream)
+{
+    if (!net) { set_error("null argument"); return YL_ERR_ARG; }
+    Network &n = net->net;
+    if (hip_stream == nullptr) {
+        if (!n.own_stream) {
+            if (n.device >= 0) YL_HIP(hipSetDevice(n.device));
+            hipStream_t s;
+            YL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+            n.stream = s; n.own_stream = true;
+        }
+        return YL_OK;
+    }
+    if (n.own_stream && n.stream) { (void)hipStreamSynchronize((hipStream_t)n.stream); (void)hipStreamDestroy((hipStream_t)n.stream); }
+    n.stream = hip_stream; n.own_stream = false;
+    return YL_OK;
+}
+
+int yl_network_synchronize(yl_network *net)
+{
+    if (!net || !net->net.on_device) { set_error("network not on device"); return YL_ERR_STATE; }
+    YL_HIP(hipSetDevice(net->net.device));
+    YL_HIP(hipStreamSynchronize((hipStream_t)net->net.stream));
+    return YL_OK;
+}
+
+int yl_network_forward(yl_network *net, const float *input_dev)
+{
+    if (!net || !input_dev) { set_error("null argument"); return YL_ERR_ARG; }
+    return forward(net->net, input_dev, false);
+}
+
+float *yl_network_predict(yl_network *net, const float *input)
+{
+    if (!net || !input) { set_error("null argument"); return nullptr; }
+    Network &n = net->net;
+    if (!n.on_device) { set_error("network not on device: call yl_network_to_device first"); return nullptr; }
+    if (hipSetDevice(n.device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
+    memcpy(n.h_pinned, input, n.pinned_bytes);
+    if (hipMemcpyAsync(n.d_input, n.h_pinned, n.pinned_bytes, hipMemcpyHostToDevice, (hipStream_t)n.stream) != hipSuccess) {
+        set_error("H2D input copy failed");
+        return nullptr;
+    }
+    if (forward(n, n.d_input, false) != YL_OK) return nullptr;
+    if (pull_heads(n, true) != YL_OK) return nullptr;
+    // last non-COST layer (src/yolov2_forward_network.c:644-645); COST never parses here
+    return n.layers.back().host_output;
+}
+
+int yl_network_pull_heads(yl_network *net)
+{
+    if (!net || !net->net.on_device) { set_error("network not on device"); return YL_ERR_STATE; }
+    YL_HIP(hipSetDevice(net->net.device));
+    return pull_heads(net->net, true);
+}
+
+int yl_network_layer_output(yl_network *net, int i, float *dst_host)
+{
+    YL_LAYER_OR(YL_ERR_ARG)
+    if (!dst_host || !net->net.on_device) { set_error("bad argument / not on device"); return YL_ERR_STATE; }
+    YL_HIP(hipSetDevice(net->net.device));
+    YL_HIP(hipStreamSynchronize((hipStream_t)net->net.stream));
+    YL_HIP(hipMemcpy(dst_host, l.d_output, sizeof(float) * (size_t)net->net.batch * l.outputs, hipMemcpyDeviceToHost));
+    return YL_OK;
+}
+
+const float *yl_network_layer_output_dev(const yl_network *net, int i) { YL_LAYER_OR(nullptr) return l.d_output; }
+
+float *yl_network_input_dev(yl_network *net) { return net ? net->net.d_input : nullptr; }
+
+static int pull_debug(yl_network *net, int i, int32_t *dst, int want_mode)
+{
+    YL_LAYER_OR(YL_ERR_ARG)
+    if (!dst || !net->net.on_device) { set_error("bad argument / not on device"); return YL_ERR_STATE; }
+    if (l.type != YL_CONVOLUTIONAL || l.conv_mode != want_mode || !l.d_debug) {
+        set_error("layer has no debug tensor of this kind (set_debug before to_device?)");
+        return YL_ERR_STATE;
+    }
+    YL_HIP(hipSetDevice(net->net.device));
+    YL_HIP(hipStreamSynchronize((hipStream_t)net->net.stream));
+    YL_HIP(hipMemcpy(dst, l.d_debug, sizeof(int32_t) * (size_t)net->net.batch * l.outputs, hipMemcpyDeviceToHost));
+    return YL_OK;
+}
+
+int yl_network_layer_xnor_counts(yl_network *net, int i, int32_t *dst_host) { return pull_debug(net, i, dst_host, CONV_XNOR); }
+int yl_network_layer_int8_acc(yl_network *net, int i, int32_t *dst_host) { return pull_debug(net, i, dst_host, CONV_INT8); }
+
+int yl_network_profile(yl_network *net, const float *input_dev, int iters, float *ms_per_layer, float *total_ms)
+{
+    if (!net || !input_dev || iters <= 0) { set_error("bad argument"); return YL_ERR_ARG; }
+    Network &n = net->net;
+    if (!n.on_device) { set_error("network not on device"); return YL_ERR_STATE; }
+    YL_HIP(hipSetDevice(n.device));
+    const size_t nl = n.layers.size();
+    while (n.layer_events.size() < nl + 1) {
+        hipEvent_t e;
+        YL_HIP(hipEventCreate(&e));
+        n.layer_events.push_back(e);
+    }
+    std::vector<double> acc(nl, 0.0);
+    double tot = 0.0;
+    for (int it = 0; it < iters; ++it) {
+        int rc = forward(n, input_dev, true);
+        if (rc != YL_OK) return rc;
+        YL_HIP(hipEventSynchronize((hipEvent_t)n.layer_events[nl]));
+        for (size_t i = 0; i < nl; ++i) {
+            float ms = 0.f;
+            YL_HIP(hipEventElapsedTime(&ms, (hipEvent_t)n.layer_events[i], (hipEvent_t)n.layer_events[i + 1]));
+            acc[i] += ms;
+        }
+        float ms = 0.f;
+        YL_HIP(hipEventElapsedTime(&ms, (hipEvent_t)n.layer_events[0], (hipEvent_t)n.layer_events[nl]));
+        tot += ms;
+    }
+    if (ms_per_layer) for (size_t i = 0; i < nl; ++i) ms_per_layer[i] = (float)(acc[i] / iters);
+    if (total_ms) *total_ms = (float)(tot / iters);
+    return YL_OK;
+}
+
+int yl_network_get_boxes(yl_network *net, int image, int w, int h, float thresh, int relative, int letter,
+                         float nms, float *rows, int max_rows, int *classes_out)
+{
+    if (!net) { set_error("null argument"); return YL_ERR_ARG; }
+    return get_boxes_host(net->net, image, w, h, thresh, relative, letter, nms, rows, max_rows, classes_out);
+}
+
+int yl_network_compact_detections(yl_network *net, float thresh, int cap, float *records_dev, int *counts_dev)
+{
+    if (!net || !records_dev || !counts_dev || cap <= 0) { set_error("bad argument"); return YL_ERR_ARG; }
+    Network &n = net->net;
+    if (!n.on_device) { set_error("network not on device"); return YL_ERR_STATE; }
+    YL_HIP(hipSetDevice(n.device));
+    HeadDesc heads[4];
+    int nh = 0;
+    const int classes = n.layers.back().classes;
+    for (const Layer &l : n.layers) {
+        if (l.type != YL_YOLO && l.type != YL_REGION) continue;
+        if (nh == 4 || l.n > 16) { set_error("too many heads/anchors for compaction"); return YL_ERR_UNSUPPORTED; }
+        if (l.classes != classes) { set_error("heads disagree on classes"); return YL_ERR_UNSUPPORTED; }
+        HeadDesc &h = heads[nh++];
+        h.out = l.d_output; h.type = l.type; h.w = l.w; h.h = l.h; h.n = l.n; h.classes = l.classes; h.outputs = l.outputs;
+        for (int k = 0; k < l.n; ++k) {
+            const int an = (l.type == YL_YOLO) ? l.mask[k] : k;
+            h.anchors_w[k] = l.anchors[2 * an];
+            h.anchors_h[k] = l.anchors[2 * an + 1];
+        }
+    }
+    if (nh == 0) { set_error("network has no detection head"); return YL_ERR_STATE; }
+    YL_LAUNCH(launch_compact(heads, nh, n.batch, n.w, n.h, thresh, cap, 6 + classes, records_dev, counts_dev, n.stream),
+              "compact");
+    return YL_OK;
+}
+
+}  // extern "C"

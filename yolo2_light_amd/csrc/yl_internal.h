@@ -1,0 +1,100 @@
+// yl_internal.h -- host-side model representation shared by the cfg/prep code
+// (plain C++) and the HIP runtime.  Field names follow the reference's `layer`
+// (src/additionally.h:409-684) where the meaning is the same.
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <string>
+#include <vector>
+
+#include "../../include/yolo2_hip.h"
+
+namespace yl {
+
+// which convolution implementation a CONVOLUTIONAL layer runs with
+enum ConvMode { CONV_F32 = 0, CONV_INT8 = 1, CONV_XNOR = 2 };
+
+struct Layer {
+    int type = YL_BLANK;
+    int activation = YL_LINEAR;
+    int batch = 0, w = 0, h = 0, c = 0;
+    int n = 0, size = 0, stride = 1, pad = 0;
+    int out_w = 0, out_h = 0, out_c = 0;
+    int outputs = 0, inputs = 0;
+    int batch_normalize = 0, xnor = 0;
+    int index = 0;                       // shortcut `from`
+    std::vector<int> input_layers, input_sizes;   // route
+    int classes = 0, coords = 4, total = 0, softmax = 0;
+    std::vector<int> mask;
+    std::vector<float> anchors;
+    float scale = 1.f;
+
+    // conv parameters (host)
+    std::vector<float> weights, biases, scales, rolling_mean, rolling_variance;
+    std::vector<int8_t> weights_int8;
+    float input_quant_multipler = 0.f, weights_quant_multipler = 0.f;
+    bool quant_ready = false;
+    std::vector<float> mean_arr;         // xnor: per-filter mean(|w|)
+    bool xnor_ready = false;
+    int conv_mode = CONV_F32;
+
+    float *host_output = nullptr;        // borrowed (desc.output) or owned (host_output_own)
+    std::vector<float> host_output_own;
+
+    // ---- device state (owned by runtime.hip) ----
+    float *d_output = nullptr;           // [batch][out_c][out_h][out_w]
+    bool  d_output_alias = false;        // route with one input aliases its source
+    float *d_weights_t = nullptr;        // FP32: k-major packed [Kpad][Mpad]
+    float *d_biases = nullptr;
+    int   Kpad = 0, Mpad = 0;
+    int8_t *d_weights_i8 = nullptr;      // INT8: [Mpad][taps][Cpad] (channel-fastest)
+    int   Cpad = 0;
+    uint64_t *d_weights_bits = nullptr;  // XNOR: [Mpad][taps][Cw] 64-bit words
+    float *d_mean = nullptr;
+    int   Cw = 0;
+    int32_t *d_debug = nullptr;          // xnor counts / int8 acc (debug mode)
+};
+
+struct Network {
+    int batch = 1, w = 0, h = 0, c = 0;
+    int quantized = 0;
+    std::vector<float> input_calibration;
+    std::vector<Layer> layers;
+    bool weights_loaded = false;
+
+    // device
+    int device = -1;
+    bool on_device = false;
+    bool debug = false;
+    void *stream = nullptr;              // hipStream_t
+    bool own_stream = false;
+    float *d_input = nullptr;
+    int8_t *d_qbuf = nullptr;            // INT8: quantised NHWC activations scratch
+    size_t qbuf_bytes = 0;
+    uint64_t *d_bitbuf = nullptr;        // XNOR: channel-packed sign bits scratch
+    size_t bitbuf_bytes = 0;
+    void *h_pinned = nullptr;            // pinned staging for the input
+    size_t pinned_bytes = 0;
+    void *ev0 = nullptr, *ev1 = nullptr; // hipEvent_t pair for profiling
+    std::vector<void *> layer_events;
+};
+
+void set_error(const std::string &msg);
+
+// host_cfg.cpp
+int parse_cfg_file(const char *path, int batch, int quantized, Network &net);
+// host_prep.cpp
+int load_weights_file(Network &net, const char *path);
+void fuse_conv_batchnorm(Network &net);
+void calculate_binary_weights(Network &net);
+void quantize_network(Network &net);
+void select_conv_modes(Network &net);
+// host_detect.cpp
+int get_boxes_host(Network &net, int image, int w, int h, float thresh, int relative,
+                   int letter, float nms, float *rows, int max_rows, int *classes_out);
+
+}  // namespace yl
+
+struct yl_network {
+    yl::Network net;
+};

@@ -1,0 +1,232 @@
+"""Host-side mirror of the reference's network API for the hot path, on top of
+the C-ABI.  Names follow the reference (src/additionally.h:907-969, src/main.c:156-229):
+
+    net = Network.from_cfg(cfg, batch, quantized)      # parse_network_cfg
+    net.load_weights(path)                             # load_weights_upto_cpu
+    net.fuse_conv_batchnorm()                          # yolov2_fuse_conv_batchnorm
+    net.calculate_binary_weights()                     # calculate_binary_weights
+    net.quantize()                                     # quantinization_and_get_multipliers
+    net.to_device(0)
+    out = net.predict(images)                          # network_predict_gpu_cudnn[_quantized]
+    dets = net.get_boxes(image, w, h, thresh, nms=.4)  # get_network_boxes + do_nms_sort
+
+Python is plumbing only: all arithmetic happens in libyolo2hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import YoloHipError, check, lib
+
+LAYER_TYPES = {0: "conv", 3: "maxpool", 8: "route", 13: "shortcut", 21: "region", 22: "yolo",
+               23: "upsample", 24: "reorg", 25: "blank"}
+INFO_FIELDS = ("type", "batch", "w", "h", "c", "n", "size", "stride", "pad", "out_w", "out_h", "out_c",
+               "outputs", "inputs", "activation", "xnor", "int8", "index", "classes", "coords", "total",
+               "softmax", "conv_mode", "batch_normalize")
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(_lib.c_float_p)
+
+
+class Network:
+    def __init__(self, handle: C.c_void_p):
+        self._h = handle
+        self._on_device = False
+
+    # ------------------------------------------------------------ build
+    @classmethod
+    def from_cfg(cls, cfg_path: str, batch: int = 1, quantized: int = 0) -> "Network":
+        h = C.c_void_p()
+        check(lib.yl_network_create_from_cfg(cfg_path.encode(), batch, quantized, C.byref(h)),
+              "yl_network_create_from_cfg")
+        return cls(h)
+
+    @classmethod
+    def from_desc(cls, descs, batch: int, w: int, h: int, c: int, quantized: int = 0,
+                  input_calibration: Optional[np.ndarray] = None) -> "Network":
+        arr = (_lib.LayerDesc * len(descs))(*descs)
+        hd = C.c_void_p()
+        ic = None
+        n_ic = 0
+        if input_calibration is not None and len(input_calibration):
+            ic_arr = np.ascontiguousarray(input_calibration, dtype=np.float32)
+            ic, n_ic = _fp(ic_arr), len(ic_arr)
+        check(lib.yl_network_create_from_desc(arr, len(descs), batch, w, h, c, quantized, ic, n_ic, C.byref(hd)),
+              "yl_network_create_from_desc")
+        return cls(hd)
+
+    @classmethod
+    def load(cls, cfg_path: str, weights_path: str, batch: int = 1, quantized: int = 0,
+             device: Optional[int] = None, debug: bool = False) -> "Network":
+        """The full prep sequence of test_detector_cpu (src/main.c:160-171)."""
+        net = cls.from_cfg(cfg_path, batch, quantized)
+        net.load_weights(weights_path)
+        net.fuse_conv_batchnorm()
+        net.calculate_binary_weights()
+        if quantized:
+            net.quantize()
+        if debug:
+            check(lib.yl_network_set_debug(net._h, 1), "yl_network_set_debug")
+        if device is not None:
+            net.to_device(device)
+        return net
+
+    def load_weights(self, path: str) -> None:
+        check(lib.yl_network_load_weights(self._h, path.encode()), "yl_network_load_weights")
+
+    def fuse_conv_batchnorm(self) -> None:
+        check(lib.yl_network_fuse_conv_batchnorm(self._h), "yl_network_fuse_conv_batchnorm")
+
+    def calculate_binary_weights(self) -> None:
+        check(lib.yl_network_calculate_binary_weights(self._h), "yl_network_calculate_binary_weights")
+
+    def quantize(self) -> None:
+        check(lib.yl_network_quantize(self._h), "yl_network_quantize")
+
+    def close(self) -> None:
+        if self._h:
+            lib.yl_network_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------ introspection
+    @property
+    def n(self) -> int:
+        return lib.yl_network_num_layers(self._h)
+
+    @property
+    def batch(self) -> int:
+        return lib.yl_network_batch(self._h)
+
+    @property
+    def input_dims(self):
+        d = (C.c_int * 3)()
+        check(lib.yl_network_input_dims(self._h, d), "yl_network_input_dims")
+        return d[0], d[1], d[2]          # w, h, c
+
+    def layer_info(self, i: int) -> dict:
+        info = (C.c_int * 24)()
+        check(lib.yl_network_layer_info(self._h, i, info), "yl_network_layer_info")
+        return dict(zip(INFO_FIELDS, list(info)))
+
+    def layers(self) -> List[dict]:
+        return [self.layer_info(i) for i in range(self.n)]
+
+    def _arr(self, ptr, n, dtype):
+        if not ptr:
+            return None
+        return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+    def layer_weights(self, i: int):
+        li = self.layer_info(i)
+        return self._arr(lib.yl_network_layer_weights(self._h, i), li["n"] * li["c"] * li["size"] ** 2, np.float32)
+
+    def layer_biases(self, i: int):
+        return self._arr(lib.yl_network_layer_biases(self._h, i), self.layer_info(i)["n"], np.float32)
+
+    def layer_weights_int8(self, i: int):
+        li = self.layer_info(i)
+        return self._arr(lib.yl_network_layer_weights_int8(self._h, i), li["n"] * li["c"] * li["size"] ** 2, np.int8)
+
+    def layer_mean_arr(self, i: int):
+        return self._arr(lib.yl_network_layer_mean_arr(self._h, i), self.layer_info(i)["n"], np.float32)
+
+    def layer_quant_multipliers(self, i: int):
+        m = (C.c_float * 2)()
+        check(lib.yl_network_layer_quant_multipliers(self._h, i, m), "yl_network_layer_quant_multipliers")
+        return float(m[0]), float(m[1])
+
+    @property
+    def flops_per_image(self) -> float:
+        return lib.yl_network_flops_per_image(self._h)
+
+    # ------------------------------------------------------------ device
+    def to_device(self, device: int = 0) -> None:
+        check(lib.yl_network_to_device(self._h, device), "yl_network_to_device")
+        self._on_device = True
+
+    def set_stream(self, stream_ptr: int) -> None:
+        check(lib.yl_network_set_stream(self._h, C.c_void_p(stream_ptr)), "yl_network_set_stream")
+
+    def synchronize(self) -> None:
+        check(lib.yl_network_synchronize(self._h), "yl_network_synchronize")
+
+    def predict(self, images: np.ndarray) -> np.ndarray:
+        """images: float32 [batch, c, h, w] in [0,1]; returns the last layer's output (a copy)."""
+        w, h, c = self.input_dims
+        x = np.ascontiguousarray(images, dtype=np.float32)
+        if x.size != self.batch * c * h * w:
+            raise ValueError("input has %d elements, network wants %d" % (x.size, self.batch * c * h * w))
+        p = lib.yl_network_predict(self._h, _fp(x))
+        if not p:
+            raise YoloHipError("yl_network_predict failed: " + _lib.last_error())
+        last = self.layer_info(self.n - 1)
+        return np.ctypeslib.as_array(p, shape=(self.batch * last["outputs"],)).copy()
+
+    def forward_device(self, input_dev_ptr: int) -> None:
+        check(lib.yl_network_forward(self._h, C.c_void_p(input_dev_ptr)), "yl_network_forward")
+
+    @property
+    def input_dev(self) -> int:
+        return lib.yl_network_input_dev(self._h)
+
+    def layer_output_dev(self, i: int) -> int:
+        return lib.yl_network_layer_output_dev(self._h, i)
+
+    def layer_output(self, i: int) -> np.ndarray:
+        li = self.layer_info(i)
+        out = np.empty(self.batch * li["outputs"], dtype=np.float32)
+        check(lib.yl_network_layer_output(self._h, i, _fp(out)), "yl_network_layer_output")
+        return out
+
+    def layer_xnor_counts(self, i: int) -> np.ndarray:
+        li = self.layer_info(i)
+        out = np.empty(self.batch * li["outputs"], dtype=np.int32)
+        check(lib.yl_network_layer_xnor_counts(self._h, i, out.ctypes.data_as(_lib.c_int32_p)),
+              "yl_network_layer_xnor_counts")
+        return out
+
+    def layer_int8_acc(self, i: int) -> np.ndarray:
+        li = self.layer_info(i)
+        out = np.empty(self.batch * li["outputs"], dtype=np.int32)
+        check(lib.yl_network_layer_int8_acc(self._h, i, out.ctypes.data_as(_lib.c_int32_p)),
+              "yl_network_layer_int8_acc")
+        return out
+
+    def profile(self, input_dev_ptr: int, iters: int = 5):
+        ms = np.zeros(self.n, dtype=np.float32)
+        tot = C.c_float(0)
+        check(lib.yl_network_profile(self._h, C.c_void_p(input_dev_ptr), iters, _fp(ms), C.byref(tot)),
+              "yl_network_profile")
+        return ms, float(tot.value)
+
+    # ------------------------------------------------------------ detections
+    def pull_heads(self) -> None:
+        check(lib.yl_network_pull_heads(self._h), "yl_network_pull_heads")
+
+    def get_boxes(self, image: int, w: int, h: int, thresh: float, nms: float = 0.0,
+                  relative: int = 1, letter: int = 0, max_rows: int = 4096) -> np.ndarray:
+        classes = C.c_int(0)
+        # first call sizes the result
+        n = lib.yl_network_get_boxes(self._h, image, w, h, thresh, relative, letter, nms, None, 0, C.byref(classes))
+        if n < 0:
+            raise YoloHipError("yl_network_get_boxes failed: " + _lib.last_error())
+        rows = np.zeros((max(n, 1), 6 + classes.value), dtype=np.float32)
+        n2 = lib.yl_network_get_boxes(self._h, image, w, h, thresh, relative, letter, nms, _fp(rows), n, C.byref(classes))
+        if n2 < 0:
+            raise YoloHipError("yl_network_get_boxes failed: " + _lib.last_error())
+        return rows[:n]
+
+    def compact_detections(self, thresh: float, cap: int, records_dev_ptr: int, counts_dev_ptr: int) -> None:
+        check(lib.yl_network_compact_detections(self._h, thresh, cap, C.c_void_p(records_dev_ptr),
+                                                C.c_void_p(counts_dev_ptr)), "yl_network_compact_detections")

@@ -1,0 +1,56 @@
+"""Synthetic darknet ``.weights`` writer.
+
+No pretrained weights exist offline, and without a weights file the
+reference leaves BN variance at 0 so fusing multiplies weights by 1e6
+(src/additionally.c:87,2809).  Every parity and bench run therefore uses a
+deterministic synthetic file in exactly the format
+``load_weights_upto_cpu`` / ``load_convolutional_weights_cpu`` read
+(src/additionally.c:3491-3529, 3459-3468):
+
+    int32 major, minor, revision ; uint64 seen (major*10+minor >= 2)
+    per CONVOLUTIONAL layer, in order:
+        biases[n] ; if batch_normalize: scales[n], rolling_mean[n], rolling_variance[n]
+        weights[n*c*size*size]                     all float32 little-endian
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+from .zoo import conv_shapes
+
+
+def write_synthetic_weights(cfg_text: str, path: str, seed: int = 1, obj_bias: float = -4.0) -> int:
+    """Write a synthetic weights file for the network described by cfg_text.
+
+    bias ~ N(0, .1), scales ~ U(.5, 1.5), mean ~ N(0, .1), var ~ U(.5, 1.5),
+    w ~ N(0, sqrt(2/K)) (He), fixed seed; the objectness channel of every
+    detection-head conv gets `obj_bias` added so that only some boxes pass the
+    0.24 threshold.  Returns the number of float32 values written.
+    """
+    rng = np.random.default_rng(seed)
+    total = 0
+    with open(path, "wb") as f:
+        f.write(struct.pack("<iii", 0, 2, 0))
+        f.write(struct.pack("<Q", 0))
+        for cv in conv_shapes(cfg_text):
+            n, c, size = cv["n"], cv["c"], cv["size"]
+            k = c * size * size
+            bias = rng.normal(0.0, 0.1, n).astype(np.float32)
+            if cv["head_anchors"]:
+                per = 5 + cv["head_classes"]
+                for a in range(cv["head_anchors"]):
+                    if a * per + 4 < n:
+                        bias[a * per + 4] += np.float32(obj_bias)
+            bias.astype("<f4").tofile(f)
+            total += n
+            if cv["bn"]:
+                rng.uniform(0.5, 1.5, n).astype("<f4").tofile(f)
+                rng.normal(0.0, 0.1, n).astype("<f4").tofile(f)
+                rng.uniform(0.5, 1.5, n).astype("<f4").tofile(f)
+                total += 3 * n
+            w = rng.normal(0.0, np.sqrt(2.0 / k), n * k).astype("<f4")
+            w.tofile(f)
+            total += n * k
+    return total
