@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the YOLO inference hot path on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched with torch.distributed.run, one rank per GPU (RCCL).
+A "step" = one pass of the hot path over one batch of synthetic images that
+are already resident in HBM: forward of every layer (FP32 MFMA conv + small
+layers) -> on-device detection compaction -> (N>1) RCCL all-gather of the
+fixed-capacity detection records to every rank.
+Default workload = BASELINE.json's metric config: yolov3.cfg 608x608,
+batch 64 per GPU, FP32, synthetic weights/images (no datasets or checkpoints
+exist offline).  Scaling is weak: the path shards by independent images, each
+rank owns `--batch` images and the replicated weights.
+
+Rank 0 prints ONE JSON line with the driver's fields plus
+  "roofline"     -- dominant kernel (the FP32 MFMA implicit-GEMM conv instance that
+                    carries most FLOPs): algorithmic FLOPs of its launches / their
+                    HIP-event-measured duration inside the timed region, vs the
+                    157.3 TFLOP/s FP32-matrix peak (MI355X_MICROARCH.md)
+  "cpu_baseline" -- the reference's own CPU path (oracle/_ref, its fastest documented
+                    build AVX+OpenMP) timed on this host, N=1 / rank 0 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="yolov3", choices=["yolov3", "yolov3-tiny", "tiny-yolo-xnor"])
+    ap.add_argument("--size", type=int, default=608)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--mode", default="fp32", choices=["fp32", "int8"])
+    ap.add_argument("--thresh", type=float, default=0.24)
+    ap.add_argument("--cap", type=int, default=1024, help="detection records per image")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--layers", action="store_true", help="also print a per-layer table to stderr")
+    ap.add_argument("--tile", type=int, default=0, help="force K1 tile config (tuning)")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg: str, wts: str, width: int, height: int, quantized: int, budget_s: float):
+    """Reference CPU path (oracle/_ref/libyolo2ref_fast.so: `make AVX=1 OPENMP=1` flags) on B=1."""
+    from oracle import refbind
+    flags = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    flags = line
+                    break
+    except OSError:
+        pass
+    fast = refbind.available(fast=True) and (" avx2 " in flags + " ") and (" fma " in flags + " ")
+    if not fast and not refbind.available():
+        return None
+    ref = refbind.RefNetwork(cfg, wts, 1, quantized, fast=fast)
+    x = np.random.default_rng(2222222).random((1, 3, height, width), dtype=np.float32)
+    t_warm = ref.time_predict(x, 1)
+    iters = max(1, min(20, int(budget_s / max(t_warm, 1e-3))))
+    t = ref.time_predict(x, iters)
+    cores = os.cpu_count() if fast else 1
+    return {
+        "value": iters / t, "unit": "images/sec", "cores": cores, "kind": "reference",
+        "sample": "%d image(s) of the same workload at batch 1 through network_predict_%s of the reference "
+                  "(%s build), wall clock %.2f s" % (iters, "quantized" if quantized else "cpu",
+                                                     "AVX=1 OPENMP=1" if fast else "scalar -O2", t),
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from yolo2_light_amd import Network, weights, zoo
+    from yolo2_light_amd._lib import lib
+
+    quantized = 1 if args.mode == "int8" else 0
+    work = tempfile.mkdtemp(prefix="yl_bench_r%d_" % rank)
+    cfg = zoo.write_cfg(args.model, work, args.size, args.size)
+    wts = os.path.join(work, "synthetic.weights")
+    with open(cfg) as f:
+        weights.write_synthetic_weights(f.read(), wts, seed=1)
+    net = Network.load(cfg, wts, args.batch, quantized, device=local_rank)
+    # one explicit (non-default) HIP stream shared by our kernels and torch/RCCL so the
+    # compaction -> all-gather dependency is ordinary stream order
+    stream = torch.cuda.Stream(device=dev)
+    net.set_stream(stream.cuda_stream)
+    if args.tile:
+        lib.yl_debug_force_conv_tile(args.tile)
+
+    B = args.batch
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2222222 + rank)
+    x = torch.rand((B, 3, args.size, args.size), generator=gen, device=dev, dtype=torch.float32)
+    last = net.layer_info(net.n - 1)
+    classes = last["classes"]
+    rec = torch.zeros((B, args.cap, 6 + classes), device=dev, dtype=torch.float32)
+    cnt = torch.zeros((B,), device=dev, dtype=torch.int32)
+    if world > 1:
+        rec_all = torch.zeros((world, B, args.cap, 6 + classes), device=dev, dtype=torch.float32)
+        cnt_all = torch.zeros((world, B), device=dev, dtype=torch.int32)
+
+    n_layers = net.n
+    layer_ms = np.zeros(n_layers, dtype=np.float64)
+
+    def step(timed: bool):
+        with torch.cuda.stream(stream):
+            net.forward_timed(x.data_ptr())
+            net.compact_detections(args.thresh, args.cap, rec.data_ptr(), cnt.data_ptr())
+            if world > 1:
+                dist.all_gather_into_tensor(rec_all, rec)
+                dist.all_gather_into_tensor(cnt_all, cnt)
+        if timed:
+            ms, _ = net.layer_times()          # waits for this step's last layer event
+            layer_ms[:] += ms
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---------------- roofline of the dominant kernel (rank-local measurement) -------------
+    infos = net.layers()
+    kern = {}
+    for i, li in enumerate(infos):
+        if li["type"] != 0:
+            continue
+        name = net.layer_kernel(i)
+        flops = 2.0 * li["n"] * li["size"] ** 2 * li["c"] * li["out_h"] * li["out_w"] * B
+        k = kern.setdefault(name, {"flops": 0.0, "ms": 0.0, "launches": 0})
+        k["flops"] += flops
+        k["ms"] += layer_ms[i] / args.steps
+        k["launches"] += 1
+    dom_name = max(kern, key=lambda n: kern[n]["flops"])
+    dom = kern[dom_name]
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+    conv_ms = sum(k["ms"] for k in kern.values())
+    conv_flops = sum(k["flops"] for k in kern.values())
+    other_ms = float(layer_ms.sum() / args.steps - conv_ms)
+    roofline = {
+        "bound": "mfma", "kernel": dom_name,
+        "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
+        "traffic": None,
+        "launches_per_step": dom["launches"],
+        "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
+        "all_conv_tflops": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
+        "conv_ms_per_step": conv_ms, "other_layers_ms_per_step": other_ms,
+        "by_kernel": {n: {"tflops": (k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0),
+                          "ms_per_step": k["ms"], "launches": k["launches"]} for n, k in kern.items()},
+    }
+
+    if rank == 0:
+        if args.layers:
+            for i, li in enumerate(infos):
+                print("%3d type=%2d %-28s %8.3f ms" % (i, li["type"], net.layer_kernel(i), layer_ms[i] / args.steps),
+                      file=sys.stderr)
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline(cfg, wts, args.size, args.size, quantized, args.cpu_seconds)
+            except Exception as e:      # the baseline is reported, never required
+                cpu = {"error": repr(e)}
+        total_images = world * B * args.steps
+        out = {
+            "metric": "images/sec (whole node) %s %dx%d batch %d %s" % (args.model, args.size, args.size, B,
+                                                                       args.mode.upper()),
+            "value": total_images / elapsed,
+            "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.mode == "fp32" else "i8", "data": "synthetic",
+            "config": {"workload": "%s.cfg %dx%d batch=%d/GPU %s, synthetic weights+images resident in HBM, "
+                                   "forward + on-device detection compaction%s" % (
+                                       args.model, args.size, args.size, B, args.mode.upper(),
+                                       " + RCCL all-gather of detections" if world > 1 else ""),
+                       "global_batch": world * B, "parallelism": "image-batch sharding x%d" % world,
+                       "gflop_per_image": net.flops_per_image / 1e9},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -191,6 +191,15 @@ int yl_network_layer_int8_acc(yl_network *net, int i, int32_t *dst_host);
  * (The reference only has clock() around predict, src/main.c:197,220.) */
 int yl_network_profile(yl_network *net, const float *input_dev, int iters,
                        float *ms_per_layer, float *total_ms);
+/* The same measurement without a host sync inside the pass: yl_network_forward with a HIP
+ * event recorded on the network's stream before every layer and after the last one;
+ * yl_network_layer_times waits for the last event and reads the elapsed times of the most
+ * recent timed forward. */
+int yl_network_forward_timed(yl_network *net, const float *input_dev);
+int yl_network_layer_times(yl_network *net, float *ms_per_layer, float *total_ms);
+/* name of the kernel (template instance) layer i's last launch used, e.g.
+ * "conv_f32_mfma<128x128,ks3>"; "" for layers that have not run or are pure aliases */
+const char *yl_network_layer_kernel(const yl_network *net, int i);
 
 /* ------------------------------------------------------------------ *
  *  Detections (L4).  The reference decodes batch item 0 only
@@ -210,6 +219,12 @@ int yl_network_get_boxes(yl_network *net, int image, int w, int h, float thresh,
 /* D2H of every YOLO/REGION layer output (what src/yolov2_forward_network_gpu.cu:438
  * does per YOLO layer) after a yl_network_forward. */
 int yl_network_pull_heads(yl_network *net);
+
+/* Tuning/test hook: force the K1 tile configuration used by every subsequent FP32
+ * conv launch in this process (0 = built-in heuristic; 1..8 see conv_f32_mfma.hip).
+ * yl_debug_last_conv_tile returns the name of the tile the last launch used. */
+int yl_debug_force_conv_tile(int cfg);
+const char *yl_debug_last_conv_tile(void);
 
 /* On-device detection compaction (new): threshold test
  * `objectness > thresh` (src/additionally.c:4341) and box decode

@@ -281,7 +281,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_f32_mfma_kernel(ConvF32Dev p)
 // host-side tile selection + launch
 // ------------------------------------------------------------------------
 static int g_force_tile = 0;
-static const char *g_last_tile = "";
+static char g_last_tile[64] = "";
+static void set_tile_name(const char *t, int ks) { snprintf(g_last_tile, sizeof(g_last_tile), "conv_f32_mfma<%s,ks%d>", t, ks); }
 void conv_f32_force_tile(int cfg) { g_force_tile = cfg; }
 const char *conv_f32_last_tile_name() { return g_last_tile; }
 
@@ -334,14 +335,14 @@ int launch_conv_f32(const ConvF32Args &a, void *stream)
         }
     }
     switch (cfg) {
-    case 1: g_last_tile = "128x128"; return launch_tile<128, 128, 2, 2>(d, ks, s);
-    case 2: g_last_tile = "64x128";  return launch_tile<64, 128, 2, 2>(d, ks, s);
-    case 3: g_last_tile = "32x256";  return launch_tile<32, 256, 1, 4>(d, ks, s);
-    case 4: g_last_tile = "64x64";   return launch_tile<64, 64, 2, 2>(d, ks, s);
-    case 5: g_last_tile = "32x128";  return launch_tile<32, 128, 1, 4>(d, ks, s);
-    case 6: g_last_tile = "128x64";  return launch_tile<128, 64, 4, 1>(d, ks, s);
-    case 7: g_last_tile = "256x64";  return launch_tile<256, 64, 4, 1>(d, ks, s);
-    case 8: g_last_tile = "128x256"; return launch_tile<128, 256, 2, 2>(d, ks, s);
+    case 1: set_tile_name("128x128", ks); return launch_tile<128, 128, 2, 2>(d, ks, s);
+    case 2: set_tile_name("64x128", ks); return launch_tile<64, 128, 2, 2>(d, ks, s);
+    case 3: set_tile_name("32x256", ks); return launch_tile<32, 256, 1, 4>(d, ks, s);
+    case 4: set_tile_name("64x64", ks); return launch_tile<64, 64, 2, 2>(d, ks, s);
+    case 5: set_tile_name("32x128", ks); return launch_tile<32, 128, 1, 4>(d, ks, s);
+    case 6: set_tile_name("128x64", ks); return launch_tile<128, 64, 4, 1>(d, ks, s);
+    case 7: set_tile_name("256x64", ks); return launch_tile<256, 64, 4, 1>(d, ks, s);
+    case 8: set_tile_name("128x256", ks); return launch_tile<128, 256, 2, 2>(d, ks, s);
     default: return (int)hipErrorInvalidValue;
     }
 }

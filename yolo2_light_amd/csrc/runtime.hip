@@ -209,6 +209,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.K = l.size * l.size * l.c; a.Kpad = l.Kpad; a.Mpad = l.Mpad;
             a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
             YL_LAUNCH(launch_conv_f32(a, s), "conv_f32");
+            l.kernel_name = conv_f32_last_tile_name();
         } else if (l.conv_mode == CONV_INT8) {
             YL_LAUNCH(launch_quantize_nhwc(input, net.d_qbuf, B, l.c, l.h, l.w, l.Cpad, l.input_quant_multipler, s),
                       "quantize_nhwc");
@@ -219,6 +220,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
             // float ALPHA1 = R_MULT / (l.input_quant_multipler * l.weights_quant_multipler);  (quantized.c:596)
             a.alpha1 = 32 / (l.input_quant_multipler * l.weights_quant_multipler);
             YL_LAUNCH(launch_conv_i8(a, s), "conv_i8");
+            l.kernel_name = "conv_i8_mfma";
         } else {
             YL_LAUNCH(launch_pack_sign_bits(input, net.d_bitbuf, B, l.c, l.h, l.w, l.Cw, s), "pack_sign_bits");
             ConvXnorArgs a;
@@ -226,6 +228,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.out = l.d_output; a.dbg = l.d_debug;
             a.B = B; a.C = l.c; a.Cw = l.Cw; a.H = l.h; a.W = l.w; a.M = l.n; a.Mpad = l.Mpad; a.act = l.activation;
             YL_LAUNCH(launch_conv_xnor(a, s), "conv_xnor");
+            l.kernel_name = "conv_xnor";
         }
         break;
     }
@@ -585,6 +588,48 @@ static int pull_debug(yl_network *net, int i, int32_t *dst, int want_mode)
 int yl_network_layer_xnor_counts(yl_network *net, int i, int32_t *dst_host) { return pull_debug(net, i, dst_host, CONV_XNOR); }
 int yl_network_layer_int8_acc(yl_network *net, int i, int32_t *dst_host) { return pull_debug(net, i, dst_host, CONV_INT8); }
 
+static int ensure_layer_events(Network &n)
+{
+    const size_t nl = n.layers.size();
+    while (n.layer_events.size() < nl + 1) {
+        hipEvent_t e;
+        YL_HIP(hipEventCreate(&e));
+        n.layer_events.push_back(e);
+    }
+    return YL_OK;
+}
+
+int yl_network_forward_timed(yl_network *net, const float *input_dev)
+{
+    if (!net || !input_dev) { set_error("null argument"); return YL_ERR_ARG; }
+    Network &n = net->net;
+    if (!n.on_device) { set_error("network not on device"); return YL_ERR_STATE; }
+    YL_HIP(hipSetDevice(n.device));
+    int rc = ensure_layer_events(n);
+    if (rc != YL_OK) return rc;
+    return forward(n, input_dev, true);
+}
+
+int yl_network_layer_times(yl_network *net, float *ms_per_layer, float *total_ms)
+{
+    if (!net) { set_error("null argument"); return YL_ERR_ARG; }
+    Network &n = net->net;
+    const size_t nl = n.layers.size();
+    if (!n.on_device || n.layer_events.size() < nl + 1) { set_error("no timed forward recorded"); return YL_ERR_STATE; }
+    YL_HIP(hipSetDevice(n.device));
+    YL_HIP(hipEventSynchronize((hipEvent_t)n.layer_events[nl]));
+    for (size_t i = 0; i < nl && ms_per_layer; ++i)
+        YL_HIP(hipEventElapsedTime(&ms_per_layer[i], (hipEvent_t)n.layer_events[i], (hipEvent_t)n.layer_events[i + 1]));
+    if (total_ms) YL_HIP(hipEventElapsedTime(total_ms, (hipEvent_t)n.layer_events[0], (hipEvent_t)n.layer_events[nl]));
+    return YL_OK;
+}
+
+const char *yl_network_layer_kernel(const yl_network *net, int i)
+{
+    YL_LAYER_OR(nullptr)
+    return l.kernel_name.c_str();
+}
+
 int yl_network_profile(yl_network *net, const float *input_dev, int iters, float *ms_per_layer, float *total_ms)
 {
     if (!net || !input_dev || iters <= 0) { set_error("bad argument"); return YL_ERR_ARG; }
@@ -592,11 +637,7 @@ int yl_network_profile(yl_network *net, const float *input_dev, int iters, float
     if (!n.on_device) { set_error("network not on device"); return YL_ERR_STATE; }
     YL_HIP(hipSetDevice(n.device));
     const size_t nl = n.layers.size();
-    while (n.layer_events.size() < nl + 1) {
-        hipEvent_t e;
-        YL_HIP(hipEventCreate(&e));
-        n.layer_events.push_back(e);
-    }
+    { int rc0 = ensure_layer_events(n); if (rc0 != YL_OK) return rc0; }
     std::vector<double> acc(nl, 0.0);
     double tot = 0.0;
     for (int it = 0; it < iters; ++it) {
@@ -623,6 +664,9 @@ int yl_network_get_boxes(yl_network *net, int image, int w, int h, float thresh,
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }
     return get_boxes_host(net->net, image, w, h, thresh, relative, letter, nms, rows, max_rows, classes_out);
 }
+
+int yl_debug_force_conv_tile(int cfg) { conv_f32_force_tile(cfg); return YL_OK; }
+const char *yl_debug_last_conv_tile(void) { return conv_f32_last_tile_name(); }
 
 int yl_network_compact_detections(yl_network *net, float thresh, int cap, float *records_dev, int *counts_dev)
 {

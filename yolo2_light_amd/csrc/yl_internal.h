@@ -53,6 +53,7 @@ struct Layer {
     float *d_mean = nullptr;
     int   Cw = 0;
     int32_t *d_debug = nullptr;          // xnor counts / int8 acc (debug mode)
+    std::string kernel_name;             // dominant kernel of this layer's last launch
 };
 
 struct Network {

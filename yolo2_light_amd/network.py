@@ -210,6 +210,19 @@ class Network:
               "yl_network_profile")
         return ms, float(tot.value)
 
+    def forward_timed(self, input_dev_ptr: int) -> None:
+        check(lib.yl_network_forward_timed(self._h, C.c_void_p(input_dev_ptr)), "yl_network_forward_timed")
+
+    def layer_times(self):
+        ms = np.zeros(self.n, dtype=np.float32)
+        tot = C.c_float(0)
+        check(lib.yl_network_layer_times(self._h, _fp(ms), C.byref(tot)), "yl_network_layer_times")
+        return ms, float(tot.value)
+
+    def layer_kernel(self, i: int) -> str:
+        p = lib.yl_network_layer_kernel(self._h, i)
+        return p.decode() if p else ""
+
     # ------------------------------------------------------------ detections
     def pull_heads(self) -> None:
         check(lib.yl_network_pull_heads(self._h), "yl_network_pull_heads")
