@@ -192,11 +192,12 @@ int yl_network_layer_int8_acc(yl_network *net, int i, int32_t *dst_host);
 int yl_network_profile(yl_network *net, const float *input_dev, int iters,
                        float *ms_per_layer, float *total_ms);
 /* The same measurement without a host sync inside the pass: yl_network_forward with a HIP
- * event recorded on the network's stream before every layer and after the last one;
- * yl_network_layer_times waits for the last event and reads the elapsed times of the most
- * recent timed forward. */
-int yl_network_forward_timed(yl_network *net, const float *input_dev);
-int yl_network_layer_times(yl_network *net, float *ms_per_layer, float *total_ms);
+ * event recorded on the network's stream before every layer and after the last one, into
+ * timing slot `slot` (0..63; one slot per step lets a bench record every step of its timed
+ * region and read all of them afterwards).  yl_network_layer_times waits for the slot's
+ * last event and reads its elapsed times. */
+int yl_network_forward_timed(yl_network *net, const float *input_dev, int slot);
+int yl_network_layer_times(yl_network *net, int slot, float *ms_per_layer, float *total_ms);
 /* name of the kernel (template instance) layer i's last launch used, e.g.
  * "conv_f32_mfma<128x128,ks3>"; "" for layers that have not run or are pure aliases */
 const char *yl_network_layer_kernel(const yl_network *net, int i);

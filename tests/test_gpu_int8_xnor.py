@@ -1,0 +1,217 @@
+"""GPU parity for the INT8 (K2) and XNOR (K3) paths and a teacher-forced
+layer-by-layer check of whole networks in all three modes.
+
+Bars: XNOR match counts and INT8 int16-clamped accumulators bit-exact; their
+FP32 epilogues replay the reference's scalar float ops, so the layer outputs
+are bit-exact too.  "Teacher forcing" = every layer is checked against the
+oracle applied to the GPU's OWN input of that layer, so one rounding-level
+difference upstream (e.g. a sign flip of a near-zero activation) cannot mask or
+fake a kernel bug downstream.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import common
+import descs as D
+from common import Network, fp, fp32_close
+from yolo2_light_amd._lib import check, lib
+
+pytestmark = pytest.mark.gpu
+
+_i8p = C.POINTER(C.c_int8)
+_i32p = C.POINTER(C.c_int32)
+
+
+def _net_from(descs_list, batch, w, h, c, quantized=0):
+    net = Network.from_desc(descs_list, batch, w, h, c, quantized)
+    check(lib.yl_network_set_debug(net._h, 1), "set_debug")
+    net.to_device(0)
+    return net
+
+
+XNOR_SHAPES = [
+    # B, C, H, W, M
+    (2, 16, 13, 17, 32),      # c%32 != 0 branch of the reference, Cw = 1
+    (1, 32, 26, 26, 64),
+    (3, 64, 7, 9, 40),        # M not a multiple of the filter tile
+    (1, 100, 12, 10, 33),     # ragged channels: Cw = 2 with 28 pad bits
+    (2, 256, 13, 13, 70),     # Cw = 4
+    (1, 512, 6, 5, 130),      # Cw = 8
+    (5, 192, 3, 3, 16),       # Cw = 3 (odd) and many tiny images per block
+]
+
+
+@pytest.mark.parametrize("shape", XNOR_SHAPES)
+def test_conv_xnor_bit_exact(olib, shape):
+    B, Cc, H, W, M = shape
+    rng = np.random.default_rng(77 + Cc + M)
+    K = Cc * 9
+    wts = rng.normal(0, 1.0, M * K).astype(np.float32)
+    wts[rng.random(M * K) < 0.02] = 0.0                      # exact zeros: bit must be 0 (w > 0 is false)
+    bias = rng.normal(0, 0.5, M).astype(np.float32)
+    mean = np.zeros(M, np.float32)
+    olib.oracle_binary_mean(fp(wts), M, K, fp(mean))
+    x = rng.standard_normal((B, Cc, H, W)).astype(np.float32)
+    x[rng.random(x.shape) < 0.05] = 0.0                       # x == 0 -> bit 0
+    d = D.conv(B, W, H, Cc, M, 3, 1, 1, D.LEAKY, wts, bias, xnor=1, mean_arr=mean)
+    net = _net_from([d], B, W, H, Cc)
+    got = net.predict(x)
+    cnt = net.layer_xnor_counts(0)
+    ref = np.zeros_like(got)
+    rcnt = np.zeros(got.size, np.int32)
+    olib.oracle_conv_xnor(fp(x), fp(wts), fp(mean), fp(bias), fp(ref), rcnt.ctypes.data_as(_i32p), B, Cc, H, W, M, D.LEAKY)
+    assert np.array_equal(cnt, rcnt), "match counts differ: %d of %d" % (np.count_nonzero(cnt != rcnt), cnt.size)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    net.close()
+
+
+INT8_SHAPES = [
+    # B, C, H, W, M, size, stride, pad
+    (2, 16, 13, 13, 32, 3, 1, 1),
+    (1, 32, 19, 23, 64, 3, 2, 1),
+    (2, 64, 9, 7, 255, 1, 1, 0),
+    (1, 100, 8, 8, 24, 3, 1, 1),       # channels padded 100 -> 128 (G = 8)
+    (3, 128, 13, 13, 130, 1, 1, 0),
+    (1, 256, 10, 10, 96, 3, 1, 1),
+    (4, 48, 5, 5, 40, 3, 1, 1),        # G = 3 -> padded to 4
+]
+
+
+@pytest.mark.parametrize("shape", INT8_SHAPES)
+def test_conv_int8_bit_exact(olib, shape):
+    B, Cc, H, W, M, size, stride, pad = shape
+    rng = np.random.default_rng(99 + Cc + M)
+    K = Cc * size * size
+    wts = rng.normal(0, np.sqrt(2.0 / K), M * K).astype(np.float32)
+    bias = rng.normal(0, 0.5, M).astype(np.float32)
+    wq = np.zeros(M * K, np.int8)
+    w_mult = olib.oracle_quantize_weights(fp(wts), M * K, wq.ctypes.data_as(_i8p))
+    in_mult = 15.497
+    x = (rng.standard_normal((B, Cc, H, W)) * 3).astype(np.float32)
+    x.reshape(-1)[:7] = [1e9, -1e9, 40000.7 / in_mult, -33000.2 / in_mult, 127.9 / in_mult, -128.5 / in_mult, 0.0]
+    l0 = D.maxpool(B, W, H, Cc, 1, 1, pad=0)                  # identity: INT8 never runs on layer 0
+    l1 = D.conv(B, W, H, Cc, M, size, stride, pad, D.LEAKY, wts, bias, weights_int8=wq, in_mult=in_mult, w_mult=w_mult)
+    net = _net_from([l0, l1], B, W, H, Cc, quantized=1)
+    assert net.layer_info(1)["int8"] == 1
+    got = net.predict(x)
+    acc = net.layer_int8_acc(1)
+    ref = np.zeros_like(got)
+    racc = np.zeros(got.size, np.int32)
+    olib.oracle_conv_int8(fp(x), wq.ctypes.data_as(_i8p), fp(bias), fp(ref), racc.ctypes.data_as(_i32p),
+                          B, Cc, H, W, M, size, stride, pad, D.LEAKY, in_mult, w_mult)
+    assert np.array_equal(acc, racc), "int16 accumulators differ: %d of %d" % (np.count_nonzero(acc != racc), acc.size)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    net.close()
+
+
+# ----------------------------------------------------------------------------
+# teacher-forced whole networks
+# ----------------------------------------------------------------------------
+def _teacher_forced(olib, name, width, height, batch, quantized):
+    cfg, wts = common.model_files(name, width, height)
+    net = Network.load(cfg, wts, batch, quantized, device=0, debug=True)
+    x = common.seeded_input(batch, 3, height, width)
+    net.predict(x)
+    infos = net.layers()
+    outs = [net.layer_output(i) for i in range(net.n)]
+    route_inputs = {}
+    from yolo2_light_amd import zoo
+    for i, (typ, o) in enumerate(zoo.parse_sections(open(cfg).read())[1:]):
+        if typ == "route":
+            ids = [int(v) for v in o["layers"].split(",")]
+            route_inputs[i] = [j + i if j < 0 else j for j in ids]
+    B = batch
+    stats = {"exact": 0, "fp32": 0}
+    for i, li in enumerate(infos):
+        cur = x.reshape(-1) if i == 0 else outs[i - 1]
+        ref = np.zeros(B * li["outputs"], np.float32)
+        t = li["type"]
+        exact = True
+        if t == common.CONV:
+            w_ = net.layer_weights(i); b_ = net.layer_biases(i)
+            if li["conv_mode"] == common.CONV_F32:
+                olib.oracle_conv_f32(fp(cur), fp(w_), fp(b_), fp(ref), B, li["c"], li["h"], li["w"], li["n"],
+                                     li["size"], li["stride"], li["pad"], li["activation"])
+                exact = False
+            elif li["conv_mode"] == common.CONV_INT8:
+                wq = net.layer_weights_int8(i)
+                im, wm = net.layer_quant_multipliers(i)
+                racc = np.zeros(ref.size, np.int32)
+                olib.oracle_conv_int8(fp(cur), wq.ctypes.data_as(_i8p), fp(b_), fp(ref), racc.ctypes.data_as(_i32p),
+                                      B, li["c"], li["h"], li["w"], li["n"], li["size"], li["stride"], li["pad"],
+                                      li["activation"], im, wm)
+                assert np.array_equal(net.layer_int8_acc(i), racc), "layer %d int8 accumulators" % i
+            else:
+                mean = net.layer_mean_arr(i)
+                rcnt = np.zeros(ref.size, np.int32)
+                olib.oracle_conv_xnor(fp(cur), fp(w_), fp(mean), fp(b_), fp(ref), rcnt.ctypes.data_as(_i32p),
+                                      B, li["c"], li["h"], li["w"], li["n"], li["activation"])
+                assert np.array_equal(net.layer_xnor_counts(i), rcnt), "layer %d xnor counts" % i
+        elif t == common.MAXPOOL:
+            olib.oracle_maxpool(fp(cur), fp(ref), li["size"], li["w"], li["h"], li["out_w"], li["out_h"], li["c"],
+                                li["pad"], li["stride"], B)
+        elif t == common.ROUTE:
+            ref = np.concatenate([outs[j].reshape(B, -1) for j in route_inputs[i]], axis=1).reshape(-1)
+        elif t == common.SHORTCUT:
+            olib.oracle_shortcut(fp(cur), fp(outs[li["index"]]), fp(ref), B, li["w"], li["h"], li["c"],
+                                 li["out_w"], li["out_h"], li["out_c"], li["activation"])
+        elif t == common.UPSAMPLE:
+            olib.oracle_upsample(fp(cur), fp(ref), B, li["c"], li["h"], li["w"], li["stride"], 1.0)
+        elif t == common.YOLO:
+            olib.oracle_yolo(fp(cur), fp(ref), B, li["n"], li["classes"], li["w"] * li["h"])
+            exact = False
+        elif t == common.REGION:
+            olib.oracle_region(fp(cur), fp(ref), B, li["n"], li["classes"], li["coords"], li["w"] * li["h"], li["softmax"])
+            exact = False
+        else:
+            raise AssertionError("unexpected layer type %d" % t)
+        got = outs[i]
+        if exact:
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "layer %d %r not bit-exact" % (i, li)
+            stats["exact"] += 1
+        else:
+            ok, ratio, worst = fp32_close(got, ref)
+            assert ok, "layer %d %r: err/allowed %.3g at %d (got %r ref %r)" % (i, li, ratio, worst, got[worst], ref[worst])
+            stats["fp32"] += 1
+    net.close()
+    return stats
+
+
+@pytest.mark.parametrize("name,width,height,batch,quantized", [
+    ("tiny-yolo-xnor", 96, 96, 2, 0),
+    ("tiny-yolo-xnor", 416, 416, 1, 0),         # BASELINE config 5 resolution
+    ("yolov3-tiny", 96, 96, 2, 1),
+    ("yolov3", 64, 64, 2, 1),
+    ("yolov3", 96, 64, 1, 0),
+])
+def test_network_teacher_forced(olib, name, width, height, batch, quantized):
+    stats = _teacher_forced(olib, name, width, height, batch, quantized)
+    assert stats["exact"] > 0
+
+
+@pytest.mark.skipif(not common.refbind.available(), reason="oracle/_ref not built")
+def test_int8_network_vs_reference_library_batch1():
+    """-quantized yolov3-tiny 416 against network_predict_quantized of the reference itself
+    (which handles batch item 0 only): final detections agree."""
+    name, width, height = "yolov3-tiny", 416, 416
+    cfg, wts = common.model_files(name, width, height)
+    ref = common.refbind.RefNetwork(cfg, wts, 1, 1)
+    net = Network.load(cfg, wts, 1, 1, device=0)
+    x = common.seeded_input(1, 3, height, width)
+    ref.predict(x)
+    net.predict(x)
+    # quantisation is a step function of FP32 inputs, so compare robustly: heads within a
+    # loose tolerance on >= 99.9 % of elements and the same detections
+    for i in range(net.n):
+        li = net.layer_info(i)
+        if li["type"] not in (common.YOLO,):
+            continue
+        g = net.layer_output(i); r = ref.layer_output(i)
+        bad = np.abs(g - r) > (1e-3 + 1e-3 * np.abs(r))
+        assert bad.mean() < 1e-3, "yolo layer %d: %.4f%% of elements differ" % (i, 100 * bad.mean())
+    r = ref.get_detections(0, width, height, 0.24, nms=0.4)
+    g = net.get_boxes(0, width, height, 0.24, nms=0.4)
+    assert abs(len(r) - len(g)) <= max(2, len(r) // 50)
+    net.close()

@@ -1,31 +1,76 @@
 #!/bin/bash
-# One gpurun invocation: parity tests, smoke, bench (+ per-layer table), rocprofv3 kernel stats.
-# Usage (from the repo root on the GPU box):  bash tools/gpu_round.sh [tag]
+# One gpurun invocation: parity tests, smoke, bench (+ per-layer table), rocprofv3 kernel stats
+# and PMC counter passes.  Usage (repo root on the GPU box):  bash tools/gpu_round.sh <tag> [steps...]
+# steps: tests smoke bench sweep prof pmc int8 xnor   (default: tests smoke bench prof)
 TAG=${1:-r1}
+shift
+STEPS=${@:-tests smoke bench prof}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
 rocminfo 2>/dev/null | grep -E "Marketing Name|gfx" | head -4 > $OUT/device.txt
 lscpu | grep -E "Model name|^CPU\(s\)" >> $OUT/device.txt
-echo "== pytest -m gpu" | tee -a $OUT/summary.txt
-timeout 900 python -m pytest tests -m gpu -q --maxfail=10 -x --durations=8 > $OUT/pytest_gpu.log 2>&1
-echo "pytest exit $?" | tee -a $OUT/summary.txt
-tail -25 $OUT/pytest_gpu.log
-echo "== smoke" | tee -a $OUT/summary.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
-echo "smoke exit $?" | tee -a $OUT/summary.txt
-tail -3 $OUT/smoke.log
-echo "== bench yolov3 608 b64" | tee -a $OUT/summary.txt
-timeout 900 python bench.py --steps 5 --warmup 2 --layers > $OUT/bench.json 2> $OUT/bench_layers.txt
-echo "bench exit $?" | tee -a $OUT/summary.txt
-cat $OUT/bench.json
-tail -5 $OUT/bench_layers.txt
-echo "== rocprofv3 kernel stats" | tee -a $OUT/summary.txt
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/rocprof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof_run.log 2>&1 )
-echo "rocprof exit $?" | tee -a $OUT/summary.txt
-find $OUT/rocprof -name "*stats*" | head
-F=$(find $OUT/rocprof -name "*kernel_stats.csv" | head -1)
-[ -n "$F" ] && head -15 "$F"
-# keep the merged-back payload small: drop the raw per-dispatch trace
-find $OUT/rocprof -name "*kernel_trace.csv" -size +20M -delete
+has() { [[ " $STEPS " == *" $1 "* ]]; }
+
+if has tests; then
+  echo "== pytest -m gpu" | tee -a $OUT/summary.txt
+  timeout 1200 python -m pytest tests -m gpu -q --maxfail=12 --durations=8 > $OUT/pytest_gpu.log 2>&1
+  echo "pytest exit $?" | tee -a $OUT/summary.txt
+  tail -30 $OUT/pytest_gpu.log
+fi
+if has smoke; then
+  echo "== smoke" | tee -a $OUT/summary.txt
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
+  echo "smoke exit $?" | tee -a $OUT/summary.txt
+  tail -3 $OUT/smoke.log
+fi
+if has bench; then
+  echo "== bench yolov3 608 b64 fp32" | tee -a $OUT/summary.txt
+  timeout 900 python bench.py --steps 10 --warmup 2 --layers > $OUT/bench.json 2> $OUT/bench_layers.txt
+  echo "bench exit $?" | tee -a $OUT/summary.txt
+  cat $OUT/bench.json
+fi
+if has int8; then
+  echo "== bench yolov3 608 b64 int8" | tee -a $OUT/summary.txt
+  timeout 900 python bench.py --mode int8 --steps 10 --warmup 2 --layers > $OUT/bench_int8.json 2> $OUT/bench_int8_layers.txt
+  echo "bench int8 exit $?" | tee -a $OUT/summary.txt
+  cat $OUT/bench_int8.json
+fi
+if has xnor; then
+  echo "== bench tiny-yolo-xnor 416 b128" | tee -a $OUT/summary.txt
+  timeout 900 python bench.py --model tiny-yolo-xnor --size 416 --batch 128 --steps 10 --warmup 2 --layers --no-cpu-baseline > $OUT/bench_xnor.json 2> $OUT/bench_xnor_layers.txt
+  echo "bench xnor exit $?" | tee -a $OUT/summary.txt
+  cat $OUT/bench_xnor.json
+  echo "== bench yolov3-tiny 416 b32 fp32" | tee -a $OUT/summary.txt
+  timeout 900 python bench.py --model yolov3-tiny --size 416 --batch 32 --steps 20 --warmup 3 --layers --no-cpu-baseline > $OUT/bench_tiny.json 2> $OUT/bench_tiny_layers.txt
+  cat $OUT/bench_tiny.json
+fi
+if has sweep; then
+  echo "== conv tile sweep" | tee -a $OUT/summary.txt
+  timeout 1200 python tools/sweep_conv.py --batch 64 --iters 3 > $OUT/sweep.txt 2>&1
+  echo "sweep exit $?" | tee -a $OUT/summary.txt
+  grep "^#" $OUT/sweep.txt
+fi
+if has prof; then
+  echo "== rocprofv3 kernel stats" | tee -a $OUT/summary.txt
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/rocprof -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/$OUT/rocprof_run.log 2>&1 )
+  echo "rocprof exit $?" | tee -a $OUT/summary.txt
+  F=$(find $OUT/rocprof -name "*kernel_stats.csv" | head -1)
+  [ -n "$F" ] && head -14 "$F" | cut -c1-200
+  find $OUT/rocprof -name "*kernel_trace.csv" -size +20M -delete
+fi
+if has pmc; then
+  echo "== rocprofv3 PMC passes (own runs, kernel-trace only)" | tee -a $OUT/summary.txt
+  rocprofv3 -L > $OUT/pmc_list.txt 2>&1
+  for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA"; do
+    N=$(echo $C | tr ' ' '_' | cut -c1-40)
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmc_$N -o pmc -- python $R/bench.py --steps 1 --warmup 0 --batch 16 --no-cpu-baseline > $R/$OUT/pmc_$N.log 2>&1 )
+    echo "pmc $N exit $?" | tee -a $OUT/summary.txt
+  done
+  python tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt 2>&1
+  cat $OUT/pmc_summary.txt | head -40
+  find $OUT -name "*counter_collection.csv" -size +30M -delete
+  find $OUT -name "*kernel_trace.csv" -size +20M -delete
+fi
 du -sh $OUT

@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""Tile sweep of the K1 FP32 MFMA conv over the unique conv shapes of yolov3-608
+ at batch B: every shape x every tile config, HIP-event timed through
+yl_network_profile.  Prints one JSON line per (shape, tile) and a best-tile table.
+
+    python tools/sweep_conv.py --batch 64 --tiles 1,2,3,6,7,8 --iters 3
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# (count, M, C, size, stride, H(=W) of the input) for yolov3 at 608x608
+SHAPES_608 = [
+    (1, 32, 3, 3, 1, 608), (1, 64, 32, 3, 2, 608), (1, 32, 64, 1, 1, 304), (1, 64, 32, 3, 1, 304),
+    (1, 128, 64, 3, 2, 304), (2, 64, 128, 1, 1, 152), (2, 128, 64, 3, 1, 152), (1, 256, 128, 3, 2, 152),
+    (10, 128, 256, 1, 1, 76), (11, 256, 128, 3, 1, 76), (1, 512, 256, 3, 2, 76), (10, 256, 512, 1, 1, 38),
+    (11, 512, 256, 3, 1, 38), (1, 1024, 512, 3, 2, 38), (7, 512, 1024, 1, 1, 19), (7, 1024, 512, 3, 1, 19),
+    (1, 255, 1024, 1, 1, 19), (1, 256, 512, 1, 1, 19), (1, 256, 768, 1, 1, 38), (1, 255, 512, 1, 1, 38),
+    (1, 128, 256, 1, 1, 38), (1, 128, 384, 1, 1, 76), (1, 255, 256, 1, 1, 76),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--tiles", default="0,1,2,3,6,7,8")
+    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--only", default="", help="comma list of shape indices")
+    args = ap.parse_args()
+    import torch
+    import descs as D
+    from yolo2_light_amd import Network
+    from yolo2_light_amd._lib import lib
+
+    tiles = [int(t) for t in args.tiles.split(",")]
+    only = [int(i) for i in args.only.split(",")] if args.only else range(len(SHAPES_608))
+    rng = np.random.default_rng(0)
+    B = args.batch
+    total_best = 0.0
+    total_flops = 0.0
+    for si in only:
+        cnt, M, Cc, size, stride, H = SHAPES_608[si]
+        pad = size // 2
+        K = Cc * size * size
+        wts = rng.normal(0, np.sqrt(2.0 / K), M * K).astype(np.float32)
+        bias = rng.normal(0, 0.1, M).astype(np.float32)
+        d = D.conv(B, H, H, Cc, M, size, stride, pad, D.LEAKY, wts, bias)
+        net = Network.from_desc([d], B, H, H, Cc)
+        net.to_device(0)
+        x = torch.rand((B, Cc, H, H), device="cuda:0", dtype=torch.float32) - 0.3
+        flops = 2.0 * M * K * d.out_h * d.out_w * B
+        best = None
+        for t in tiles:
+            if t in (1, 6, 7, 8) and M <= 32 and t != 1:
+                pass
+            lib.yl_debug_force_conv_tile(t)
+            try:
+                net.profile(x.data_ptr(), 1)          # warm-up
+                ms, _ = net.profile(x.data_ptr(), args.iters)
+            finally:
+                lib.yl_debug_force_conv_tile(0)
+            tf = flops / (ms[0] * 1e-3) / 1e12
+            rec = {"shape": si, "M": M, "C": Cc, "size": size, "stride": stride, "H": H, "count": cnt,
+                   "tile": t, "kernel": net.layer_kernel(0), "ms": float(ms[0]), "tflops": tf}
+            print(json.dumps(rec), flush=True)
+            if t != 0 and (best is None or ms[0] < best[1]):
+                best = (t, float(ms[0]), tf, net.layer_kernel(0))
+        if best:
+            total_best += best[1] * cnt
+            total_flops += flops * cnt
+            print("# shape %2d x%-2d M=%4d C=%4d k=%d s=%d H=%3d  best tile %d %-28s %.3f ms %.1f TF" % (
+                si, cnt, M, Cc, size, stride, H, best[0], best[3], best[1], best[2]), flush=True)
+        net.close()
+        del x
+        torch.cuda.empty_cache()
+    if total_best > 0:
+        print("# all conv layers with per-shape best tile: %.2f ms per batch of %d -> %.1f TF, %.1f img/s (conv only)" % (
+            total_best, B, total_flops / (total_best * 1e-3) / 1e12, B / (total_best * 1e-3)))
+
+
+if __name__ == "__main__":
+    main()

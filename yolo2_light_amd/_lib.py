@@ -88,8 +88,8 @@ _SIGS = {
     "yl_network_layer_xnor_counts": (C.c_int, [_vp, C.c_int, c_int32_p]),
     "yl_network_layer_int8_acc": (C.c_int, [_vp, C.c_int, c_int32_p]),
     "yl_network_profile": (C.c_int, [_vp, _vp, C.c_int, c_float_p, c_float_p]),
-    "yl_network_forward_timed": (C.c_int, [_vp, _vp]),
-    "yl_network_layer_times": (C.c_int, [_vp, c_float_p, c_float_p]),
+    "yl_network_forward_timed": (C.c_int, [_vp, _vp, C.c_int]),
+    "yl_network_layer_times": (C.c_int, [_vp, C.c_int, c_float_p, c_float_p]),
     "yl_network_layer_kernel": (C.c_char_p, [_vp, C.c_int]),
     "yl_network_get_boxes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_float,
                                        c_float_p, C.c_int, c_int_p]),

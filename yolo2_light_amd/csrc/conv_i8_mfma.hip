@@ -1,7 +1,298 @@
-// placeholder: replaced by the INT8 MFMA implementation
+// conv_i8_mfma.hip -- K2: the `-quantized` INT8 convolution on gfx950 INT8 MFMA.
+//
+// Replaces forward_convolutional_layer_q (src/yolov2_forward_network_quantized.c:527-631:
+// input quantisation :554-560, im2col_cpu_int8 :186-209, gemm_nn_int8_int16 :469-491,
+// dequant/bias/leaky :596-627) and the reference GPU's cudnnTransformTensor +
+// INT8x4 cudnnConvolutionBiasActivationForward (src/yolov2_forward_network_gpu.cu:189-229).
+//
+// Data layout in HBM (chosen for 16-byte coalescing, not inherited from the reference):
+//   activations  act_q[B][G][H][W][16]  int8, G = Cpad/16 channel groups ("NC/16HW16"):
+//                for a fixed channel group consecutive pixels are consecutive 16-byte units,
+//                so both the quantise kernel's stores and the conv's im2col gathers are
+//                perfectly coalesced dwordx4 accesses.
+//   weights      w_q[K16pad][Mpad][16]  int8, K16 index = tap*G + cg (tap = ky*size+kx),
+//                i.e. k-major panels of 16-byte units, zero padded.
+// Math: v_mfma_i32_32x32x32_i8.  Each lane feeds 16 consecutive k-bytes of one filter (A)
+// and of one output pixel (B); integer accumulation is exact, so any k order that A and B
+// share gives the reference's acc32 bit for bit.  The epilogue replays the reference's
+// scalar arithmetic exactly:
+//   o16 = clamp_abs(acc32 / 32 [C truncating division], 32767)
+//   y   = o16 * ALPHA1 ; y += bias ; leaky: y > 0 ? y : y / 10
+// Roofline: with FP32 activations in/out this path is HBM-bound, not MFMA-bound.
 #include <hip/hip_runtime.h>
+#include <climits>
+
 #include "kernels.h"
+#include "../../include/yolo2_hip.h"
+
 namespace yl {
-int launch_quantize_nhwc(const float *, int8_t *, int, int, int, int, int, float, void *) { return (int)hipErrorNotSupported; }
-int launch_conv_i8(const ConvI8Args &, void *) { return (int)hipErrorNotSupported; }
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------ K2a: quantise + repack
+// one lane per (b, cg, pixel): 16 coalesced plane reads, one 16-byte coalesced store
+__global__ __launch_bounds__(256) void quantize_nc16_kernel(const float *__restrict__ in, int8_t *__restrict__ out,
+                                                            size_t total, int C, int HW, int G, float mult)
+{
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int pix = (int)(idx % HW);
+        size_t t = idx / HW;
+        const int cg = (int)(t % G);
+        const size_t b = t / G;
+        const float *src = in + (b * C + (size_t)cg * 16) * HW + pix;
+        unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            int q = 0;
+            if (cg * 16 + j < C) {
+                const float tv = __fmul_rn(src[(size_t)j * HW], mult);
+                // `int16_t src = float` on x86-64/gcc: cvttss2si (0x80000000 when out of range
+                // or NaN) then keep the low 16 bits
+                int i32 = (fabsf(tv) < 2147483648.f) ? (int)tv : INT_MIN;
+                int s = (int)(short)(i32 & 0xFFFF);
+                // max_abs(src, 127)
+                q = (abs(s) > 127) ? ((s > 0) ? 127 : -127) : s;
+            }
+            w[j >> 2] |= ((unsigned)(q & 0xFF)) << ((j & 3) * 8);
+        }
+        uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<uint4 *>(out + idx * 16) = v;
+    }
 }
+
+int launch_quantize_nhwc(const float *in, int8_t *out, int B, int C, int H, int W, int Cpad, float mult, void *stream)
+{
+    const int G = Cpad / 16;
+    const size_t total = (size_t)B * G * H * W;
+    size_t g = (total + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g == 0) g = 1;
+    hipLaunchKernelGGL(quantize_nc16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                       in, out, total, C, H * W, G, mult);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ K2b: INT8 MFMA implicit GEMM
+constexpr int BK16 = 8;          // 16-byte k-units per LDS panel (= 4 MFMA k-steps of 32)
+constexpr int NT = 256;
+
+struct ConvI8Dev {
+    const int8_t *in_q;
+    const int8_t *w_q;
+    const float *bias;
+    float *out;
+    int32_t *dbg;
+    int B, G, Gshift, H, W, M, Mpad, OH, OW;
+    int size, stride, pad, act;
+    int K16, K16pad;
+    float alpha1;
+    int Ntotal, OHW, tiles_m;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(NT) void conv_i8_mfma_kernel(ConvI8Dev p)
+{
+    constexpr int TM = BM / (WM * 32);
+    constexpr int TN = BN / (WN * 32);
+    static_assert(WM * WN == 4, "4 waves");
+    static_assert(BN % 64 == 0 && BN <= NT, "B panel mapping");
+    constexpr int A_UNITS = BK16 * BM;                 // 16-byte units per A panel
+    constexpr int A_PER_THREAD = A_UNITS / NT;
+    static_assert(A_UNITS % NT == 0, "A panel divides evenly");
+    constexpr int B_PER_THREAD = BK16 * BN / NT;
+    constexpr int G_STEP = NT / BN;
+
+    __shared__ __attribute__((aligned(16))) uint4 smem[2 * BK16 * BM + 2 * BK16 * BN];
+    uint4 *As = smem;
+    uint4 *Bs = smem + 2 * BK16 * BM;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tile_m = logical % p.tiles_m;
+    const int tile_n = logical / p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int n_local = tid % BN;
+    const int g0 = __builtin_amdgcn_readfirstlane(tid / BN);
+    const int HW = p.H * p.W;
+    const int n_g = n0 + n_local;
+    const bool n_ok = n_g < p.Ntotal;
+    const int bimg = n_g / p.OHW;
+    const int pix = n_g - bimg * p.OHW;
+    const int oy = pix / p.OW;
+    const int ox = pix - oy * p.OW;
+    const int iy0 = oy * p.stride - p.pad;
+    const int ix0 = ox * p.stride - p.pad;
+
+    // buffer descriptor over act_q, based at the first image of this tile, shifted back by
+    // pad*(W+1) units so lane offsets are non-negative; invalid taps -> voffset 0xFFFFFFFF -> 0
+    const int b_first = n0 / p.OHW;
+    const size_t img_units = (size_t)p.G * HW;
+    const int8_t *tile_base = p.in_q + ((size_t)b_first * img_units) * 16 - (ptrdiff_t)p.pad * (p.W + 1) * 16;
+    size_t rec = ((size_t)p.B - b_first) * img_units * 16 + (size_t)p.pad * (p.W + 1) * 16;
+    if (rec > 0xFFFFFFFEull) rec = 0xFFFFFFFEull;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)tile_base, 0, (int)(unsigned)rec, 0x00020000);
+    const int voff = (int)(((unsigned)(bimg - b_first) * (unsigned)img_units +
+                            (unsigned)(oy * p.stride) * (unsigned)p.W + (unsigned)(ox * p.stride)) * 16u);
+
+    // inverted tap validity, bit t = tap index ky*size+kx (size <= 5 -> 25 bits)
+    unsigned ntapmask = 0xFFFFFFFFu;
+    if (n_ok) {
+        unsigned m = 0;
+        for (int ky = 0; ky < p.size; ++ky)
+            for (int kx = 0; kx < p.size; ++kx) {
+                const int iy = iy0 + ky, ix = ix0 + kx;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) m |= 1u << (ky * p.size + kx);
+            }
+        ntapmask = ~m;
+    }
+
+    v4i a_reg[A_PER_THREAD];
+    v4i b_reg[B_PER_THREAD];
+
+#define YL_LOAD(KB)                                                                                 \
+    {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < A_PER_THREAD; ++i) {                                  \
+            const int idx = tid + i * NT;                                                           \
+            const int gr = idx / BM;                                                                \
+            const int mm = idx - gr * BM;                                                           \
+            a_reg[i] = *reinterpret_cast<const v4i *>(                                              \
+                p.w_q + ((size_t)((KB) * BK16 + gr) * p.Mpad + m0 + mm) * 16);                      \
+        }                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < B_PER_THREAD; ++i) {                                  \
+            const int g = (KB) * BK16 + g0 + i * G_STEP;          /* wave-uniform */                \
+            const int tap = g >> p.Gshift;                                                          \
+            const int cg = g & (p.G - 1);                                                           \
+            const int ky = tap / p.size;                                                            \
+            const int kx = tap - ky * p.size;                                                       \
+            const int kinv = (g >= p.K16) ? -1 : 0;                                                 \
+            const int soff = kinv ? 0 : (cg * HW + ky * p.W + kx) * 16;                             \
+            const int tinv = __builtin_amdgcn_sbfe((int)ntapmask, kinv ? 31 : tap, 1);              \
+            b_reg[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(               \
+                rsrc, voff | tinv | kinv, soff, 0));                                                \
+        }                                                                                           \
+    }
+
+#define YL_STORE(BUF)                                                                               \
+    {                                                                                               \
+        uint4 *Ab_ = As + (BUF) * BK16 * BM;                                                        \
+        uint4 *Bb_ = Bs + (BUF) * BK16 * BN;                                                        \
+        _Pragma("unroll") for (int i = 0; i < A_PER_THREAD; ++i)                                    \
+            Ab_[tid + i * NT] = __builtin_bit_cast(uint4, a_reg[i]);                                \
+        _Pragma("unroll") for (int i = 0; i < B_PER_THREAD; ++i)                                    \
+            Bb_[(g0 + i * G_STEP) * BN + n_local] = __builtin_bit_cast(uint4, b_reg[i]);            \
+    }
+
+    v16i acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int wm0 = wm * TM * 32, wn0 = wn * TN * 32;
+    const int nkb = p.K16pad / BK16;
+
+    YL_LOAD(0)
+    YL_STORE(0)
+    __syncthreads();
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+        const bool more = kb + 1 < nkb;
+        if (more) YL_LOAD(kb + 1)
+        const uint4 *Ab = As + buf * BK16 * BM + wm0 + l31;
+        const uint4 *Bb = Bs + buf * BK16 * BN + wn0 + l31;
+#pragma unroll
+        for (int ks = 0; ks < BK16 / 2; ++ks) {
+            v4i av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = __builtin_bit_cast(v4i, Ab[(2 * ks + half) * BM + i * 32]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = __builtin_bit_cast(v4i, Bb[(2 * ks + half) * BN + j * 32]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) YL_STORE(buf ^ 1)
+        __syncthreads();
+    }
+#undef YL_LOAD
+#undef YL_STORE
+
+    // ---- exact reference epilogue ----
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + l31;
+        if (n >= p.Ntotal) continue;
+        const int ob = n / p.OHW;
+        const int opix = n - ob * p.OHW;
+        const size_t obase = (size_t)ob * p.M * p.OHW + opix;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (m < p.M) {
+                    int o = acc[i][j][e] / 32;                       // C truncating division
+                    if (o > 32767) o = 32767;                        // max_abs(., 256*128-1)
+                    if (o < -32767) o = -32767;
+                    const size_t oi = obase + (size_t)m * p.OHW;
+                    if (p.dbg) p.dbg[oi] = o;
+                    float y = __fmul_rn((float)o, p.alpha1);
+                    y = __fadd_rn(y, p.bias[m]);
+                    if (p.act == YL_LEAKY) y = (y > 0.f) ? y : __fdiv_rn(y, 10.f);
+                    p.out[oi] = y;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_i8_tile(ConvI8Dev p, hipStream_t s)
+{
+    p.tiles_m = (p.M + BM - 1) / BM;
+    const long long blocks = (long long)p.tiles_m * ((p.Ntotal + BN - 1) / BN);
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(NT), 0, s, p);
+    return (int)hipGetLastError();
+}
+
+int launch_conv_i8(const ConvI8Args &a, void *stream)
+{
+    ConvI8Dev d;
+    d.in_q = a.in_q; d.w_q = a.w_q; d.bias = a.bias; d.out = a.out; d.dbg = a.dbg;
+    d.B = a.B; d.G = a.Cpad / 16; d.H = a.H; d.W = a.W; d.M = a.M; d.Mpad = a.Mpad; d.OH = a.OH; d.OW = a.OW;
+    d.size = a.size; d.stride = a.stride; d.pad = a.pad; d.act = a.act; d.alpha1 = a.alpha1;
+    if (d.G <= 0 || (d.G & (d.G - 1)) != 0 || a.size > 5) return (int)hipErrorInvalidValue;
+    d.Gshift = 0;
+    while ((1 << d.Gshift) < d.G) ++d.Gshift;
+    d.K16 = a.size * a.size * d.G;
+    d.K16pad = (d.K16 + BK16 - 1) / BK16 * BK16;
+    d.OHW = a.OH * a.OW;
+    const long long nt = (long long)a.B * d.OHW;
+    if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    d.Ntotal = (int)nt;
+    d.tiles_m = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (a.M <= 32) return launch_i8_tile<32, 256, 1, 4>(d, s);
+    if (a.M <= 64) return launch_i8_tile<64, 128, 2, 2>(d, s);
+    return launch_i8_tile<128, 128, 2, 2>(d, s);
+}
+
+}  // namespace yl

@@ -1,7 +1,187 @@
-// placeholder: replaced by the XNOR implementation
+// conv_xnor.hip -- K3: the BIT1-XNOR convolution as 64-bit packed XNOR + popcount.
+//
+// Replaces the XNOR branch of forward_convolutional_layer_cpu
+// (src/yolov2_forward_network.c:116-203: repack_input/float_to_bit/im2col/transpose_uint32 or
+// im2col_cpu_custom_bin/transpose_bin, then gemm_nn_custom_bin_mean_transposed,
+// src/additionally.c:1504-1534) and the reference GPU pipeline (float_to_bit_gpu,
+// repack_input_kernel_bin, transpose_*, gemm_nn_custom_bin_mean_transposed_*,
+// src/gpu.cu:1028-2046).  CDNA4 has no 1-bit MFMA: this is VALU work
+// (v_xnor_b32 + v_bcnt_u32_b32 with a free accumulate) behind HBM-bound FP32 I/O.
+//
+// Layout in HBM:
+//   activations  bits[B][Cw][H][W] uint64, bit (c & 63) of word plane (c >> 6) = (x[b][c][y][x] > 0)
+//                (src/additionally.c:132,1544); pad channels = 0.  Consecutive pixels are
+//                consecutive 8-byte words -> coalesced pack stores and tap loads.
+//   weights      wbits[Mpad][9][Cw] uint64, bit = (w_fused > 0); pad channels = 1, so a pad bit
+//                never matches (activation 0 vs weight 1) and out-of-image taps -- loaded as 0
+//                through the buffer descriptor's range check -- count as -1 on every REAL
+//                channel exactly like the reference's zero-padded bit im2col.
+// Mapping: one lane = one output pixel; the filter loop is wave-uniform, so the compiler
+// fetches weight words with scalar loads (SMEM) and they enter v_xnor as SGPR operands: no
+// LDS, no vector traffic for weights.  Input words of a channel chunk stay in VGPRs while FT
+// filters are accumulated; count = #matching bits is integer-exact.
+//   out = act( (2*count - K) * mean[f] + bias[f] ),  K = 9*C   (src/additionally.c:1531)
 #include <hip/hip_runtime.h>
+
 #include "kernels.h"
+#include "../../include/yolo2_hip.h"
+
 namespace yl {
-int launch_pack_sign_bits(const float *, uint64_t *, int, int, int, int, int, void *) { return (int)hipErrorNotSupported; }
-int launch_conv_xnor(const ConvXnorArgs &, void *) { return (int)hipErrorNotSupported; }
+
+// ------------------------------------------------------------------ K3a: sign-bit packing
+__global__ __launch_bounds__(256) void pack_sign_bits_kernel(const float *__restrict__ in, uint64_t *__restrict__ out,
+                                                             size_t total, int C, int HW, int Cw)
+{
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int pix = (int)(idx % HW);
+        size_t t = idx / HW;
+        const int cw = (int)(t % Cw);
+        const size_t b = t / Cw;
+        const float *src = in + (b * C + (size_t)cw * 64) * HW + pix;
+        const int nc = (C - cw * 64) < 64 ? (C - cw * 64) : 64;
+        unsigned lo = 0, hi = 0;
+        for (int j = 0; j < nc && j < 32; ++j) lo |= (src[(size_t)j * HW] > 0.f ? 1u : 0u) << j;
+        for (int j = 32; j < nc; ++j) hi |= (src[(size_t)j * HW] > 0.f ? 1u : 0u) << (j - 32);
+        out[idx] = ((uint64_t)hi << 32) | lo;
+    }
 }
+
+int launch_pack_sign_bits(const float *in, uint64_t *out, int B, int C, int H, int W, int Cw, void *stream)
+{
+    const size_t total = (size_t)B * Cw * H * W;
+    size_t g = (total + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g == 0) g = 1;
+    hipLaunchKernelGGL(pack_sign_bits_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                       in, out, total, C, H * W, Cw);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------ K3b: XNOR + popcount conv (3x3, stride 1, pad 1)
+struct ConvXnorDev {
+    const uint64_t *in_bits;
+    const uint64_t *w_bits;
+    const float *mean;
+    const float *bias;
+    float *out;
+    int32_t *dbg;
+    int B, C, Cw, H, W, M, act;
+    int Ntotal, HW;
+};
+
+template <int CWC, int FT>
+__global__ __launch_bounds__(256) void conv_xnor_kernel(ConvXnorDev p)
+{
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x * 256 + tid;
+    const int f0 = blockIdx.y * FT;
+    const bool n_ok = n < p.Ntotal;
+    const int n_first = blockIdx.x * 256;
+    const int b_first = n_first / p.HW;                          // uniform
+    const int bimg = n / p.HW;
+    const int pix = n - bimg * p.HW;
+    const int y = pix / p.W;
+    const int x = pix - y * p.W;
+
+    // descriptor based at the first image of this block, shifted back one row + one pixel
+    const size_t img_words = (size_t)p.Cw * p.HW;
+    const uint64_t *base = p.in_bits + (size_t)b_first * img_words - (p.W + 1);
+    size_t rec = (((size_t)p.B - b_first) * img_words + (size_t)(p.W + 1)) * 8;
+    if (rec > 0xFFFFFFFEull) rec = 0xFFFFFFFEull;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(unsigned)rec, 0x00020000);
+    const int voff = (int)(((unsigned)(bimg - b_first) * (unsigned)img_words + (unsigned)y * (unsigned)p.W + (unsigned)x) * 8u);
+
+    // inverted validity of the 9 taps (bit t set <=> tap outside the image -> word reads as 0)
+    unsigned ntap = 0xFFFFFFFFu;
+    if (n_ok) {
+        unsigned m = 0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = y + ky - 1, ix = x + kx - 1;
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) m |= 1u << (ky * 3 + kx);
+            }
+        ntap = ~m;
+    }
+
+    int cnt[FT];
+#pragma unroll
+    for (int f = 0; f < FT; ++f) cnt[f] = 0;
+
+    for (int cw0 = 0; cw0 < p.Cw; cw0 += CWC) {
+        unsigned in_lo[9][CWC], in_hi[9][CWC];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int tinv = __builtin_amdgcn_sbfe((int)ntap, t, 1);
+            const int ky = t / 3, kx = t - ky * 3;
+#pragma unroll
+            for (int w = 0; w < CWC; ++w) {
+                const int soff = ((cw0 + w) * p.HW + ky * p.W + kx) * 8;
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                const v2u v = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff | tinv, soff, 0));
+                in_lo[t][w] = v[0];
+                in_hi[t][w] = v[1];
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+            // wave-uniform address -> scalar loads
+            const uint64_t *wf = p.w_bits + ((size_t)(f0 + f) * 9) * p.Cw + cw0;
+            int c = cnt[f];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+#pragma unroll
+                for (int w = 0; w < CWC; ++w) {
+                    const uint64_t ww = wf[(size_t)t * p.Cw + w];
+                    c += __popc(~(in_lo[t][w] ^ (unsigned)ww));
+                    c += __popc(~(in_hi[t][w] ^ (unsigned)(ww >> 32)));
+                }
+            }
+            cnt[f] = c;
+        }
+    }
+
+    if (!n_ok) return;
+    const int K = 9 * p.C;
+    const size_t obase = (size_t)bimg * p.M * p.HW + pix;
+#pragma unroll
+    for (int f = 0; f < FT; ++f) {
+        const int m = f0 + f;
+        if (m < p.M) {
+            const size_t oi = obase + (size_t)m * p.HW;
+            if (p.dbg) p.dbg[oi] = cnt[f];
+            float v = __fmul_rn((float)(2 * cnt[f] - K), p.mean[m]);
+            v = __fadd_rn(v, p.bias[m]);
+            if (p.act == YL_LEAKY) v = (v > 0.f) ? v : (float)(.1 * (double)v);
+            p.out[oi] = v;
+        }
+    }
+}
+
+template <int CWC, int FT>
+static int launch_xnor(const ConvXnorDev &d, hipStream_t s)
+{
+    dim3 grid((unsigned)((d.Ntotal + 255) / 256), (unsigned)((d.M + FT - 1) / FT));
+    hipLaunchKernelGGL((conv_xnor_kernel<CWC, FT>), grid, dim3(256), 0, s, d);
+    return (int)hipGetLastError();
+}
+
+int launch_conv_xnor(const ConvXnorArgs &a, void *stream)
+{
+    ConvXnorDev d;
+    d.in_bits = a.in_bits; d.w_bits = a.w_bits; d.mean = a.mean; d.bias = a.bias; d.out = a.out; d.dbg = a.dbg;
+    d.B = a.B; d.C = a.C; d.Cw = a.Cw; d.H = a.H; d.W = a.W; d.M = a.M; d.act = a.act;
+    d.HW = a.H * a.W;
+    const long long nt = (long long)a.B * d.HW;
+    if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    d.Ntotal = (int)nt;
+    hipStream_t s = (hipStream_t)stream;
+    // weights are padded to a multiple of 64 filters (runtime.hip), FT must divide that
+    if (a.Cw % 4 == 0) return launch_xnor<4, 16>(d, s);
+    if (a.Cw % 2 == 0) return launch_xnor<2, 32>(d, s);
+    return launch_xnor<1, 32>(d, s);
+}
+
+}  // namespace yl

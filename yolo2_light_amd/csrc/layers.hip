@@ -294,6 +294,27 @@ struct HeadsDev {
     int n_heads;
 };
 
+// Wave-aggregated slot allocation: all lanes of a wave that pass the threshold for the same
+// image get consecutive slots from ONE atomicAdd on counts[image] (lanes of a wave almost
+// always belong to one image; the loop handles the image-boundary wave).
+__device__ __forceinline__ int wave_alloc_slot(int *counts, int b, bool pass)
+{
+    const unsigned long long lane_lt = (1ull << (threadIdx.x & 63)) - 1ull;
+    unsigned long long todo = __ballot(pass);
+    int slot = -1;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int bl = __shfl(b, leader);
+        const unsigned long long grp = __ballot(pass && b == bl);
+        int base = 0;
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&counts[bl], __popcll(grp));
+        base = __shfl(base, leader);
+        if (pass && b == bl) slot = base + __popcll(grp & lane_lt);
+        todo &= ~grp;
+    }
+    return slot;
+}
+
 // one lane per (image, head, cell, anchor).  Record row (stride = 6 + classes):
 //   x y w h objectness sort_class(-1) prob[classes]
 // boxes are relative to the network input (== get_network_boxes(net, 1, 1, thresh, ., 0, relative=1, ., 0)).
@@ -307,39 +328,43 @@ __global__ __launch_bounds__(256) void compact_kernel(HeadsDev hd, int B, int ne
         const HeadDesc &h = hd.h[hi];
         const int wh = h.w * h.h;
         const size_t total = (size_t)B * wh * h.n;
-        for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-             idx += (size_t)gridDim.x * blockDim.x) {
-            const int n = (int)(idx % h.n);
-            size_t t = idx / h.n;
-            const int cell = (int)(t % wh);
-            const int b = (int)(t / wh);
+        const size_t stride_all = (size_t)gridDim.x * blockDim.x;
+        // every lane of a wave runs the same number of iterations (wave_alloc_slot uses ballots)
+        const size_t iters = (total + stride_all - 1) / stride_all;
+        for (size_t it = 0; it < iters; ++it) {
+            const size_t idx = it * stride_all + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+            const bool in_range = idx < total;
+            // anchor index is the SLOWEST of (n, cell) inside an image so lanes walk cells (coalesced)
+            const int cell = in_range ? (int)(idx % wh) : 0;
+            const size_t t = in_range ? idx / wh : 0;
+            const int n = (int)(t % h.n);
+            const int b = (int)(t / h.n);
             const int row = cell / h.w, col = cell % h.w;
             const float *p = h.out + (size_t)b * h.outputs;
             if (h.type == YL_YOLO) {
                 const float *e = p + (size_t)n * wh * (5 + h.classes) + cell;    // entry k at e[k*wh]
-                const float objectness = e[4 * (size_t)wh];
-                if (objectness > thresh) {
-                    const int slot = atomicAdd(&counts[b], 1);
-                    if (slot < cap) {
-                        float *r = records + ((size_t)b * cap + slot) * row_stride;
-                        r[0] = __fdiv_rn(__fadd_rn((float)col, e[0]), (float)h.w);
-                        r[1] = __fdiv_rn(__fadd_rn((float)row, e[(size_t)wh]), (float)h.h);
-                        r[2] = (float)(exp((double)e[2 * (size_t)wh]) * (double)h.anchors_w[n] / (double)netw);
-                        r[3] = (float)(exp((double)e[3 * (size_t)wh]) * (double)h.anchors_h[n] / (double)neth);
-                        r[4] = objectness;
-                        r[5] = -1.f;
-                        for (int j = 0; j < h.classes; ++j) {
-                            const float prob = __fmul_rn(objectness, e[(size_t)(5 + j) * wh]);
-                            r[6 + j] = (prob > thresh) ? prob : 0.f;
-                        }
+                const float objectness = in_range ? e[4 * (size_t)wh] : 0.f;
+                const bool pass = in_range && (objectness > thresh);
+                const int slot = wave_alloc_slot(counts, b, pass);
+                if (pass && slot < cap) {
+                    float *r = records + ((size_t)b * cap + slot) * row_stride;
+                    r[0] = __fdiv_rn(__fadd_rn((float)col, e[0]), (float)h.w);
+                    r[1] = __fdiv_rn(__fadd_rn((float)row, e[(size_t)wh]), (float)h.h);
+                    r[2] = (float)(exp((double)e[2 * (size_t)wh]) * (double)h.anchors_w[n] / (double)netw);
+                    r[3] = (float)(exp((double)e[3 * (size_t)wh]) * (double)h.anchors_h[n] / (double)neth);
+                    r[4] = objectness;
+                    r[5] = -1.f;
+                    for (int j = 0; j < h.classes; ++j) {
+                        const float prob = __fmul_rn(objectness, e[(size_t)(5 + j) * wh]);
+                        r[6 + j] = (prob > thresh) ? prob : 0.f;
                     }
                 }
             } else {    // REGION: flattened HWC rows, every (cell, anchor) is a detection
                 const int index = cell * h.n + n;
                 const float *e = p + (size_t)index * (h.classes + 5);
-                const float scale = e[4];
-                const int slot = atomicAdd(&counts[b], 1);
-                if (slot < cap) {
+                const int slot = wave_alloc_slot(counts, b, in_range);
+                if (in_range && slot < cap) {
+                    const float scale = e[4];
                     float *r = records + ((size_t)b * cap + slot) * row_stride;
                     const float lx = (float)(1. / (1. + exp((double)(-e[0]))));
                     const float ly = (float)(1. / (1. + exp((double)(-e[1]))));

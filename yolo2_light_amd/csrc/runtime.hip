@@ -97,15 +97,23 @@ static int upload_conv(Network &net, Layer &l)
         YL_HIP(hipMemcpy(l.d_weights_t, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
     } else if (l.conv_mode == CONV_INT8) {
         if (!l.quant_ready) { set_error("INT8 layer without yl_network_quantize()"); return YL_ERR_STATE; }
-        // channel-fastest [Mpad][taps][Cpad], zero padded; Cpad multiple of 16 (one MFMA k-group)
+        // k-major panels of 16-byte units [K16pad][Mpad][16], K16 index = tap*G + cg, zero padded;
+        // G = channel groups of 16 rounded up to a power of two (shift/mask decode in the kernel)
         const int taps = l.size * l.size;
-        l.Cpad = round_up(l.c, 16);
+        if (l.size > 5) { set_error("INT8 conv: size > 5 unsupported"); return YL_ERR_UNSUPPORTED; }
+        int G = 1;
+        while (G * 16 < l.c) G *= 2;
+        l.Cpad = G * 16;
         l.Mpad = round_up(M, 128);
-        std::vector<int8_t> wq((size_t)l.Mpad * taps * l.Cpad, 0);
+        const int K16 = taps * G;
+        const int K16pad = round_up(K16, 8);
+        std::vector<int8_t> wq((size_t)K16pad * l.Mpad * 16, 0);
         for (int m = 0; m < M; ++m)
             for (int c = 0; c < l.c; ++c)
-                for (int t = 0; t < taps; ++t)
-                    wq[((size_t)m * taps + t) * l.Cpad + c] = l.weights_int8[((size_t)m * l.c + c) * taps + t];
+                for (int t = 0; t < taps; ++t) {
+                    const int g = t * G + c / 16;
+                    wq[((size_t)g * l.Mpad + m) * 16 + (c % 16)] = l.weights_int8[((size_t)m * l.c + c) * taps + t];
+                }
         YL_HIP(hipMalloc((void **)&l.d_weights_i8, wq.size()));
         YL_HIP(hipMemcpy(l.d_weights_i8, wq.data(), wq.size(), hipMemcpyHostToDevice));
         const size_t qb = (size_t)net.batch * l.h * l.w * l.Cpad;
@@ -269,18 +277,21 @@ static int forward_layer(Network &net, size_t i, const float *input)
     return YL_OK;
 }
 
-static int forward(Network &net, const float *input_dev, bool timed)
+// slot < 0: untimed; otherwise HIP events of timing slot `slot` are recorded around every layer
+static int forward(Network &net, const float *input_dev, int slot)
 {
     if (!net.on_device) { set_error("network not on device: call yl_network_to_device first"); return YL_ERR_STATE; }
     YL_HIP(hipSetDevice(net.device));
     const float *input = input_dev;
-    for (size_t i = 0; i < net.layers.size(); ++i) {
-        if (timed) YL_HIP(hipEventRecord((hipEvent_t)net.layer_events[i], (hipStream_t)net.stream));
+    const size_t nl = net.layers.size();
+    void **ev = slot >= 0 ? &net.layer_events[(size_t)slot * (nl + 1)] : nullptr;
+    for (size_t i = 0; i < nl; ++i) {
+        if (ev) YL_HIP(hipEventRecord((hipEvent_t)ev[i], (hipStream_t)net.stream));
         int rc = forward_layer(net, i, input);
         if (rc != YL_OK) return rc;
         input = net.layers[i].d_output;
     }
-    if (timed) YL_HIP(hipEventRecord((hipEvent_t)net.layer_events[net.layers.size()], (hipStream_t)net.stream));
+    if (ev) YL_HIP(hipEventRecord((hipEvent_t)ev[nl], (hipStream_t)net.stream));
     return YL_OK;
 }
 
@@ -530,7 +541,7 @@ int yl_network_synchronize(yl_network *net)
 int yl_network_forward(yl_network *net, const float *input_dev)
 {
     if (!net || !input_dev) { set_error("null argument"); return YL_ERR_ARG; }
-    return forward(net->net, input_dev, false);
+    return forward(net->net, input_dev, -1);
 }
 
 float *yl_network_predict(yl_network *net, const float *input)
@@ -544,7 +555,7 @@ float *yl_network_predict(yl_network *net, const float *input)
         set_error("H2D input copy failed");
         return nullptr;
     }
-    if (forward(n, n.d_input, false) != YL_OK) return nullptr;
+    if (forward(n, n.d_input, -1) != YL_OK) return nullptr;
     if (pull_heads(n, true) != YL_OK) return nullptr;
     // last non-COST layer (src/yolov2_forward_network.c:644-645); COST never parses here
     return n.layers.back().host_output;
@@ -588,10 +599,12 @@ static int pull_debug(yl_network *net, int i, int32_t *dst, int want_mode)
 int yl_network_layer_xnor_counts(yl_network *net, int i, int32_t *dst_host) { return pull_debug(net, i, dst_host, CONV_XNOR); }
 int yl_network_layer_int8_acc(yl_network *net, int i, int32_t *dst_host) { return pull_debug(net, i, dst_host, CONV_INT8); }
 
-static int ensure_layer_events(Network &n)
+#define YL_MAX_TIMING_SLOTS 64
+
+static int ensure_layer_events(Network &n, int slots)
 {
     const size_t nl = n.layers.size();
-    while (n.layer_events.size() < nl + 1) {
+    while (n.layer_events.size() < (size_t)slots * (nl + 1)) {
         hipEvent_t e;
         YL_HIP(hipEventCreate(&e));
         n.layer_events.push_back(e);
@@ -599,28 +612,29 @@ static int ensure_layer_events(Network &n)
     return YL_OK;
 }
 
-int yl_network_forward_timed(yl_network *net, const float *input_dev)
+int yl_network_forward_timed(yl_network *net, const float *input_dev, int slot)
 {
-    if (!net || !input_dev) { set_error("null argument"); return YL_ERR_ARG; }
+    if (!net || !input_dev || slot < 0 || slot >= YL_MAX_TIMING_SLOTS) { set_error("bad argument"); return YL_ERR_ARG; }
     Network &n = net->net;
     if (!n.on_device) { set_error("network not on device"); return YL_ERR_STATE; }
     YL_HIP(hipSetDevice(n.device));
-    int rc = ensure_layer_events(n);
+    int rc = ensure_layer_events(n, slot + 1);
     if (rc != YL_OK) return rc;
-    return forward(n, input_dev, true);
+    return forward(n, input_dev, slot);
 }
 
-int yl_network_layer_times(yl_network *net, float *ms_per_layer, float *total_ms)
+int yl_network_layer_times(yl_network *net, int slot, float *ms_per_layer, float *total_ms)
 {
-    if (!net) { set_error("null argument"); return YL_ERR_ARG; }
+    if (!net || slot < 0) { set_error("bad argument"); return YL_ERR_ARG; }
     Network &n = net->net;
     const size_t nl = n.layers.size();
-    if (!n.on_device || n.layer_events.size() < nl + 1) { set_error("no timed forward recorded"); return YL_ERR_STATE; }
+    if (!n.on_device || n.layer_events.size() < (size_t)(slot + 1) * (nl + 1)) { set_error("no timed forward recorded in this slot"); return YL_ERR_STATE; }
     YL_HIP(hipSetDevice(n.device));
-    YL_HIP(hipEventSynchronize((hipEvent_t)n.layer_events[nl]));
+    void **ev = &n.layer_events[(size_t)slot * (nl + 1)];
+    YL_HIP(hipEventSynchronize((hipEvent_t)ev[nl]));
     for (size_t i = 0; i < nl && ms_per_layer; ++i)
-        YL_HIP(hipEventElapsedTime(&ms_per_layer[i], (hipEvent_t)n.layer_events[i], (hipEvent_t)n.layer_events[i + 1]));
-    if (total_ms) YL_HIP(hipEventElapsedTime(total_ms, (hipEvent_t)n.layer_events[0], (hipEvent_t)n.layer_events[nl]));
+        YL_HIP(hipEventElapsedTime(&ms_per_layer[i], (hipEvent_t)ev[i], (hipEvent_t)ev[i + 1]));
+    if (total_ms) YL_HIP(hipEventElapsedTime(total_ms, (hipEvent_t)ev[0], (hipEvent_t)ev[nl]));
     return YL_OK;
 }
 
@@ -635,28 +649,24 @@ int yl_network_profile(yl_network *net, const float *input_dev, int iters, float
     if (!net || !input_dev || iters <= 0) { set_error("bad argument"); return YL_ERR_ARG; }
     Network &n = net->net;
     if (!n.on_device) { set_error("network not on device"); return YL_ERR_STATE; }
-    YL_HIP(hipSetDevice(n.device));
     const size_t nl = n.layers.size();
-    { int rc0 = ensure_layer_events(n); if (rc0 != YL_OK) return rc0; }
     std::vector<double> acc(nl, 0.0);
+    std::vector<float> ms(nl, 0.f);
     double tot = 0.0;
     for (int it = 0; it < iters; ++it) {
-        int rc = forward(n, input_dev, true);
+        int rc = yl_network_forward_timed(net, input_dev, 0);
         if (rc != YL_OK) return rc;
-        YL_HIP(hipEventSynchronize((hipEvent_t)n.layer_events[nl]));
-        for (size_t i = 0; i < nl; ++i) {
-            float ms = 0.f;
-            YL_HIP(hipEventElapsedTime(&ms, (hipEvent_t)n.layer_events[i], (hipEvent_t)n.layer_events[i + 1]));
-            acc[i] += ms;
-        }
-        float ms = 0.f;
-        YL_HIP(hipEventElapsedTime(&ms, (hipEvent_t)n.layer_events[0], (hipEvent_t)n.layer_events[nl]));
-        tot += ms;
+        float t = 0.f;
+        rc = yl_network_layer_times(net, 0, ms.data(), &t);
+        if (rc != YL_OK) return rc;
+        for (size_t i = 0; i < nl; ++i) acc[i] += ms[i];
+        tot += t;
     }
     if (ms_per_layer) for (size_t i = 0; i < nl; ++i) ms_per_layer[i] = (float)(acc[i] / iters);
     if (total_ms) *total_ms = (float)(tot / iters);
     return YL_OK;
 }
+
 
 int yl_network_get_boxes(yl_network *net, int image, int w, int h, float thresh, int relative, int letter,
                          float nms, float *rows, int max_rows, int *classes_out)

@@ -210,13 +210,13 @@ class Network:
               "yl_network_profile")
         return ms, float(tot.value)
 
-    def forward_timed(self, input_dev_ptr: int) -> None:
-        check(lib.yl_network_forward_timed(self._h, C.c_void_p(input_dev_ptr)), "yl_network_forward_timed")
+    def forward_timed(self, input_dev_ptr: int, slot: int = 0) -> None:
+        check(lib.yl_network_forward_timed(self._h, C.c_void_p(input_dev_ptr), slot), "yl_network_forward_timed")
 
-    def layer_times(self):
+    def layer_times(self, slot: int = 0):
         ms = np.zeros(self.n, dtype=np.float32)
         tot = C.c_float(0)
-        check(lib.yl_network_layer_times(self._h, _fp(ms), C.byref(tot)), "yl_network_layer_times")
+        check(lib.yl_network_layer_times(self._h, slot, _fp(ms), C.byref(tot)), "yl_network_layer_times")
         return ms, float(tot.value)
 
     def layer_kernel(self, i: int) -> str:

@@ -197,7 +197,7 @@ def conv_shapes(text: str) -> List[dict]:
             pad = size // 2 if int(o.get("pad", 0)) else int(o.get("padding", 0))
             convs.append(dict(index=idx, n=n, c=c, size=size, bn=int(o.get("batch_normalize", 0)),
                               linear=o.get("activation", "logistic") == "linear",
-                              head_anchors=0, head_classes=0))
+                              head_anchors=0, head_classes=0, before_shortcut=False))
             h, w, c = (h + 2 * pad - size) // stride + 1, (w + 2 * pad - size) // stride + 1, n
         elif typ == "maxpool":
             stride = int(o.get("stride", 1))
@@ -225,6 +225,9 @@ def conv_shapes(text: str) -> List[dict]:
             if convs and convs[-1]["index"] == idx - 1:
                 convs[-1]["head_anchors"] = anchors
                 convs[-1]["head_classes"] = classes
-        # shortcut keeps h, w, c
+        elif typ == "shortcut":
+            # shortcut keeps h, w, c; tag the conv producing the residual branch
+            if convs and convs[-1]["index"] == idx - 1:
+                convs[-1]["before_shortcut"] = True
         outs.append((h, w, c))
     return convs
