@@ -225,6 +225,10 @@ int yl_network_pull_heads(yl_network *net);
  * conv launch in this process (0 = built-in heuristic; 1..8 see conv_f32_mfma.hip).
  * yl_debug_last_conv_tile returns the name of the tile the last launch used. */
 int yl_debug_force_conv_tile(int cfg);
+/* Tuning/test hook: K1 schedule used by networks uploaded AFTER this call:
+ * 0 = v1 burst schedule, 1 = v2 software-pipelined schedule (default); with v2, forced tile
+ * ids are 10 + cfg (conv_f32_mfma_v2.hip). */
+int yl_debug_set_conv_variant(int v);
 const char *yl_debug_last_conv_tile(void);
 
 /* On-device detection compaction (new): threshold test

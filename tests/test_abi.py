@@ -1,0 +1,66 @@
+"""The C-ABI library loads and exports every symbol include/yolo2_hip.h declares
+(no compute calls: this runs without a GPU)."""
+import os
+import re
+
+import common  # noqa: F401
+from yolo2_light_amd import _lib
+
+HEADER = os.path.join(common.ROOT, "include", "yolo2_hip.h")
+
+
+def header_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(yl_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_every_declared_symbol_is_exported():
+    names = header_functions()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(_lib.lib, n), "libyolo2hip.so does not export %s" % n
+
+
+def test_binding_table_matches_header():
+    assert sorted(_lib.EXPORTED) == header_functions()
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """Device entry points must fail with an error (never compute on the CPU)."""
+    import numpy as np
+    import descs as D
+    if _lib.lib.yl_device_count() > 0:
+        return
+    w = np.ones(3 * 4, np.float32)
+    d = D.conv(1, 4, 4, 3, 4, 1, 1, 0, D.LINEAR, w, np.zeros(4, np.float32))
+    from yolo2_light_amd import Network, YoloHipError
+    net = Network.from_desc([d], 1, 4, 4, 3)
+    try:
+        net.to_device(0)
+    except YoloHipError as e:
+        assert "no HIP device" in str(e) or "hip" in str(e).lower()
+    else:
+        raise AssertionError("to_device succeeded without a GPU")
+    try:
+        net.predict(np.zeros((1, 3, 4, 4), np.float32))
+    except YoloHipError:
+        pass
+    else:
+        raise AssertionError("predict succeeded without a GPU")
+
+
+def test_layer_desc_struct_matches_header_field_order():
+    text = open(HEADER).read()
+    body = text[text.index("typedef struct yl_layer_desc {"):text.index("} yl_layer_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^(const\s+)?(int8_t|int|float|unsigned char)\s*", "", decl)
+        for part in decl.split(","):
+            fields.append(part.replace("*", "").replace("const", "").strip())
+    assert fields == [f[0] for f in _lib.LayerDesc._fields_]

@@ -1,0 +1,58 @@
+"""Host detection decode + NMS (yl_network_get_boxes) against the reference's
+get_network_boxes + do_nms_sort on the SAME head tensors: bit-exact, same order.
+CPU only: the head tensors come from the reference CPU path."""
+import numpy as np
+import pytest
+
+import common
+import descs as D
+from common import Network, refbind
+
+pytestmark = pytest.mark.skipif(not refbind.available(), reason="oracle/_ref not built")
+
+
+def _head_only_network(ref, cfg_text, batch, keep):
+    """A desc network that contains just the YOLO/REGION layers, with `output`
+    pointing at the reference's head tensors."""
+    from yolo2_light_amd import zoo
+    secs = zoo.parse_sections(cfg_text)[1:]
+    descs = []
+    for i in range(ref.n):
+        li = ref.layer_info(i)
+        if li["type"] == common.YOLO:
+            o = secs[i][1]
+            mask = [int(v) for v in o["mask"].split(",")]
+            anchors = [float(v) for v in o["anchors"].split(",")]
+            d = D.yolo(batch, li["w"], li["h"], li["n"], li["classes"], li["total"], mask, anchors)
+        elif li["type"] == common.REGION:
+            o = secs[i][1]
+            anchors = [float(v) for v in o["anchors"].split(",")]
+            d = D.region(batch, li["w"], li["h"], li["n"], li["classes"], anchors, softmax=1)
+        else:
+            continue
+        out = ref.layer_output(i)
+        keep.append(out)
+        d.output = common.fp(out)
+        descs.append(d)
+    return Network.from_desc(descs, batch, ref.w, ref.hgt, ref.c)
+
+
+@pytest.mark.parametrize("name,width,height,batch", [("yolov3-tiny", 160, 160, 2), ("yolov3", 96, 96, 2),
+                                                     ("tiny-yolo-xnor", 160, 160, 2)])
+@pytest.mark.parametrize("nms", [0.0, 0.4])
+def test_get_boxes_equals_reference(name, width, height, batch, nms):
+    cfg, wts = common.model_files(name, width, height)
+    ref = refbind.RefNetwork(cfg, wts, batch, 0)
+    x = common.seeded_input(batch, 3, height, width)
+    ref.predict(x)
+    keep = []
+    net = _head_only_network(ref, open(cfg).read(), batch, keep)
+    total = 0
+    for b in range(batch):
+        for (iw, ih, rel) in [(width, height, 1), (768, 576, 0)]:
+            r = ref.get_detections(b, iw, ih, 0.24, nms=nms, relative=rel)
+            g = net.get_boxes(b, iw, ih, 0.24, nms=nms, relative=rel)
+            assert r.shape == g.shape, (b, r.shape, g.shape)
+            assert np.array_equal(r.view(np.uint32), g.view(np.uint32)), "image %d" % b
+            total += len(r)
+    assert total > 0, "fixture produced no detections at all"

@@ -43,12 +43,19 @@ CONV_SHAPES = [
     (1, 6, 11, 11, 40, 1, 2, 0, D.LINEAR),         # 1x1 stride 2
     (5, 20, 5, 5, 70, 3, 1, 1, D.LEAKY),           # many tiny images in one N tile
     (1, 256, 13, 13, 512, 3, 1, 1, D.LEAKY),       # deep K = 2304
+    (2, 48, 11, 9, 96, 3, 1, 1, D.LEAKY),          # C % 16 == 0 but % 32 != 0 (BK=32 variants fall back)
+    (1, 32, 10, 12, 20, 5, 2, 2, D.LINEAR),        # 5x5 stride 2, tap-major generic size
 ]
 
 
+# (variant, forced tile): variant 0 = v1 burst schedule (tiles 1..8), variant 1 = v2 software-pipelined
+# schedule with tap-major K order where C % 16 == 0 (tiles 11..19); tile 0 = the built-in heuristic
+VARIANT_TILES = [(0, t) for t in range(0, 9)] + [(1, 0)] + [(1, t) for t in range(11, 20)]
+
+
 @pytest.mark.parametrize("shape", CONV_SHAPES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7, 8])
-def test_conv_f32_vs_oracle(olib, shape, tile):
+@pytest.mark.parametrize("variant,tile", VARIANT_TILES)
+def test_conv_f32_vs_oracle(olib, shape, variant, tile):
     B, Cc, H, W, M, size, stride, pad, act = shape
     rng = np.random.default_rng(1234 + M + size)
     K = Cc * size * size
@@ -56,16 +63,18 @@ def test_conv_f32_vs_oracle(olib, shape, tile):
     bias = rng.normal(0, 0.5, M).astype(np.float32)
     x = rng.standard_normal((B, Cc, H, W)).astype(np.float32)
     d = D.conv(B, W, H, Cc, M, size, stride, pad, act, wts, bias)
+    lib.yl_debug_set_conv_variant(variant)
     lib.yl_debug_force_conv_tile(tile)
     try:
         net = _net_from([d], B, W, H, Cc)
         got = net.predict(x)
     finally:
         lib.yl_debug_force_conv_tile(0)
+        lib.yl_debug_set_conv_variant(1)
     ref = np.zeros(B * d.outputs, dtype=np.float32)
     olib.oracle_conv_f32(fp(x), fp(wts), fp(bias), fp(ref), B, Cc, H, W, M, size, stride, pad, act)
     ok, ratio, worst = fp32_close(got, ref)
-    assert ok, "tile %d shape %r: err/allowed %.3g at %d: got %r ref %r" % (tile, shape, ratio, worst, got[worst], ref[worst])
+    assert ok, "variant %d tile %d shape %r: err/allowed %.3g at %d: got %r ref %r" % (variant, tile, shape, ratio, worst, got[worst], ref[worst])
     # MFMA f32 is an fma chain: expect f32-roundoff-class agreement, far inside the 1e-4 bar
     assert ratio < 0.2
     net.close()
@@ -242,9 +251,11 @@ def test_full_size_vs_reference_library(name, width, height, batch):
         if len(r) and len(g):
             # match rows by box (NMS ordering of near-equal probabilities is not stable under
             # 1e-6 perturbations), then compare objectness and per-class probabilities
-            dist = np.abs(r[:, None, :4] - g[None, :, :4]).max(axis=2)
+            with np.errstate(invalid="ignore", over="ignore"):
+                dist = (np.abs(r[:, None, :4] - g[None, :, :4]) / (1e-5 + 1e-4 * np.abs(r[:, None, :4]))).max(axis=2)
+            dist = np.nan_to_num(dist, nan=0.0)          # inf - inf: both overflowed identically
             j = dist.argmin(axis=1)
-            matched = dist[np.arange(len(r)), j] < 1e-4
+            matched = dist[np.arange(len(r)), j] < 1.0
             assert matched.mean() > 0.99
             rr, gg = r[matched], g[j[matched]]
             np.testing.assert_allclose(gg[:, 4], rr[:, 4], rtol=1e-4, atol=1e-5)

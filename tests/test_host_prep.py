@@ -1,0 +1,98 @@
+"""Host-side model build: our cfg parser + prep passes (BN fuse, binary means,
+INT8 weight quantisation + multipliers) against the reference's own
+(oracle/_ref) and against the oracle restatement.  Bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import common
+from common import Network, fp, refbind
+
+GEOM = ("type", "w", "h", "c", "n", "size", "stride", "pad", "out_w", "out_h", "out_c", "outputs", "inputs")
+
+MODELS = [("yolov3-tiny", 416, 416), ("yolov3", 608, 608), ("tiny-yolo-xnor", 416, 416), ("yolov3", 96, 160)]
+
+
+@pytest.mark.skipif(not refbind.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name,width,height", MODELS)
+@pytest.mark.parametrize("quantized", [0, 1])
+def test_parser_and_prep_match_reference(name, width, height, quantized):
+    cfg, wts = common.model_files(name, width, height)
+    ref = refbind.RefNetwork(cfg, wts, 2, quantized)
+    net = Network.load(cfg, wts, 2, quantized)
+    assert ref.n == net.n
+    convs = 0
+    for i in range(net.n):
+        a, b = net.layer_info(i), ref.layer_info(i)
+        for k in GEOM:
+            if a["type"] in (common.ROUTE, common.REGION) and k in ("w", "h", "c", "n", "out_w", "out_h", "out_c", "size", "stride"):
+                continue     # fields the reference leaves unset for these layers
+            if a["type"] in (common.SHORTCUT, common.YOLO, common.UPSAMPLE, common.MAXPOOL) and k in ("size", "stride", "pad", "n"):
+                if a["type"] == common.MAXPOOL or (a["type"] == common.UPSAMPLE and k == "stride") or (a["type"] == common.YOLO and k == "n"):
+                    pass
+                else:
+                    continue
+            assert a[k] == b[k], (i, k, a[k], b[k])
+        if a["type"] == common.CONV:
+            convs += 1
+            assert a["activation"] == b["activation"] and a["xnor"] == b["xnor"]
+            assert np.array_equal(net.layer_weights(i).view(np.uint32), ref.layer_weights(i).view(np.uint32)), i
+            assert np.array_equal(net.layer_biases(i).view(np.uint32), ref.layer_biases(i).view(np.uint32)), i
+            if a["xnor"]:
+                assert np.array_equal(net.layer_mean_arr(i).view(np.uint32), ref.layer_mean_arr(i).view(np.uint32)), i
+            if quantized:
+                assert np.array_equal(net.layer_weights_int8(i), ref.layer_weights_int8(i)), i
+                assert net.layer_quant_multipliers(i) == ref.layer_quant_multipliers(i), i
+        if a["type"] == common.SHORTCUT:
+            assert a["index"] == b["index"]
+        if a["type"] in (common.YOLO, common.REGION):
+            assert a["classes"] == b["classes"] and a["n"] == b["n"]
+    assert convs > 0
+
+
+def test_prep_matches_oracle_restatement(olib):
+    """The same passes against oracle/yolo2_oracle.c (runs even without oracle/_ref)."""
+    rng = np.random.default_rng(4)
+    n, fs = 7, 45
+    w = rng.normal(0, 0.3, n * fs).astype(np.float32)
+    b = rng.normal(0, 0.1, n).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    mu = rng.normal(0, 0.1, n).astype(np.float32)
+    var = rng.uniform(0.5, 1.5, n).astype(np.float32)
+    import descs as D
+    d = D.conv(1, 5, 5, 5, n, 3, 1, 1, D.LEAKY, w, b, xnor=1)
+    d.batch_normalize = 1
+    d.scales = fp(sc); d.rolling_mean = fp(mu); d.rolling_variance = fp(var)
+    l0 = D.maxpool(1, 5, 5, 5, 1, 1, pad=0)
+    net = Network.from_desc([l0, d], 1, 5, 5, 5, quantized=1)
+    net.fuse_conv_batchnorm(); net.calculate_binary_weights(); net.quantize()
+    w2, b2 = w.copy(), b.copy()
+    olib.oracle_fuse_bn(fp(w2), fp(b2), fp(sc), fp(mu), fp(var), n, fs)
+    assert np.array_equal(net.layer_weights(1).view(np.uint32), w2.view(np.uint32))
+    assert np.array_equal(net.layer_biases(1).view(np.uint32), b2.view(np.uint32))
+    mean = np.zeros(n, np.float32)
+    olib.oracle_binary_mean(fp(w2), n, fs, fp(mean))
+    assert np.array_equal(net.layer_mean_arr(1).view(np.uint32), mean.view(np.uint32))
+    wq = np.zeros(n * fs, np.int8)
+    wm = olib.oracle_quantize_weights(fp(w2), n * fs, wq.ctypes.data_as(C.POINTER(C.c_int8)))
+    assert np.array_equal(net.layer_weights_int8(1), wq)
+    assert net.layer_quant_multipliers(1)[1] == wm
+    assert net.layer_quant_multipliers(1)[0] == 40.0          # no calibration list -> 40
+
+
+def test_cfg_errors_are_reported(tmp_path):
+    from yolo2_light_amd import YoloHipError
+    p = tmp_path / "bad.cfg"
+    p.write_text("[net]\nwidth=32\nheight=32\nchannels=3\n[convolutional]\nfilters=8\nsize=3\nstride=1\npad=1\nactivation=leaky\n[yolo]\nmask=0\nanchors=1,2\nclasses=80\nnum=1\n")
+    with pytest.raises(YoloHipError):
+        Network.from_cfg(str(p), 1, 0)           # filters != n*(classes+5)
+    with pytest.raises(YoloHipError):
+        Network.from_cfg(str(tmp_path / "missing.cfg"), 1, 0)
+    p2 = tmp_path / "short.cfg"
+    p2.write_text("[net]\nwidth=32\nheight=32\nchannels=3\n[convolutional]\nfilters=8\nsize=3\nstride=1\npad=1\nactivation=leaky\n")
+    net = Network.from_cfg(str(p2), 1, 0)
+    wfile = tmp_path / "short.weights"
+    wfile.write_bytes(b"\0" * 40)
+    with pytest.raises(YoloHipError):
+        net.load_weights(str(wfile))             # truncated file is refused, not half-loaded

@@ -30,7 +30,9 @@ SHAPES_608 = [
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--tiles", default="0,1,2,3,6,7,8")
+    ap.add_argument("--tiles", default="0,11,12,13,15,16,17,18,19",
+                    help="forced tile ids: 1..8 = v1 kernel, 11..19 = v2 pipelined kernel, 0 = heuristic")
+    ap.add_argument("--variant", type=int, default=1, help="0 = v1 (c-major weights), 1 = v2 (tap-major where possible)")
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--only", default="", help="comma list of shape indices")
     args = ap.parse_args()
@@ -40,6 +42,7 @@ def main():
     from yolo2_light_amd._lib import lib
 
     tiles = [int(t) for t in args.tiles.split(",")]
+    lib.yl_debug_set_conv_variant(args.variant)
     only = [int(i) for i in args.only.split(",")] if args.only else range(len(SHAPES_608))
     rng = np.random.default_rng(0)
     B = args.batch
@@ -58,17 +61,18 @@ def main():
         flops = 2.0 * M * K * d.out_h * d.out_w * B
         best = None
         for t in tiles:
-            if t in (1, 6, 7, 8) and M <= 32 and t != 1:
-                pass
             lib.yl_debug_force_conv_tile(t)
             try:
                 net.profile(x.data_ptr(), 1)          # warm-up
                 ms, _ = net.profile(x.data_ptr(), args.iters)
+            except Exception as e:                    # a tile that does not apply to this shape
+                print("# shape %d tile %d: %s" % (si, t, e), flush=True)
+                continue
             finally:
                 lib.yl_debug_force_conv_tile(0)
             tf = flops / (ms[0] * 1e-3) / 1e12
             rec = {"shape": si, "M": M, "C": Cc, "size": size, "stride": stride, "H": H, "count": cnt,
-                   "tile": t, "kernel": net.layer_kernel(0), "ms": float(ms[0]), "tflops": tf}
+                   "tile": t, "kernel": net.layer_kernel(0), "ms": float(ms[0]), "tflops": float(tf)}
             print(json.dumps(rec), flush=True)
             if t != 0 and (best is None or ms[0] < best[1]):
                 best = (t, float(ms[0]), tf, net.layer_kernel(0))

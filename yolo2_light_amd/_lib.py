@@ -96,6 +96,7 @@ _SIGS = {
     "yl_network_pull_heads": (C.c_int, [_vp]),
     "yl_debug_force_conv_tile": (C.c_int, [C.c_int]),
     "yl_debug_last_conv_tile": (C.c_char_p, []),
+    "yl_debug_set_conv_variant": (C.c_int, [C.c_int]),
     "yl_network_compact_detections": (C.c_int, [_vp, C.c_float, C.c_int, _vp, _vp]),
 }
 

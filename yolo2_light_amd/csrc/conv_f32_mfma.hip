@@ -301,8 +301,26 @@ static int launch_tile(const ConvF32Dev &d, int ks, hipStream_t s)
     return (int)hipGetLastError();
 }
 
+static int g_variant = 1;      // 0 = v1 burst schedule, 1 = v2 software-pipelined schedule (default)
+void conv_f32_set_variant(int v) { g_variant = v; }
+int conv_f32_get_variant() { return g_variant; }
+
 int launch_conv_f32(const ConvF32Args &a, void *stream)
 {
+    if (a.tapmajor || g_variant >= 1) {
+        int cfg = g_force_tile >= 10 ? g_force_tile - 10 : 0;
+        if (cfg == 0) {
+            const long long ntot = (long long)a.B * a.OH * a.OW;
+            auto nblocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((ntot + bn - 1) / bn); };
+            if (a.M <= 32) cfg = 3;
+            else if (a.M <= 64) cfg = 2;
+            else cfg = 1;
+            if (nblocks(cfg == 1 ? 128 : (cfg == 2 ? 64 : 32), cfg == 3 ? 256 : 128) < 512) cfg = 4;
+        }
+        // BK=32 variants need C % 32 == 0 in tap-major order
+        if ((cfg == 5 || cfg == 8) && a.tapmajor && (a.C % 32) != 0) cfg = (cfg == 5) ? 1 : 6;
+        return launch_conv_f32_v2(a, cfg, stream, g_last_tile, sizeof(g_last_tile));
+    }
     ConvF32Dev d;
     d.in = a.in; d.wt = a.wt; d.bias = a.bias; d.add = a.add; d.out = a.out;
     d.B = a.B; d.C = a.C; d.H = a.H; d.W = a.W; d.M = a.M; d.OH = a.OH; d.OW = a.OW;

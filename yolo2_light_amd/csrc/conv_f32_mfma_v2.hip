@@ -1,0 +1,370 @@
+// conv_f32_mfma_v2.hip -- K1, software-pipelined variant.
+//
+// Same math, layouts and epilogue as conv_f32_mfma.hip (see the header there), different
+// schedule.  Measured on MI355X (profiles/): in the first version every wave issues its whole
+// im2col gather (~100 SALU/VALU + 10 VMEM) in one burst in front of the 32-MFMA block and its
+// LDS writes + vmcnt(0) behind it, so the matrix pipe idles ~37 % of the cycles even with 2-3
+// workgroups per CU.  v_mfma_f32_32x32x2_f32 occupies the pipe for 64 cycles while the wave
+// can keep issuing independent instructions, so here the staging work is cut into BK/2 slices
+// and each slice is placed between the MFMAs of one k-step:
+//
+//   iteration kb (registers hold panel kb+1, loaded one iteration ago):
+//     for ks in 0 .. BK/2-1:
+//        ds_write   slice ks of panel kb+1  -> LDS buffer (kb+1)&1   (not read in this iteration)
+//        buffer/global loads slice ks of panel kb+2 -> the SAME registers
+//        ds_read    operands of k-step ks+1
+//        TM*TN MFMAs of k-step ks
+//        sched_barrier                        (pins the slice to its k-step)
+//     one barrier
+//
+// Loads get a whole iteration (>= BK/2 * TM*TN * 64 cycles) of latency budget, waits are
+// counted vmcnt(N) (loads return in order), and no instruction burst separates MFMA blocks.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+#include "kernels.h"
+#include "../../include/yolo2_hip.h"
+
+namespace yl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvF32DevV2 {
+    const float *in;
+    const float *wt;
+    const float *bias;
+    const float *add;
+    float *out;
+    int B, C, H, W, M, OH, OW;
+    int K, Kpad, Mpad;
+    int size, stride, pad;
+    int act;
+    int Ntotal;
+    int OHW;
+    int tiles_m;
+};
+
+template <int BM, int BN, int WM, int WN, int KS, int BK, int NWAVES, bool TAPMAJOR>
+__global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32DevV2 p)
+{
+    constexpr int NT = NWAVES * 64;
+    constexpr int TM = BM / (WM * 32);
+    constexpr int TN = BN / (WN * 32);
+    constexpr int KSTEPS = BK / 2;
+    static_assert(WM * WN == NWAVES, "wave grid");
+    static_assert(TM >= 1 && TN >= 1, "tile too small");
+    static_assert(BN % 64 == 0 && BN <= NT, "a wave must stay inside one k row of the B panel");
+    constexpr int A_F4 = BK * BM / 4;
+    constexpr int APT = (A_F4 + NT - 1) / NT;               // float4 per thread per panel
+    constexpr bool A_FULL = (A_F4 % NT) == 0;
+    constexpr int BPT = BK * BN / NT;                       // gathered floats per thread per panel
+    constexpr int K_STEP = NT / BN;
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * BM + 2 * BK * BN];
+    float *As = smem;
+    float *Bs = smem + 2 * BK * BM;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tile_m = logical % p.tiles_m;
+    const int tile_n = logical / p.tiles_m;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const int n_local = tid % BN;
+    const int krow0 = __builtin_amdgcn_readfirstlane(tid / BN);
+    const int HW = p.H * p.W;
+    const int CHW = p.C * HW;
+    const int n_g = n0 + n_local;
+    const bool n_ok = n_g < p.Ntotal;
+    const int bimg = n_g / p.OHW;
+    const int pix = n_g - bimg * p.OHW;
+    const int oy = pix / p.OW;
+    const int ox = pix - oy * p.OW;
+    const int iy0 = oy * p.stride - p.pad;
+    const int ix0 = ox * p.stride - p.pad;
+
+    const int b_first = n0 / p.OHW;
+    const float *tile_base = p.in + (size_t)b_first * CHW - (ptrdiff_t)p.pad * (p.W + 1);
+    size_t rec = ((size_t)p.B - b_first) * CHW * sizeof(float) + (size_t)p.pad * (p.W + 1) * sizeof(float);
+    if (rec > 0xFFFFFFFEull) rec = 0xFFFFFFFEull;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)tile_base, 0, (int)(unsigned)rec, 0x00020000);
+    const int voff = (int)(((unsigned)(bimg - b_first) * (unsigned)CHW +
+                            (unsigned)(oy * p.stride) * (unsigned)p.W + (unsigned)(ox * p.stride)) * 4u);
+
+    unsigned ntapmask = 0xFFFFFFFFu;
+    if (n_ok) {
+        if (KS == 1) {
+            ntapmask = 0u;
+        } else if (KS == 0 && TAPMAJOR) {
+            unsigned m = 0;
+            for (int ky = 0; ky < p.size; ++ky)
+                for (int kx = 0; kx < p.size; ++kx) {
+                    const int iy = iy0 + ky, ix = ix0 + kx;
+                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) m |= 1u << (ky * p.size + kx);
+                }
+            ntapmask = ~m;
+        } else if (KS == 3) {
+            unsigned m = 0;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int iy = iy0 + ky, ix = ix0 + kx;
+                    if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) m |= 1u << (ky * 3 + kx);
+                }
+            ntapmask = ~m;
+        }
+    }
+
+    float a_reg[APT][4];
+    float b_reg[BPT];
+
+    // ---- slice helpers (E = element index inside the thread's share of a panel) ----
+#define YL_LOAD_A(KB, E)                                                                           \
+    {                                                                                              \
+        const int idx = tid + (E) * NT;                                                            \
+        if (A_FULL || idx < A_F4) {                                                                \
+            const int kr = idx / (BM / 4);                                                         \
+            const int c4 = idx - kr * (BM / 4);                                                    \
+            const float4 t4 = *reinterpret_cast<const float4 *>(                                   \
+                p.wt + (size_t)((KB) * BK + kr) * p.Mpad + m0 + c4 * 4);                           \
+            a_reg[E][0] = t4.x; a_reg[E][1] = t4.y; a_reg[E][2] = t4.z; a_reg[E][3] = t4.w;        \
+        }                                                                                          \
+    }
+#define YL_LOAD_B(KB, E)                                                                           \
+    {                                                                                              \
+        const int k = (KB) * BK + krow0 + (E) * K_STEP;            /* wave-uniform */              \
+        /* tap-major needs C % BK == 0, so K == Kpad and no K tail exists */                       \
+        const int kinv = TAPMAJOR ? 0 : ((k >= p.K) ? -1 : 0);                                     \
+        int soff, tinv;                                                                            \
+        if (TAPMAJOR) {                                                                            \
+            /* K order (tap, c): the whole panel shares one tap; decode hoisted to pn_* */         \
+            soff = pn_soff + (krow0 + (E) * K_STEP) * HW * 4;                                      \
+            tinv = pn_tinv;                                                                        \
+        } else if (KS == 1) {                                                                      \
+            soff = k * HW * 4;                                                                     \
+            tinv = (int)ntapmask;                                                                  \
+        } else if (KS == 3) {                                                                      \
+            const int c = k / 9;                                                                   \
+            const int rr = k - c * 9;                                                              \
+            const int ky = rr / 3;                                                                 \
+            const int kx = rr - ky * 3;                                                            \
+            soff = (c * HW + ky * p.W + kx) * 4;                                                   \
+            tinv = __builtin_amdgcn_sbfe((int)ntapmask, rr, 1);                                    \
+        } else {                                                                                   \
+            const int ss = p.size * p.size;                                                        \
+            const int c = k / ss;                                                                  \
+            const int rr = k - c * ss;                                                             \
+            const int ky = rr / p.size;                                                            \
+            const int kx = rr - ky * p.size;                                                       \
+            const int iy = iy0 + ky, ix = ix0 + kx;                                                \
+            soff = (c * HW + ky * p.W + kx) * 4;                                                   \
+            tinv = (n_ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? 0 : -1;                  \
+        }                                                                                          \
+        if (kinv) soff = 0;                                                                        \
+        b_reg[E] = __builtin_bit_cast(float,                                                       \
+            __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff | tinv | kinv, soff, 0));              \
+    }
+#define YL_STORE_A(BUF, E)                                                                         \
+    {                                                                                              \
+        const int idx = tid + (E) * NT;                                                            \
+        if (A_FULL || idx < A_F4)                                                                  \
+            *reinterpret_cast<float4 *>(As + (BUF) * BK * BM + idx * 4) =                          \
+                make_float4(a_reg[E][0], a_reg[E][1], a_reg[E][2], a_reg[E][3]);                   \
+    }
+#define YL_STORE_B(BUF, E)                                                                         \
+    { Bs[(BUF) * BK * BN + (krow0 + (E) * K_STEP) * BN + n_local] = b_reg[E]; }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int wm = wave / WN;
+    const int wn = wave - wm * WN;
+    const int wm0 = wm * TM * 32;
+    const int wn0 = wn * TN * 32;
+    const int nkb = p.Kpad / BK;
+
+    // tap-major panel state: tap index / first channel of the NEXT panel to be loaded
+    int pn_tap = 0, pn_c0 = 0, pn_soff = 0, pn_tinv = 0;
+#define YL_PANEL_SETUP()                                                                           \
+    if (TAPMAJOR) {                                                                                \
+        const int ky = (KS == 3) ? ((pn_tap * 11) >> 5) : (pn_tap / p.size);                       \
+        const int kx = pn_tap - ky * ((KS == 3) ? 3 : p.size);                                     \
+        pn_soff = (pn_c0 * HW + ky * p.W + kx) * 4;                                                \
+        pn_tinv = __builtin_amdgcn_sbfe((int)ntapmask, pn_tap, 1);                                 \
+    }
+#define YL_PANEL_ADVANCE()                                                                         \
+    if (TAPMAJOR) {                                                                                \
+        pn_c0 += BK;                                                                               \
+        if (pn_c0 >= p.C) { pn_c0 = 0; ++pn_tap; }                                                 \
+    }
+
+    // ---- prologue: panel 0 -> LDS buffer 0, panel 1 -> registers ----
+    YL_PANEL_SETUP()
+#pragma unroll
+    for (int e = 0; e < APT; ++e) YL_LOAD_A(0, e)
+#pragma unroll
+    for (int e = 0; e < BPT; ++e) YL_LOAD_B(0, e)
+#pragma unroll
+    for (int e = 0; e < APT; ++e) YL_STORE_A(0, e)
+#pragma unroll
+    for (int e = 0; e < BPT; ++e) YL_STORE_B(0, e)
+    YL_PANEL_ADVANCE()
+    if (nkb > 1) {
+        YL_PANEL_SETUP()
+#pragma unroll
+        for (int e = 0; e < APT; ++e) YL_LOAD_A(1, e)
+#pragma unroll
+        for (int e = 0; e < BPT; ++e) YL_LOAD_B(1, e)
+        YL_PANEL_ADVANCE()
+    }
+    __syncthreads();
+
+    // one k-block; DO_STORE: registers (panel kb+1) -> LDS[buf^1]; DO_LOAD: panel kb+2 -> registers
+#define YL_ITER(KB, DO_STORE, DO_LOAD)                                                             \
+    {                                                                                              \
+        const int buf = (KB) & 1;                                                                  \
+        if (DO_LOAD) { YL_PANEL_SETUP() }                                                          \
+        const float *Ab = As + buf * BK * BM + wm0 + l31;                                          \
+        const float *Bb = Bs + buf * BK * BN + wn0 + l31;                                          \
+        float av[2][TM], bv[2][TN];                                                                \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) av[0][i] = Ab[half * BM + i * 32];          \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[0][j] = Bb[half * BN + j * 32];          \
+        _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                    \
+            const int cur = ks & 1, nxt = cur ^ 1;                                                 \
+            _Pragma("unroll") for (int e = ks * APT / KSTEPS; e < (ks + 1) * APT / KSTEPS; ++e) {  \
+                if (DO_STORE) YL_STORE_A(buf ^ 1, e)                                               \
+                if (DO_LOAD) YL_LOAD_A((KB) + 2, e)                                                \
+            }                                                                                      \
+            _Pragma("unroll") for (int e = ks * BPT / KSTEPS; e < (ks + 1) * BPT / KSTEPS; ++e) {  \
+                if (DO_STORE) YL_STORE_B(buf ^ 1, e)                                               \
+                if (DO_LOAD) YL_LOAD_B((KB) + 2, e)                                                \
+            }                                                                                      \
+            if (ks + 1 < KSTEPS) {                                                                 \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                     \
+                    av[nxt][i] = Ab[(2 * (ks + 1) + half) * BM + i * 32];                          \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                     \
+                    bv[nxt][j] = Bb[(2 * (ks + 1) + half) * BN + j * 32];                          \
+            }                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                         \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                     \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j],       \
+                                                                     acc[i][j], 0, 0, 0);          \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
+        if (DO_LOAD) { YL_PANEL_ADVANCE() }                                                        \
+        __syncthreads();                                                                           \
+    }
+
+    int kb = 0;
+    for (; kb + 2 < nkb; ++kb) YL_ITER(kb, true, true)
+    if (kb + 1 < nkb) { YL_ITER(kb, true, false) ++kb; }
+    if (kb < nkb) YL_ITER(kb, false, false)
+#undef YL_ITER
+#undef YL_PANEL_SETUP
+#undef YL_PANEL_ADVANCE
+#undef YL_LOAD_A
+#undef YL_LOAD_B
+#undef YL_STORE_A
+#undef YL_STORE_B
+
+    // ---- fused epilogue (identical arithmetic to v1) ----
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + l31;
+        if (n >= p.Ntotal) continue;
+        const int ob = n / p.OHW;
+        const int opix = n - ob * p.OHW;
+        const size_t obase = (size_t)ob * p.M * p.OHW + opix;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (m < p.M) {
+                    float v = acc[i][j][e] + p.bias[m];
+                    if (p.act == YL_LEAKY) v = (v > 0.f) ? v : (float)(.1 * (double)v);
+                    const size_t o = obase + (size_t)m * p.OHW;
+                    if (p.add) v = v + p.add[o];
+                    p.out[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int NWAVES>
+static int launch_pipe(const ConvF32DevV2 &d, int ks, bool tapmajor, hipStream_t s)
+{
+    ConvF32DevV2 p = d;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n = (p.Ntotal + BN - 1) / BN;
+    const long long blocks = (long long)p.tiles_m * tiles_n;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    // the packed weights are zero-padded to a multiple of 32 rows: use only the panels K needs
+    if ((p.K + BK - 1) / BK * BK > p.Kpad) return (int)hipErrorInvalidValue;
+    p.Kpad = (p.K + BK - 1) / BK * BK;
+    dim3 grid((unsigned)blocks), block(NWAVES * 64);
+    if (tapmajor) {
+        if (p.C % BK != 0 || p.size > 5) return (int)hipErrorInvalidValue;
+        if (ks == 3) hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 3, BK, NWAVES, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 0, BK, NWAVES, true>), grid, block, 0, s, p);
+    } else if (ks == 1) hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 1, BK, NWAVES, false>), grid, block, 0, s, p);
+    else if (ks == 3) hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 3, BK, NWAVES, false>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 0, BK, NWAVES, false>), grid, block, 0, s, p);
+    return (int)hipGetLastError();
+}
+
+// cfg: 1 128x128/4w  2 64x128/4w  3 32x256/4w  4 64x64/4w  5 128x128 BK32/4w  6 256x128/8w
+//      7 128x256/8w  8 256x128 BK32/8w  9 128x128/8w(TM1)
+int launch_conv_f32_v2(const ConvF32Args &a, int cfg, void *stream, char *name, size_t name_len)
+{
+    ConvF32DevV2 d;
+    d.in = a.in; d.wt = a.wt; d.bias = a.bias; d.add = a.add; d.out = a.out;
+    d.B = a.B; d.C = a.C; d.H = a.H; d.W = a.W; d.M = a.M; d.OH = a.OH; d.OW = a.OW;
+    d.K = a.K; d.Kpad = a.Kpad; d.Mpad = a.Mpad;
+    d.size = a.size; d.stride = a.stride; d.pad = a.pad; d.act = a.act;
+    d.OHW = a.OH * a.OW;
+    const long long nt = (long long)a.B * d.OHW;
+    if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    d.Ntotal = (int)nt;
+    d.tiles_m = 0;
+    hipStream_t s = (hipStream_t)stream;
+    int ks = 0;
+    if (a.size == 1 && a.pad == 0) ks = 1;
+    else if (a.size == 3) ks = 3;
+    const char *t = "?";
+    int rc;
+    switch (cfg) {
+    case 1: t = "128x128";      rc = launch_pipe<128, 128, 2, 2, 16, 4>(d, ks, a.tapmajor != 0, s); break;
+    case 2: t = "64x128";       rc = launch_pipe<64, 128, 2, 2, 16, 4>(d, ks, a.tapmajor != 0, s); break;
+    case 3: t = "32x256";       rc = launch_pipe<32, 256, 1, 4, 16, 4>(d, ks, a.tapmajor != 0, s); break;
+    case 4: t = "64x64";        rc = launch_pipe<64, 64, 2, 2, 16, 4>(d, ks, a.tapmajor != 0, s); break;
+    case 5: t = "128x128k32";   rc = launch_pipe<128, 128, 2, 2, 32, 4>(d, ks, a.tapmajor != 0, s); break;
+    case 6: t = "256x128w8";    rc = launch_pipe<256, 128, 4, 2, 16, 8>(d, ks, a.tapmajor != 0, s); break;
+    case 7: t = "128x256w8";    rc = launch_pipe<128, 256, 2, 4, 16, 8>(d, ks, a.tapmajor != 0, s); break;
+    case 8: t = "256x128w8k32"; rc = launch_pipe<256, 128, 4, 2, 32, 8>(d, ks, a.tapmajor != 0, s); break;
+    case 9: t = "128x128w8";    rc = launch_pipe<128, 128, 4, 2, 16, 8>(d, ks, a.tapmajor != 0, s); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+    if (name) snprintf(name, name_len, "conv_f32_mfma_pipe<%s,ks%d%s>", t, ks, a.tapmajor ? ",tap" : "");
+    return rc;
+}
+
+}  // namespace yl

@@ -17,10 +17,14 @@ struct ConvF32Args {
     int K, Kpad, Mpad;
     int size, stride, pad;
     int act;              // YL_LINEAR / YL_LEAKY
+    int tapmajor;         // K order of `wt`: 0 = (c,ky,kx) like im2col_cpu, 1 = (ky,kx,c) (needs C % 16 == 0)
 };
 int launch_conv_f32(const ConvF32Args &a, void *stream);
 // force a tile config (0 = heuristic): used by the tile sweep in bench/tests
 void conv_f32_force_tile(int cfg);
+void conv_f32_set_variant(int v);
+int conv_f32_get_variant();
+int launch_conv_f32_v2(const ConvF32Args &a, int cfg, void *stream, char *name, size_t name_len);
 const char *conv_f32_last_tile_name();
 
 // ---- K2: INT8 path ----

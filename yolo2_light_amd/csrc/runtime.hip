@@ -88,11 +88,20 @@ static int upload_conv(Network &net, Layer &l)
             return YL_ERR_UNSUPPORTED;
         }
         // k-major panel layout [Kpad][Mpad], zero padded
-        l.Kpad = round_up(K, 16);
+        // K order: (c,ky,kx) like im2col_cpu, or -- for the pipelined kernel when C % 16 == 0 --
+        // tap-major (ky,kx,c) so that one BK panel shares a single tap (scalar decode once per panel)
+        l.Kpad = round_up(K, 32);
         l.Mpad = round_up(M, 256);
+        l.tapmajor = (conv_f32_get_variant() >= 1 && l.size > 1 && l.size <= 5 && (l.c % 16) == 0) ? 1 : 0;
+        const int taps = l.size * l.size;
         std::vector<float> wt((size_t)l.Kpad * l.Mpad, 0.f);
         for (int m = 0; m < M; ++m)
-            for (int k = 0; k < K; ++k) wt[(size_t)k * l.Mpad + m] = l.weights[(size_t)m * K + k];
+            for (int c = 0; c < l.c; ++c)
+                for (int t = 0; t < taps; ++t) {
+                    const int k_ref = c * taps + t;
+                    const int k_dev = l.tapmajor ? (t * l.c + c) : k_ref;
+                    wt[(size_t)k_dev * l.Mpad + m] = l.weights[(size_t)m * K + k_ref];
+                }
         YL_HIP(hipMalloc((void **)&l.d_weights_t, wt.size() * sizeof(float)));
         YL_HIP(hipMemcpy(l.d_weights_t, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
     } else if (l.conv_mode == CONV_INT8) {
@@ -216,6 +225,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.B = B; a.C = l.c; a.H = l.h; a.W = l.w; a.M = l.n; a.OH = l.out_h; a.OW = l.out_w;
             a.K = l.size * l.size * l.c; a.Kpad = l.Kpad; a.Mpad = l.Mpad;
             a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
+            a.tapmajor = l.tapmajor;
             YL_LAUNCH(launch_conv_f32(a, s), "conv_f32");
             l.kernel_name = conv_f32_last_tile_name();
         } else if (l.conv_mode == CONV_INT8) {
@@ -676,6 +686,7 @@ int yl_network_get_boxes(yl_network *net, int image, int w, int h, float thresh,
 }
 
 int yl_debug_force_conv_tile(int cfg) { conv_f32_force_tile(cfg); return YL_OK; }
+int yl_debug_set_conv_variant(int v) { conv_f32_set_variant(v); return YL_OK; }
 const char *yl_debug_last_conv_tile(void) { return conv_f32_last_tile_name(); }
 
 int yl_network_compact_detections(yl_network *net, float thresh, int cap, float *records_dev, int *counts_dev)

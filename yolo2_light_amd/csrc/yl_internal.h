@@ -47,6 +47,7 @@ struct Layer {
     float *d_weights_t = nullptr;        // FP32: k-major packed [Kpad][Mpad]
     float *d_biases = nullptr;
     int   Kpad = 0, Mpad = 0;
+    int   tapmajor = 0;                  // K order of d_weights_t (see conv_f32_mfma_v2.hip)
     int8_t *d_weights_i8 = nullptr;      // INT8: [Mpad][taps][Cpad] (channel-fastest)
     int   Cpad = 0;
     uint64_t *d_weights_bits = nullptr;  // XNOR: [Mpad][taps][Cw] 64-bit words
