@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--layers", action="store_true", help="also print a per-layer table to stderr")
     ap.add_argument("--tile", type=int, default=0, help="force K1 tile config (tuning)")
+    ap.add_argument("--no-fuse", action="store_true", help="keep [shortcut] layers as separate kernels")
     return ap.parse_args()
 
 
@@ -111,7 +112,7 @@ def main():
     wts = os.path.join(work, "synthetic.weights")
     with open(cfg) as f:
         weights.write_synthetic_weights(f.read(), wts, seed=1)
-    net = Network.load(cfg, wts, args.batch, quantized, device=local_rank)
+    net = Network.load(cfg, wts, args.batch, quantized, device=local_rank, fuse=not args.no_fuse)
     # one explicit (non-default) HIP stream shared by our kernels and torch/RCCL so the
     # compaction -> all-gather dependency is ordinary stream order
     stream = torch.cuda.Stream(device=dev)

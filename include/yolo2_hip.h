@@ -146,6 +146,15 @@ double yl_network_flops_per_image(const yl_network *net);
  * init_gpu_int8x4 (src/yolov2_forward_network_gpu.cu). */
 int yl_network_to_device(yl_network *net, int device);
 
+/* Call BEFORE yl_network_to_device.  on = 1: a same-shape linear [shortcut] whose input is
+ * the convolution right before it is folded into that convolution's epilogue
+ * (shortcut.out = act(conv) + layers[from].out, bit-identical to the two-kernel result), as the
+ * reference GPU path does for XNOR convs (calculate_binary_weights, src/additionally.c:326-339).
+ * The folded conv's own output tensor is then NOT materialised (only legal -- and only done --
+ * when no route/shortcut references it), so per-layer readback of that conv is undefined;
+ * YOLO/REGION/route/shortcut outputs are unaffected.  Default off; ignored in debug mode. */
+int yl_network_set_fusion(yl_network *net, int on);
+
 /* float *network_predict_gpu_cudnn[_quantized](network net, float *input)
  *                                         src/yolov2_forward_network_gpu.cu:547,576
  * Same contract as network_predict_cpu (src/yolov2_forward_network.c:632):

@@ -328,3 +328,29 @@ def test_compact_detections_matches_host_decode():
         np.testing.assert_allclose(dev[kd][:, :5], host[ks][:, :5], rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(dev[kd][:, 6:], host[ks][:, 6:], rtol=1e-6, atol=1e-7)
     net.close()
+
+
+def test_shortcut_fusion_is_bit_identical():
+    """conv+[shortcut] epilogue fusion (yl_network_set_fusion): every tensor that is still
+    materialised -- all shortcut/route/head outputs -- equals the unfused run bit for bit."""
+    name, width, height, batch = "yolov3", 96, 96, 2
+    cfg, wts = common.model_files(name, width, height)
+    x = common.seeded_input(batch, 3, height, width)
+    plain = Network.load(cfg, wts, batch, 0, device=0)
+    fused = Network.load(cfg, wts, batch, 0, device=0, fuse=True)
+    plain.predict(x)
+    fused.predict(x)
+    infos = plain.layers()
+    skipped = 0
+    for i, li in enumerate(infos):
+        nxt = infos[i + 1] if i + 1 < len(infos) else None
+        if li["type"] == common.CONV and nxt is not None and nxt["type"] == common.SHORTCUT:
+            skipped += 1              # folded conv: its own tensor is not materialised
+            continue
+        a, b = plain.layer_output(i), fused.layer_output(i)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "layer %d %r" % (i, li)
+    assert skipped == 23              # yolov3 has 23 residual blocks
+    for b in range(batch):
+        assert np.array_equal(plain.get_boxes(b, width, height, 0.24, nms=0.4),
+                              fused.get_boxes(b, width, height, 0.24, nms=0.4))
+    plain.close(); fused.close()

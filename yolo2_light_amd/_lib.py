@@ -77,6 +77,7 @@ _SIGS = {
     "yl_network_layer_quant_multipliers": (C.c_int, [_vp, C.c_int, c_float_p]),
     "yl_network_flops_per_image": (C.c_double, [_vp]),
     "yl_network_to_device": (C.c_int, [_vp, C.c_int]),
+    "yl_network_set_fusion": (C.c_int, [_vp, C.c_int]),
     "yl_network_predict": (c_float_p, [_vp, c_float_p]),
     "yl_network_forward": (C.c_int, [_vp, _vp]),
     "yl_network_set_stream": (C.c_int, [_vp, _vp]),

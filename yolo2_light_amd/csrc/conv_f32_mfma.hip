@@ -47,6 +47,7 @@ struct ConvF32Dev {
     const float *wt;
     const float *bias;
     const float *add;
+    float *out_add;
     float *out;
     int B, C, H, W, M, OH, OW;
     int K, Kpad, Mpad;
@@ -269,8 +270,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_f32_mfma_kernel(ConvF32Dev p)
                     float v = acc[i][j][e] + p.bias[m];
                     if (p.act == YL_LEAKY) v = (v > 0.f) ? v : (float)(.1 * (double)v);
                     const size_t o = obase + (size_t)m * p.OHW;
-                    if (p.add) v = v + p.add[o];
-                    p.out[o] = v;
+                    if (p.out) p.out[o] = v;
+                    if (p.add) p.out_add[o] = v + p.add[o];
                 }
             }
         }
@@ -312,17 +313,22 @@ int launch_conv_f32(const ConvF32Args &a, void *stream)
         if (cfg == 0) {
             const long long ntot = (long long)a.B * a.OH * a.OW;
             auto nblocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((ntot + bn - 1) / bn); };
+            // measured on MI355X with tools/sweep_conv.py (profiles/sweep_r1.txt): the 8-wave
+            // 128x256 tile wins every 3x3 shape with M >= 128 (118-125 TF), the 8-wave 128x128
+            // tile the 1x1 shapes, 64x128 / 32x256 the narrow-M early layers; layers too small
+            // to give every CU two workgroups fall back to 64x64 tiles.
             if (a.M <= 32) cfg = 3;
             else if (a.M <= 64) cfg = 2;
-            else cfg = 1;
-            if (nblocks(cfg == 1 ? 128 : (cfg == 2 ? 64 : 32), cfg == 3 ? 256 : 128) < 512) cfg = 4;
+            else if (a.size == 1) cfg = (nblocks(128, 128) >= 512) ? 9 : 4;
+            else cfg = (nblocks(128, 256) >= 384) ? 7 : ((nblocks(128, 128) >= 512) ? 1 : 4);
+            if (cfg <= 3 && nblocks(cfg == 2 ? 64 : 32, cfg == 3 ? 256 : 128) < 512) cfg = 4;
         }
         // BK=32 variants need C % 32 == 0 in tap-major order
         if ((cfg == 5 || cfg == 8) && a.tapmajor && (a.C % 32) != 0) cfg = (cfg == 5) ? 1 : 6;
         return launch_conv_f32_v2(a, cfg, stream, g_last_tile, sizeof(g_last_tile));
     }
     ConvF32Dev d;
-    d.in = a.in; d.wt = a.wt; d.bias = a.bias; d.add = a.add; d.out = a.out;
+    d.in = a.in; d.wt = a.wt; d.bias = a.bias; d.add = a.add; d.out_add = a.out_add; d.out = a.out;
     d.B = a.B; d.C = a.C; d.H = a.H; d.W = a.W; d.M = a.M; d.OH = a.OH; d.OW = a.OW;
     d.K = a.K; d.Kpad = a.Kpad; d.Mpad = a.Mpad;
     d.size = a.size; d.stride = a.stride; d.pad = a.pad;

@@ -34,6 +34,7 @@ struct ConvF32DevV2 {
     const float *wt;
     const float *bias;
     const float *add;
+    float *out_add;
     float *out;
     int B, C, H, W, M, OH, OW;
     int K, Kpad, Mpad;
@@ -301,8 +302,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
                     float v = acc[i][j][e] + p.bias[m];
                     if (p.act == YL_LEAKY) v = (v > 0.f) ? v : (float)(.1 * (double)v);
                     const size_t o = obase + (size_t)m * p.OHW;
-                    if (p.add) v = v + p.add[o];
-                    p.out[o] = v;
+                    if (p.out) p.out[o] = v;
+                    if (p.add) p.out_add[o] = v + p.add[o];
                 }
             }
         }
@@ -336,7 +337,7 @@ static int launch_pipe(const ConvF32DevV2 &d, int ks, bool tapmajor, hipStream_t
 int launch_conv_f32_v2(const ConvF32Args &a, int cfg, void *stream, char *name, size_t name_len)
 {
     ConvF32DevV2 d;
-    d.in = a.in; d.wt = a.wt; d.bias = a.bias; d.add = a.add; d.out = a.out;
+    d.in = a.in; d.wt = a.wt; d.bias = a.bias; d.add = a.add; d.out_add = a.out_add; d.out = a.out;
     d.B = a.B; d.C = a.C; d.H = a.H; d.W = a.W; d.M = a.M; d.OH = a.OH; d.OW = a.OW;
     d.K = a.K; d.Kpad = a.Kpad; d.Mpad = a.Mpad;
     d.size = a.size; d.stride = a.stride; d.pad = a.pad; d.act = a.act;

@@ -11,8 +11,9 @@ struct ConvF32Args {
     const float *in;      // [B][C][H][W]
     const float *wt;      // k-major packed weights [Kpad][Mpad]
     const float *bias;    // [M]
-    const float *add;     // optional residual, same shape as out (nullptr = none)
-    float *out;           // [B][M][OH][OW]
+    const float *add;     // optional fused [shortcut]: out_add = act(conv) + add (nullptr = none)
+    float *out_add;       // destination of the fused shortcut (the SHORTCUT layer's output)
+    float *out;           // [B][M][OH][OW]; may be nullptr when only out_add is wanted
     int B, C, H, W, M, OH, OW;
     int K, Kpad, Mpad;
     int size, stride, pad;
@@ -35,7 +36,7 @@ struct ConvI8Args {
     const int8_t *in_q;   // [B][H][W][Cpad]
     const int8_t *w_q;    // [Mpad][size*size][Cpad]
     const float *bias;    // [M]
-    float *out;           // [B][M][OH][OW] fp32
+    float *out;           // [B][M][OH][OW]; may be nullptr when only out_add is wanted fp32
     int32_t *dbg;         // optional int16-clamped accumulators [B][M][OH][OW]
     int B, Cpad, H, W, M, Mpad, OH, OW;
     int size, stride, pad;

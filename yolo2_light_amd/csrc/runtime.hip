@@ -203,6 +203,29 @@ static int to_device(Network &net, int device)
     }
     if (net.qbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_qbuf, net.qbuf_bytes));
     if (net.bitbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_bitbuf, net.bitbuf_bytes));
+    // ---- optional conv+shortcut fusion plan ----
+    for (Layer &l : net.layers) { l.fused_shortcut = -1; l.fused_into_conv = false; }
+    if (net.fuse && !net.debug) {
+        const int nl = (int)net.layers.size();
+        for (int i = 1; i < nl; ++i) {
+            Layer &sc = net.layers[i];
+            Layer &cv = net.layers[i - 1];
+            if (sc.type != YL_SHORTCUT || cv.type != YL_CONVOLUTIONAL || cv.conv_mode != CONV_F32) continue;
+            if (sc.activation != YL_LINEAR) continue;
+            if (!(sc.w == sc.out_w && sc.h == sc.out_h && sc.c == sc.out_c)) continue;   // same-shape add only
+            if (sc.index == i - 1) continue;
+            bool referenced = (i - 1 == nl - 1);
+            for (int j = i + 1; j < nl && !referenced; ++j) {
+                const Layer &o = net.layers[j];
+                if (o.type == YL_SHORTCUT && o.index == i - 1) referenced = true;
+                if (o.type == YL_ROUTE)
+                    for (int id : o.input_layers) if (id == i - 1) referenced = true;
+            }
+            if (referenced) continue;
+            cv.fused_shortcut = i;
+            sc.fused_into_conv = true;
+        }
+    }
     hipEvent_t e0, e1;
     YL_HIP(hipEventCreate(&e0));
     YL_HIP(hipEventCreate(&e1));
@@ -221,7 +244,17 @@ static int forward_layer(Network &net, size_t i, const float *input)
     case YL_CONVOLUTIONAL: {
         if (l.conv_mode == CONV_F32) {
             ConvF32Args a;
-            a.in = input; a.wt = l.d_weights_t; a.bias = l.d_biases; a.add = nullptr; a.out = l.d_output;
+            a.in = input; a.wt = l.d_weights_t; a.bias = l.d_biases; a.add = nullptr; a.out_add = nullptr;
+            a.out = l.d_output;
+            if (l.fused_shortcut >= 0) {
+                // conv + [shortcut] in one pass (the reference GPU path fuses the same pair for XNOR
+                // convs, src/additionally.c:326-339): shortcut.out = act(conv) + layers[index].out;
+                // the conv's own tensor is not referenced by any other layer and is not written.
+                Layer &sc = net.layers[l.fused_shortcut];
+                a.add = net.layers[sc.index].d_output;
+                a.out_add = sc.d_output;
+                a.out = nullptr;
+            }
             a.B = B; a.C = l.c; a.H = l.h; a.W = l.w; a.M = l.n; a.OH = l.out_h; a.OW = l.out_w;
             a.K = l.size * l.size * l.c; a.Kpad = l.Kpad; a.Mpad = l.Mpad;
             a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
@@ -265,6 +298,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
         break;
     }
     case YL_SHORTCUT:
+        if (l.fused_into_conv) break;          // written by the preceding conv's epilogue
         YL_LAUNCH(launch_shortcut(input, net.layers[l.index].d_output, l.d_output, B, l.w, l.h, l.c,
                                   l.out_w, l.out_h, l.out_c, l.activation, s), "shortcut");
         break;
@@ -511,6 +545,14 @@ int yl_network_set_debug(yl_network *net, int on)
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }
     if (net->net.on_device) { set_error("set_debug must precede to_device"); return YL_ERR_STATE; }
     net->net.debug = on != 0;
+    return YL_OK;
+}
+
+int yl_network_set_fusion(yl_network *net, int on)
+{
+    if (!net) { set_error("null argument"); return YL_ERR_ARG; }
+    if (net->net.on_device) { set_error("set_fusion must precede to_device"); return YL_ERR_STATE; }
+    net->net.fuse = on != 0;
     return YL_OK;
 }
 

@@ -55,6 +55,8 @@ struct Layer {
     int   Cw = 0;
     int32_t *d_debug = nullptr;          // xnor counts / int8 acc (debug mode)
     std::string kernel_name;             // dominant kernel of this layer's last launch
+    int   fused_shortcut = -1;           // conv: index of the [shortcut] layer folded into its epilogue
+    bool  fused_into_conv = false;       // shortcut: produced by the preceding conv's epilogue
 };
 
 struct Network {
@@ -68,6 +70,7 @@ struct Network {
     int device = -1;
     bool on_device = false;
     bool debug = false;
+    bool fuse = false;                   // conv+shortcut epilogue fusion (yl_network_set_fusion)
     void *stream = nullptr;              // hipStream_t
     bool own_stream = false;
     float *d_input = nullptr;

@@ -62,7 +62,7 @@ class Network:
 
     @classmethod
     def load(cls, cfg_path: str, weights_path: str, batch: int = 1, quantized: int = 0,
-             device: Optional[int] = None, debug: bool = False) -> "Network":
+             device: Optional[int] = None, debug: bool = False, fuse: bool = False) -> "Network":
         """The full prep sequence of test_detector_cpu (src/main.c:160-171)."""
         net = cls.from_cfg(cfg_path, batch, quantized)
         net.load_weights(weights_path)
@@ -72,6 +72,8 @@ class Network:
             net.quantize()
         if debug:
             check(lib.yl_network_set_debug(net._h, 1), "yl_network_set_debug")
+        if fuse:
+            net.set_fusion(True)
         if device is not None:
             net.to_device(device)
         return net
@@ -151,6 +153,10 @@ class Network:
         return lib.yl_network_flops_per_image(self._h)
 
     # ------------------------------------------------------------ device
+    def set_fusion(self, on: bool = True) -> None:
+        """Fold same-shape linear [shortcut] layers into the preceding conv's epilogue (before to_device)."""
+        check(lib.yl_network_set_fusion(self._h, 1 if on else 0), "yl_network_set_fusion")
+
     def to_device(self, device: int = 0) -> None:
         check(lib.yl_network_to_device(self._h, device), "yl_network_to_device")
         self._on_device = True
