@@ -324,7 +324,7 @@ int launch_conv_f32(const ConvF32Args &a, void *stream)
             if (cfg <= 3 && nblocks(cfg == 2 ? 64 : 32, cfg == 3 ? 256 : 128) < 512) cfg = 4;
         }
         // BK=32 variants need C % 32 == 0 in tap-major order
-        if ((cfg == 5 || cfg == 8) && a.tapmajor && (a.C % 32) != 0) cfg = (cfg == 5) ? 1 : 6;
+        if ((cfg == 5 || cfg == 8) && a.tapmajor) cfg = (cfg == 5) ? 1 : 6;   // tap-major blocks are 16 channels
         return launch_conv_f32_v2(a, cfg, stream, g_last_tile, sizeof(g_last_tile));
     }
     ConvF32Dev d;

@@ -212,8 +212,11 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
     }
 #define YL_PANEL_ADVANCE()                                                                         \
     if (TAPMAJOR) {                                                                                \
-        pn_c0 += BK;                                                                               \
-        if (pn_c0 >= p.C) { pn_c0 = 0; ++pn_tap; }                                                 \
+        /* K order = (16-channel block, tap, channel in block): the taps of one channel block   */ \
+        /* are consecutive panels, so their (shifted) input lines are re-read while still in    */ \
+        /* L1/L2 instead of after a sweep over all C channels                                    */ \
+        ++pn_tap;                                                                                  \
+        if (pn_tap >= p.size * p.size) { pn_tap = 0; pn_c0 += BK; }                                \
     }
 
     // ---- prologue: panel 0 -> LDS buffer 0, panel 1 -> registers ----

@@ -99,7 +99,8 @@ static int upload_conv(Network &net, Layer &l)
             for (int c = 0; c < l.c; ++c)
                 for (int t = 0; t < taps; ++t) {
                     const int k_ref = c * taps + t;
-                    const int k_dev = l.tapmajor ? (t * l.c + c) : k_ref;
+                    // tap-major inside 16-channel blocks: k = ((c/16)*taps + t)*16 + c%16
+                    const int k_dev = l.tapmajor ? (((c / 16) * taps + t) * 16 + (c % 16)) : k_ref;
                     wt[(size_t)k_dev * l.Mpad + m] = l.weights[(size_t)m * K + k_ref];
                 }
         YL_HIP(hipMalloc((void **)&l.d_weights_t, wt.size() * sizeof(float)));
