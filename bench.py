@@ -129,8 +129,8 @@ def main():
     rec = torch.zeros((B, args.cap, 6 + classes), device=dev, dtype=torch.float32)
     cnt = torch.zeros((B,), device=dev, dtype=torch.int32)
     if world > 1:
-        rec_all = torch.zeros((world, B, args.cap, 6 + classes), device=dev, dtype=torch.float32)
-        cnt_all = torch.zeros((world, B), device=dev, dtype=torch.int32)
+        rec_all = torch.zeros((world * B, args.cap, 6 + classes), device=dev, dtype=torch.float32)
+        cnt_all = torch.zeros((world * B,), device=dev, dtype=torch.int32)
 
     n_layers = net.n
     layer_ms = np.zeros(n_layers, dtype=np.float64)

@@ -1,0 +1,102 @@
+/*
+ * integration/network_predict_hip.c -- the reference-side binding of libyolo2hip.so.
+ *
+ * This is the file a maintainer of AlexeyAB/yolo2_light adds to src/ (plus one
+ * `#elif defined(HIP)` arm at the three call sites src/main.c:199-219, :394-414,
+ * src/additionally.c:4639-4659).  It is compiled TOGETHER WITH the reference's own
+ * host code, built WITHOUT -DGPU so `layer` (952 B) and `network` (224 B) keep their CPU
+ * layout (src/additionally.h:409-763), and links against libyolo2hip.so only through the
+ * plain-C ABI of include/yolo2_hip.h.
+ *
+ *     float *network_predict_hip(network net, float *input);
+ *
+ * has exactly the contract of network_predict_cpu (src/yolov2_forward_network.c:632-646)
+ * and network_predict_gpu_cudnn (src/yolov2_forward_network_gpu.cu:547-573):
+ *   - `net` by value, `input` = host float[net.batch*net.c*net.h*net.w], CHW, [0,1];
+ *   - returns net.layers[last non-COST].output (a borrowed host pointer);
+ *   - fills the host `l.output` of every YOLO/REGION layer so that get_network_boxes
+ *     (src/additionally.c:4403) and do_nms_sort (src/box.c:296) run unchanged;
+ *   - `-quantized` follows net.quantized, XNOR follows l.xnor, using the weights the host
+ *     prepared in main.c:160-171 (fused BN, weights_int8 + multipliers, mean_arr).
+ * Errors follow the reference convention: error() = perror + exit (src/additionally.c:1595).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "additionally.h"
+#include "yolo2_hip.h"
+
+extern int gpu_index;            /* src/additionally.c:22; -i <n> selects the device (main.c:653) */
+void error(const char *s);       /* src/additionally.c:1595 */
+
+static yl_network *g_hip_net = NULL;
+static layer *g_hip_owner = NULL;       /* the network whose device image g_hip_net holds */
+
+static void hip_fail(const char *what)
+{
+    fprintf(stderr, "%s: %s\n", what, yl_last_error());
+    error(what);
+}
+
+static yl_network *hip_build(network *net)
+{
+    int i;
+    yl_network *h = NULL;
+    yl_layer_desc *d = (yl_layer_desc *)calloc(net->n, sizeof(yl_layer_desc));
+    for (i = 0; i < net->n; ++i) {
+        layer *l = &net->layers[i];
+        d[i].type = l->type;
+        d[i].activation = l->activation;
+        d[i].batch = l->batch; d[i].w = l->w; d[i].h = l->h; d[i].c = l->c;
+        d[i].n = l->n; d[i].size = l->size; d[i].stride = l->stride; d[i].pad = l->pad;
+        d[i].out_w = l->out_w; d[i].out_h = l->out_h; d[i].out_c = l->out_c;
+        d[i].outputs = l->outputs; d[i].inputs = l->inputs;
+        d[i].batch_normalize = l->batch_normalize;
+        d[i].xnor = l->xnor;
+        d[i].index = l->index;
+        d[i].input_layers = l->input_layers; d[i].input_sizes = l->input_sizes;
+        d[i].classes = l->classes; d[i].coords = l->coords; d[i].total = l->total; d[i].softmax = l->softmax;
+        d[i].mask = l->mask;
+        d[i].anchors = (l->type == YOLO || l->type == REGION) ? l->biases : NULL;
+        d[i].scale = l->scale;
+        if (l->type == CONVOLUTIONAL) {
+            d[i].weights = l->weights; d[i].biases = l->biases;
+            d[i].scales = l->scales; d[i].rolling_mean = l->rolling_mean; d[i].rolling_variance = l->rolling_variance;
+            if (net->quantized) {
+                d[i].weights_int8 = l->weights_int8;
+                d[i].input_quant_multipler = l->input_quant_multipler;
+                d[i].weights_quant_multipler = l->weights_quant_multipler;
+            }
+            d[i].mean_arr = l->xnor ? l->mean_arr : NULL;
+        }
+        d[i].output = l->output;
+    }
+    if (yl_network_create_from_desc(d, net->n, net->batch, net->w, net->h, net->c, net->quantized,
+                                    net->input_calibration, net->input_calibration_size, &h) != YL_OK)
+        hip_fail("yl_network_create_from_desc");
+    free(d);
+    if (yl_network_to_device(h, gpu_index >= 0 ? gpu_index : 0) != YL_OK) hip_fail("yl_network_to_device");
+    return h;
+}
+
+float *network_predict_hip(network net, float *input)
+{
+    float *out;
+    if (!g_hip_net || g_hip_owner != net.layers) {
+        if (g_hip_net) yl_network_destroy(g_hip_net);
+        g_hip_net = hip_build(&net);
+        g_hip_owner = net.layers;
+    }
+    out = yl_network_predict(g_hip_net, input);
+    if (!out) hip_fail("yl_network_predict");
+    return out;
+}
+
+/* call before free_network(net) (src/additionally.c:2054) */
+void free_network_hip(void)
+{
+    if (g_hip_net) yl_network_destroy(g_hip_net);
+    g_hip_net = NULL;
+    g_hip_owner = NULL;
+}

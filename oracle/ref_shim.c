@@ -180,3 +180,21 @@ void ref_maxpool(float *src, float *dst, int size, int w, int h, int out_w, int 
     forward_maxpool_layer_avx(src, dst, idx, size, w, h, out_w, out_h, c, pad, stride, batch);
     free(idx);
 }
+
+#ifdef WITH_HIP_ADAPTOR
+/* the drop-in under test: the reference's host code + integration/network_predict_hip.c
+ * (the binding a maintainer would add) driving libyolo2hip.so */
+float *network_predict_hip(network net, float *input);
+void free_network_hip(void);
+
+float *ref_predict_hip(ref_net *r, float *input)
+{
+    float *out;
+    hush();
+    out = network_predict_hip(r->net, input);
+    unhush();
+    return out;
+}
+
+void ref_free_hip(void) { free_network_hip(); }
+#endif

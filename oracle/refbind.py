@@ -14,6 +14,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(_HERE, "_ref", "libyolo2ref.so")
 FAST = os.path.join(_HERE, "_ref", "libyolo2ref_fast.so")
+# reference host code + integration/network_predict_hip.c bound to libyolo2hip.so (drop-in test)
+HIP = os.path.join(_HERE, "_ref", "libyolo2ref_hip.so")
 
 INFO_FIELDS = ("type", "batch", "w", "h", "c", "n", "size", "stride", "pad", "out_w", "out_h", "out_c",
                "outputs", "inputs", "activation", "xnor", "quantized", "index", "classes", "coords", "total",
@@ -67,8 +69,13 @@ def _bind(path: str) -> C.CDLL:
 class RefNetwork:
     """The reference's own network, driven through the shim (src/main.c:160-229 sequence)."""
 
-    def __init__(self, cfg: str, weights: str, batch: int = 1, quantized: int = 0, fast: bool = False):
-        self.lib = _bind(FAST if fast else GOLD)
+    def __init__(self, cfg: str, weights: str, batch: int = 1, quantized: int = 0, fast: bool = False,
+                 hip: bool = False):
+        self.lib = _bind(HIP if hip else (FAST if fast else GOLD))
+        if hip:
+            self.lib.ref_predict_hip.restype = _fp
+            self.lib.ref_predict_hip.argtypes = [C.c_void_p, _fp]
+            self.lib.ref_free_hip.restype = None
         self.h = self.lib.ref_load(cfg.encode(), (weights or "").encode(), batch, quantized)
         if not self.h:
             raise RuntimeError("ref_load failed")
@@ -87,6 +94,13 @@ class RefNetwork:
         x = np.ascontiguousarray(x, dtype=np.float32)
         self._keep = x
         self.lib.ref_predict(self.h, x.ctypes.data_as(_fp))
+
+    def predict_hip(self, x: np.ndarray) -> None:
+        """network_predict_hip(net, input): the reference's host code driving libyolo2hip.so."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        self._keep = x
+        if not self.lib.ref_predict_hip(self.h, x.ctypes.data_as(_fp)):
+            raise RuntimeError("network_predict_hip returned NULL")
 
     def time_predict(self, x: np.ndarray, iters: int) -> float:
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -1,0 +1,86 @@
+"""Committed golden fixtures (tests/golden/*.npz, generated from the reference
+itself by tests/golden/make_golden.py):
+  - not gpu: the oracle restatement reproduces them bit for bit;
+  - gpu:     the HIP path reproduces them within the north_star tolerances."""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import common
+from common import Network, OracleNet, fp32_close
+
+FIXTURES = sorted(glob.glob(os.path.join(common.GOLDEN_DIR, "*.npz")))
+
+
+def _case(path):
+    base = os.path.basename(path)[:-4]
+    name, dims, b, mode = base.rsplit("_", 3)
+    w, h = dims.split("x")
+    return name, int(w), int(h), int(b[1:]), 1 if mode == "int8" else 0
+
+
+def _load(path):
+    name, w, h, b, q = _case(path)
+    g = np.load(path)
+    cfg, wts = common.model_files(name, w, h)
+    assert hashlib.sha256(open(wts, "rb").read()).hexdigest() == str(g["weights_sha256"]), \
+        "synthetic weights differ from the ones the fixture was generated with (numpy RNG stream changed?)"
+    x = common.seeded_input(b, 3, h, w)
+    assert hashlib.sha256(x.tobytes()).hexdigest() == str(g["input_sha256"])
+    return name, w, h, b, q, g, cfg, wts, x
+
+
+def test_fixtures_exist():
+    assert len(FIXTURES) >= 5
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_oracle_reproduces_golden(olib, path):
+    name, w, h, b, q, g, cfg, wts, x = _load(path)
+    net = Network.load(cfg, wts, b, q)
+    on = OracleNet(net, olib)
+    on.set_route_inputs(open(cfg).read())
+    on.forward(x)
+    sums = g["layer_sums"]
+    for i in range(net.n):
+        o = on.outputs[i].astype(np.float64)
+        assert o.sum() == sums[i, 0] and np.abs(o).sum() == sums[i, 1], "layer %d checksum" % i
+    for key in g.files:
+        if key.startswith("layer_") and key != "layer_sums":
+            i = int(key.split("_")[1])
+            want = g[key]
+            got = on.outputs[i]
+            if q:
+                want = want.reshape(b, -1)[:1].reshape(-1); got = got.reshape(b, -1)[:1].reshape(-1)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_hip_reproduces_golden(path):
+    name, w, h, b, q, g, cfg, wts, x = _load(path)
+    net = Network.load(cfg, wts, b, q, device=0)
+    net.predict(x)
+    exact_chain = (q == 0 and name != "tiny-yolo-xnor")
+    for key in g.files:
+        if not (key.startswith("layer_") and key != "layer_sums"):
+            continue
+        i = int(key.split("_")[1])
+        want = g[key]; got = net.layer_output(i)
+        if exact_chain:
+            ok, ratio, worst = fp32_close(got, want)
+            assert ok, "%s: err/allowed %.3g" % (key, ratio)
+        else:
+            # step-function paths (INT8 quantisation, sign bits): statistical agreement end to end,
+            # exactness per layer is established by the teacher-forced tests
+            gd, wd = got.astype(np.float64), want.astype(np.float64)
+            assert np.sqrt(np.mean((gd - wd) ** 2)) / max(np.sqrt(np.mean(wd * wd)), 1e-12) < 0.08, key
+    if exact_chain:
+        for bi in range(b):
+            want = g["dets_%d" % bi]
+            got = net.get_boxes(bi, w, h, 0.24, nms=0.4)
+            assert abs(len(got) - len(want)) <= 1
+    net.close()

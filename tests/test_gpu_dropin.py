@@ -1,0 +1,69 @@
+"""End-to-end drop-in: the REFERENCE's own host code (parse_network_cfg,
+load_weights_upto_cpu, fuse/binarize/quantize prep, get_network_boxes,
+do_nms_sort -- compiled unmodified into oracle/_ref/libyolo2ref_hip.so) calls
+`network_predict_hip` from integration/network_predict_hip.c (the binding
+INTEGRATION.md tells a maintainer to add), which reaches the HIP kernels only
+through the C-ABI.  Results are compared with the reference CPU path run on the
+very same `network` object."""
+import os
+
+import numpy as np
+import pytest
+
+import common
+from common import refbind, fp32_close
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not os.path.exists(refbind.HIP), reason="oracle/_ref/libyolo2ref_hip.so not built")]
+
+
+def _heads(ref):
+    return [i for i in range(ref.n) if ref.layer_info(i)["type"] in (common.YOLO, common.REGION)]
+
+
+@pytest.mark.parametrize("name,width,height,batch", [("yolov3-tiny", 416, 416, 2), ("yolov3", 160, 160, 2),
+                                                     ("tiny-yolo-xnor", 416, 416, 1)])
+def test_reference_host_code_drives_hip_path(name, width, height, batch):
+    cfg, wts = common.model_files(name, width, height)
+    ref = refbind.RefNetwork(cfg, wts, batch, 0, hip=True)
+    x = common.seeded_input(batch, 3, height, width)
+    ref.predict(x)                                            # network_predict_cpu
+    heads = _heads(ref)
+    cpu_heads = {i: ref.layer_output(i) for i in heads}
+    cpu_dets = [ref.get_detections(b, width, height, 0.24, nms=0.4) for b in range(batch)]
+    ref.predict_hip(x)                                        # network_predict_hip -> same l.output buffers
+    xnor = name == "tiny-yolo-xnor"
+    for i in heads:
+        got, want = ref.layer_output(i), cpu_heads[i]
+        if xnor:
+            # a sign flip of a near-zero FP32 activation changes a count by 1: statistical agreement
+            bad = np.abs(got - want) > (1e-3 + 1e-3 * np.abs(want))
+            assert bad.mean() < 0.02
+        else:
+            ok, ratio, worst = fp32_close(got, want)
+            assert ok, "head layer %d: err/allowed %.3g" % (i, ratio)
+    for b in range(batch):
+        g = ref.get_detections(b, width, height, 0.24, nms=0.4)   # the reference's own decode + NMS
+        r = cpu_dets[b]
+        assert abs(len(g) - len(r)) <= max(2, len(r) // 20)
+        if len(r) and len(g) and not xnor:
+            with np.errstate(invalid="ignore", over="ignore"):
+                dist = (np.abs(r[:, None, :4] - g[None, :, :4]) / (1e-5 + 1e-4 * np.abs(r[:, None, :4]))).max(axis=2)
+            j = np.nan_to_num(dist, nan=0.0).argmin(axis=1)
+            assert (np.nan_to_num(dist, nan=0.0)[np.arange(len(r)), j] < 1.0).mean() > 0.98
+    ref.lib.ref_free_hip()
+
+
+def test_reference_host_code_quantized():
+    name, width, height = "yolov3-tiny", 416, 416
+    cfg, wts = common.model_files(name, width, height)
+    ref = refbind.RefNetwork(cfg, wts, 1, 1, hip=True)        # -quantized
+    x = common.seeded_input(1, 3, height, width)
+    ref.predict(x)                                            # network_predict_quantized
+    heads = _heads(ref)
+    cpu_heads = {i: ref.layer_output(i).astype(np.float64) for i in heads}
+    ref.predict_hip(x)
+    for i in heads:
+        g = ref.layer_output(i).astype(np.float64); r = cpu_heads[i]
+        assert np.sqrt(np.mean((g - r) ** 2)) / np.sqrt(np.mean(r * r)) < 0.05
+    ref.lib.ref_free_hip()
