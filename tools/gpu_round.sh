@@ -73,4 +73,14 @@ if has pmc; then
   find $OUT -name "*counter_collection.csv" -size +30M -delete
   find $OUT -name "*kernel_trace.csv" -size +20M -delete
 fi
+if has pmc64; then
+  echo "== rocprofv3 HBM traffic counters at the bench batch (64)" | tee -a $OUT/summary.txt
+  for C in "FETCH_SIZE" "WRITE_SIZE"; do
+    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmc64_$C -o pmc -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/$OUT/pmc64_$C.log 2>&1 )
+    echo "pmc64 $C exit $?" | tee -a $OUT/summary.txt
+  done
+  python tools/pmc_summary.py $OUT > $OUT/pmc64_summary.txt 2>&1
+  grep -E "FETCH_SIZE|WRITE_SIZE" $OUT/pmc64_summary.txt | head -20
+  find $OUT -name "*kernel_trace.csv" -size +20M -delete
+fi
 du -sh $OUT
