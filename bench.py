@@ -94,7 +94,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # launched by torch.distributed.run (RANK set) -> always use the RCCL path, even at world 1,
+    # so the single-GPU box exercises exactly the code the multi-GPU runs execute
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world)
@@ -128,7 +131,7 @@ def main():
     classes = last["classes"]
     rec = torch.zeros((B, args.cap, 6 + classes), device=dev, dtype=torch.float32)
     cnt = torch.zeros((B,), device=dev, dtype=torch.int32)
-    if world > 1:
+    if use_dist:
         rec_all = torch.zeros((world * B, args.cap, 6 + classes), device=dev, dtype=torch.float32)
         cnt_all = torch.zeros((world * B,), device=dev, dtype=torch.int32)
 
@@ -141,20 +144,20 @@ def main():
         with torch.cuda.stream(stream):
             net.forward_timed(x.data_ptr(), slot)   # HIP events around every layer, no host sync
             net.compact_detections(args.thresh, args.cap, rec.data_ptr(), cnt.data_ptr())
-            if world > 1:
+            if use_dist:
                 dist.all_gather_into_tensor(rec_all, rec)
                 dist.all_gather_into_tensor(cnt_all, cnt)
 
     for _ in range(args.warmup):
         step(0)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k % MAX_SLOTS)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -164,7 +167,7 @@ def main():
         ms, _ = net.layer_times(sl)
         layer_ms[:] += ms
     layer_ms *= args.steps / n_slots        # layer_ms holds the sum over all timed steps
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -187,11 +190,33 @@ def main():
     conv_ms = sum(k["ms"] for k in kern.values())
     conv_flops = sum(k["flops"] for k in kern.values())
     other_ms = float(layer_ms.sum() / args.steps - conv_ms)
+    # HBM traffic of the dominant kernel: PMC counters need their own rocprofv3 passes (they
+    # serialise kernels), so the per-launch figure comes from the committed summary of those
+    # passes for this exact workload (profiles/pmc_traffic.json), null for any other workload
+    traffic = None
+    algo_bytes = None
+    try:
+        if args.model == "yolov3" and args.size == 608 and B == 64 and args.mode == "fp32":
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pt = json.load(f).get(dom_name)
+            if pt:
+                traffic = (2.0 * pt["fetch_kib"] + pt["write_kib"]) * 1024.0
+    except (OSError, ValueError):
+        traffic = None
+    # algorithmic bytes per launch of the dominant kernel: input + weights read once, output written once
+    ab = 0.0
+    for i, li in enumerate(infos):
+        if li["type"] == 0 and net.layer_kernel(i) == dom_name:
+            ab += 4.0 * (B * li["c"] * li["h"] * li["w"] + li["n"] * li["c"] * li["size"] ** 2
+                         + B * li["n"] * li["out_h"] * li["out_w"])
+    algo_bytes = ab / max(dom["launches"], 1)
     roofline = {
         "bound": "mfma", "kernel": dom_name,
         "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
-        "traffic": None,
+        "traffic": traffic, "traffic_unit": "bytes/launch (PMC, separate passes)",
+        "algorithmic_bytes_per_launch": algo_bytes,
+        "algorithmic_flops_per_launch": dom["flops"] / max(dom["launches"], 1),
         "launches_per_step": dom["launches"],
         "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
         "all_conv_tflops": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
@@ -224,14 +249,14 @@ def main():
             "config": {"workload": "%s.cfg %dx%d batch=%d/GPU %s, synthetic weights+images resident in HBM, "
                                    "forward + on-device detection compaction%s" % (
                                        args.model, args.size, args.size, B, args.mode.upper(),
-                                       " + RCCL all-gather of detections" if world > 1 else ""),
+                                       " + RCCL all-gather of detections" if use_dist else ""),
                        "global_batch": world * B, "parallelism": "image-batch sharding x%d" % world,
                        "gflop_per_image": net.flops_per_image / 1e9},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
