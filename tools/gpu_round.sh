@@ -73,6 +73,13 @@ if has pmc; then
   find $OUT -name "*counter_collection.csv" -size +30M -delete
   find $OUT -name "*kernel_trace.csv" -size +20M -delete
 fi
+if has dist1; then
+  echo "== bench through torch.distributed.run, world 1 (RCCL all-gather path)" | tee -a $OUT/summary.txt
+  timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err
+  echo "dist1 exit $?" | tee -a $OUT/summary.txt
+  tail -2 $OUT/bench_dist1.json | cut -c1-400
+  tail -3 $OUT/bench_dist1.err
+fi
 if has pmc64; then
   echo "== rocprofv3 HBM traffic counters at the bench batch (64)" | tee -a $OUT/summary.txt
   for C in "FETCH_SIZE" "WRITE_SIZE"; do

@@ -75,6 +75,12 @@ int launch_quantize_nhwc(const float *in, int8_t *out, int B, int C, int H, int 
 }
 
 // ------------------------------------------------------------------ K2b: INT8 MFMA implicit GEMM
+// Schedule: like K1 v2.  One LDS panel = BK16 16-byte k-units (128 bytes of K) for BM filters and
+// BN pixels; LDS is double-buffered, and a 2-deep REGISTER ring holds panels kb+1 and kb+2, so a
+// gather issued in iteration kb is consumed in iteration kb+2 (two iterations of latency budget:
+// with 32-cycle MFMAs an iteration is only ~512 pipe cycles, far less than a loaded HBM/L2 round
+// trip).  The staging slices (ds_write of the older ring entry, its reload, next operands' ds_read)
+// are interleaved between the MFMAs of each k-step and pinned with sched_barrier.
 constexpr int BK16 = 8;          // 16-byte k-units per LDS panel (= 4 MFMA k-steps of 32)
 constexpr int NT = 256;
 
@@ -91,17 +97,30 @@ struct ConvI8Dev {
     int Ntotal, OHW, tiles_m;
 };
 
+// y / 10 correctly rounded (the reference's leaky on this path is `y / 10`, quantized.c:625):
+// Markstein's sequence q = RN(y*r), e = fma(-10, q, y), q' = fma(e, r, q) with r = RN(1/10) returns
+// RN(y/10) for normal operands; tiny |y| (possible subnormal intermediates) take the IEEE divide.
+__device__ __forceinline__ float div10_exact(float y)
+{
+    if (fabsf(y) < 1e-30f) return __fdiv_rn(y, 10.f);
+    const float r = 0.1f;
+    const float q = __fmul_rn(y, r);
+    const float e = __fmaf_rn(-10.f, q, y);
+    return __fmaf_rn(e, r, q);
+}
+
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(NT) void conv_i8_mfma_kernel(ConvI8Dev p)
 {
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
+    constexpr int KSTEPS = BK16 / 2;
     static_assert(WM * WN == 4, "4 waves");
     static_assert(BN % 64 == 0 && BN <= NT, "B panel mapping");
     constexpr int A_UNITS = BK16 * BM;                 // 16-byte units per A panel
-    constexpr int A_PER_THREAD = A_UNITS / NT;
-    static_assert(A_UNITS % NT == 0, "A panel divides evenly");
-    constexpr int B_PER_THREAD = BK16 * BN / NT;
+    constexpr int APT = (A_UNITS + NT - 1) / NT;
+    constexpr bool A_FULL = (A_UNITS % NT) == 0;
+    constexpr int BPT = BK16 * BN / NT;
     constexpr int G_STEP = NT / BN;
 
     __shared__ __attribute__((aligned(16))) uint4 smem[2 * BK16 * BM + 2 * BK16 * BN];
@@ -157,41 +176,39 @@ __global__ __launch_bounds__(NT) void conv_i8_mfma_kernel(ConvI8Dev p)
         ntapmask = ~m;
     }
 
-    v4i a_reg[A_PER_THREAD];
-    v4i b_reg[B_PER_THREAD];
+    v4i a_reg[2][APT];
+    v4i b_reg[2][BPT];
 
-#define YL_LOAD(KB)                                                                                 \
+#define YL_LOAD_A(KB, RS, E)                                                                        \
     {                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < A_PER_THREAD; ++i) {                                  \
-            const int idx = tid + i * NT;                                                           \
+        const int idx = tid + (E) * NT;                                                             \
+        if (A_FULL || idx < A_UNITS) {                                                              \
             const int gr = idx / BM;                                                                \
             const int mm = idx - gr * BM;                                                           \
-            a_reg[i] = *reinterpret_cast<const v4i *>(                                              \
+            a_reg[RS][E] = *reinterpret_cast<const v4i *>(                                          \
                 p.w_q + ((size_t)((KB) * BK16 + gr) * p.Mpad + m0 + mm) * 16);                      \
         }                                                                                           \
-        _Pragma("unroll") for (int i = 0; i < B_PER_THREAD; ++i) {                                  \
-            const int g = (KB) * BK16 + g0 + i * G_STEP;          /* wave-uniform */                \
-            const int tap = g >> p.Gshift;                                                          \
-            const int cg = g & (p.G - 1);                                                           \
-            const int ky = tap / p.size;                                                            \
-            const int kx = tap - ky * p.size;                                                       \
-            const int kinv = (g >= p.K16) ? -1 : 0;                                                 \
-            const int soff = kinv ? 0 : (cg * HW + ky * p.W + kx) * 16;                             \
-            const int tinv = __builtin_amdgcn_sbfe((int)ntapmask, kinv ? 31 : tap, 1);              \
-            b_reg[i] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(               \
-                rsrc, voff | tinv | kinv, soff, 0));                                                \
-        }                                                                                           \
     }
-
-#define YL_STORE(BUF)                                                                               \
+#define YL_LOAD_B(KB, RS, E)                                                                        \
     {                                                                                               \
-        uint4 *Ab_ = As + (BUF) * BK16 * BM;                                                        \
-        uint4 *Bb_ = Bs + (BUF) * BK16 * BN;                                                        \
-        _Pragma("unroll") for (int i = 0; i < A_PER_THREAD; ++i)                                    \
-            Ab_[tid + i * NT] = __builtin_bit_cast(uint4, a_reg[i]);                                \
-        _Pragma("unroll") for (int i = 0; i < B_PER_THREAD; ++i)                                    \
-            Bb_[(g0 + i * G_STEP) * BN + n_local] = __builtin_bit_cast(uint4, b_reg[i]);            \
+        const int g = (KB) * BK16 + g0 + (E) * G_STEP;            /* wave-uniform */                \
+        const int tap = g >> p.Gshift;                                                              \
+        const int cg = g & (p.G - 1);                                                               \
+        const int ky = (p.size == 3) ? ((tap * 11) >> 5) : ((p.size == 1) ? 0 : tap / p.size);      \
+        const int kx = tap - ky * p.size;                                                           \
+        const int kinv = (g >= p.K16) ? -1 : 0;                                                     \
+        const int soff = kinv ? 0 : (cg * HW + ky * p.W + kx) * 16;                                 \
+        const int tinv = __builtin_amdgcn_sbfe((int)ntapmask, kinv ? 31 : tap, 1);                  \
+        b_reg[RS][E] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(               \
+            rsrc, voff | tinv | kinv, soff, 0));                                                    \
     }
+#define YL_STORE_A(BUF, RS, E)                                                                      \
+    {                                                                                               \
+        const int idx = tid + (E) * NT;                                                             \
+        if (A_FULL || idx < A_UNITS) As[(BUF) * BK16 * BM + idx] = __builtin_bit_cast(uint4, a_reg[RS][E]); \
+    }
+#define YL_STORE_B(BUF, RS, E)                                                                      \
+    { Bs[(BUF) * BK16 * BN + (g0 + (E) * G_STEP) * BN + n_local] = __builtin_bit_cast(uint4, b_reg[RS][E]); }
 
     v16i acc[TM][TN];
 #pragma unroll
@@ -205,34 +222,74 @@ __global__ __launch_bounds__(NT) void conv_i8_mfma_kernel(ConvI8Dev p)
     const int wm0 = wm * TM * 32, wn0 = wn * TN * 32;
     const int nkb = p.K16pad / BK16;
 
-    YL_LOAD(0)
-    YL_STORE(0)
+    // ---- prologue: panel 0 -> LDS[0]; panels 1, 2 -> register ring ----
+#pragma unroll
+    for (int e = 0; e < APT; ++e) YL_LOAD_A(0, 0, e)
+#pragma unroll
+    for (int e = 0; e < BPT; ++e) YL_LOAD_B(0, 0, e)
+#pragma unroll
+    for (int e = 0; e < APT; ++e) YL_STORE_A(0, 0, e)
+#pragma unroll
+    for (int e = 0; e < BPT; ++e) YL_STORE_B(0, 0, e)
+    if (nkb > 1) {
+#pragma unroll
+        for (int e = 0; e < APT; ++e) YL_LOAD_A(1, 1, e)
+#pragma unroll
+        for (int e = 0; e < BPT; ++e) YL_LOAD_B(1, 1, e)
+    }
+    if (nkb > 2) {
+#pragma unroll
+        for (int e = 0; e < APT; ++e) YL_LOAD_A(2, 0, e)
+#pragma unroll
+        for (int e = 0; e < BPT; ++e) YL_LOAD_B(2, 0, e)
+    }
     __syncthreads();
 
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int buf = kb & 1;
-        const bool more = kb + 1 < nkb;
-        if (more) YL_LOAD(kb + 1)
-        const uint4 *Ab = As + buf * BK16 * BM + wm0 + l31;
-        const uint4 *Bb = Bs + buf * BK16 * BN + wn0 + l31;
-#pragma unroll
-        for (int ks = 0; ks < BK16 / 2; ++ks) {
-            v4i av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = __builtin_bit_cast(v4i, Ab[(2 * ks + half) * BM + i * 32]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = __builtin_bit_cast(v4i, Bb[(2 * ks + half) * BN + j * 32]);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-        if (more) YL_STORE(buf ^ 1)
-        __syncthreads();
+    // iteration KB computes from LDS[KB&1]; ring entry RS = (KB+1)&1 holds panel KB+1 (stored to
+    // LDS[(KB+1)&1] in slices) and is then refilled with panel KB+3
+#define YL_ITER(KB, RS)                                                                             \
+    {                                                                                               \
+        const int buf = (KB) & 1;                                                                   \
+        const bool do_store = (KB) + 1 < nkb;                                                       \
+        const bool do_load = (KB) + 3 < nkb;                                                        \
+        const uint4 *Ab = As + buf * BK16 * BM + wm0 + l31;                                         \
+        const uint4 *Bb = Bs + buf * BK16 * BN + wn0 + l31;                                         \
+        v4i av[2][TM], bv[2][TN];                                                                   \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) av[0][i] = __builtin_bit_cast(v4i, Ab[half * BM + i * 32]); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[0][j] = __builtin_bit_cast(v4i, Bb[half * BN + j * 32]); \
+        _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                     \
+            const int cur = ks & 1, nxt = cur ^ 1;                                                  \
+            _Pragma("unroll") for (int e = ks * APT / KSTEPS; e < (ks + 1) * APT / KSTEPS; ++e) {   \
+                if (do_store) YL_STORE_A(buf ^ 1, RS, e)                                            \
+                if (do_load) YL_LOAD_A((KB) + 3, RS, e)                                             \
+            }                                                                                       \
+            _Pragma("unroll") for (int e = ks * BPT / KSTEPS; e < (ks + 1) * BPT / KSTEPS; ++e) {   \
+                if (do_store) YL_STORE_B(buf ^ 1, RS, e)                                            \
+                if (do_load) YL_LOAD_B((KB) + 3, RS, e)                                             \
+            }                                                                                       \
+            if (ks + 1 < KSTEPS) {                                                                  \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                      \
+                    av[nxt][i] = __builtin_bit_cast(v4i, Ab[(2 * (ks + 1) + half) * BM + i * 32]);  \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                      \
+                    bv[nxt][j] = __builtin_bit_cast(v4i, Bb[(2 * (ks + 1) + half) * BN + j * 32]);  \
+            }                                                                                       \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                      \
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                      \
+        }                                                                                           \
+        __syncthreads();                                                                            \
     }
-#undef YL_LOAD
-#undef YL_STORE
+
+    for (int kb = 0; kb < nkb; kb += 2) {
+        YL_ITER(kb, 1)
+        if (kb + 1 < nkb) YL_ITER(kb + 1, 0)
+    }
+#undef YL_ITER
+#undef YL_LOAD_A
+#undef YL_LOAD_B
+#undef YL_STORE_A
+#undef YL_STORE_B
 
     // ---- exact reference epilogue ----
 #pragma unroll
@@ -248,14 +305,14 @@ __global__ __launch_bounds__(NT) void conv_i8_mfma_kernel(ConvI8Dev p)
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
                 if (m < p.M) {
-                    int o = acc[i][j][e] / 32;                       // C truncating division
-                    if (o > 32767) o = 32767;                        // max_abs(., 256*128-1)
-                    if (o < -32767) o = -32767;
+                    const int a = acc[i][j][e];
+                    int o = (a + ((a >> 31) & 31)) >> 5;             // a / 32, C truncation toward zero
+                    o = o > 32767 ? 32767 : (o < -32767 ? -32767 : o);   // max_abs(., 256*128-1)
                     const size_t oi = obase + (size_t)m * p.OHW;
                     if (p.dbg) p.dbg[oi] = o;
                     float y = __fmul_rn((float)o, p.alpha1);
                     y = __fadd_rn(y, p.bias[m]);
-                    if (p.act == YL_LEAKY) y = (y > 0.f) ? y : __fdiv_rn(y, 10.f);
+                    if (p.act == YL_LEAKY) y = (y > 0.f) ? y : div10_exact(y);
                     p.out[oi] = y;
                 }
             }
