@@ -21,6 +21,7 @@
 // Roofline: with FP32 activations in/out this path is HBM-bound, not MFMA-bound.
 #include <hip/hip_runtime.h>
 #include <climits>
+#include <cstdlib>
 
 #include "kernels.h"
 #include "../../include/yolo2_hip.h"
@@ -75,12 +76,15 @@ int launch_quantize_nhwc(const float *in, int8_t *out, int B, int C, int H, int 
 }
 
 // ------------------------------------------------------------------ K2b: INT8 MFMA implicit GEMM
-// Schedule: like K1 v2.  One LDS panel = BK16 16-byte k-units (128 bytes of K) for BM filters and
-// BN pixels; LDS is double-buffered, and a 2-deep REGISTER ring holds panels kb+1 and kb+2, so a
-// gather issued in iteration kb is consumed in iteration kb+2 (two iterations of latency budget:
-// with 32-cycle MFMAs an iteration is only ~512 pipe cycles, far less than a loaded HBM/L2 round
-// trip).  The staging slices (ds_write of the older ring entry, its reload, next operands' ds_read)
-// are interleaved between the MFMAs of each k-step and pinned with sched_barrier.
+// With 32-cycle MFMAs and K of only 0.1-9 KB per output the matrix work is ~5 % of this
+// kernel; measured (profiles/r1_int8_pmc.txt) it is bound by instruction issue and by how
+// many waves are in flight, so the design goals are: few instructions per output, small
+// register/LDS footprint (3 waves/SIMD), loads one full iteration ahead.
+//   - one LDS panel = BK16 16-byte k-units (128 bytes of K), double-buffered; registers hold
+//     panel kb+1 and are refilled with panel kb+2 in slices interleaved with the MFMAs (as K1 v2)
+//   - when G >= BK16 (C >= 128) a panel lies inside one tap: tap decode once per panel
+//   - bias comes from LDS, the epilogue is ~15 VALU per output and exact (see below)
+//   - optional fused [shortcut] (out_add = y + add), bit-identical to the separate kernel
 constexpr int BK16 = 8;          // 16-byte k-units per LDS panel (= 4 MFMA k-steps of 32)
 constexpr int NT = 256;
 
@@ -88,6 +92,8 @@ struct ConvI8Dev {
     const int8_t *in_q;
     const int8_t *w_q;
     const float *bias;
+    const float *add;
+    float *out_add;
     float *out;
     int32_t *dbg;
     int B, G, Gshift, H, W, M, Mpad, OH, OW;
@@ -109,7 +115,7 @@ __device__ __forceinline__ float div10_exact(float y)
     return __fmaf_rn(e, r, q);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool TAPPANEL>
 __global__ __launch_bounds__(NT) void conv_i8_mfma_kernel(ConvI8Dev p)
 {
     constexpr int TM = BM / (WM * 32);
@@ -123,9 +129,10 @@ __global__ __launch_bounds__(NT) void conv_i8_mfma_kernel(ConvI8Dev p)
     constexpr int BPT = BK16 * BN / NT;
     constexpr int G_STEP = NT / BN;
 
-    __shared__ __attribute__((aligned(16))) uint4 smem[2 * BK16 * BM + 2 * BK16 * BN];
+    __shared__ __attribute__((aligned(16))) uint4 smem[2 * BK16 * BM + 2 * BK16 * BN + BM / 4];
     uint4 *As = smem;
     uint4 *Bs = smem + 2 * BK16 * BM;
+    float *bias_s = reinterpret_cast<float *>(smem + 2 * BK16 * BM + 2 * BK16 * BN);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -139,6 +146,8 @@ __global__ __launch_bounds__(NT) void conv_i8_mfma_kernel(ConvI8Dev p)
     const int tile_m = logical % p.tiles_m;
     const int tile_n = logical / p.tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    if (tid < BM) bias_s[tid] = (m0 + tid < p.M) ? p.bias[m0 + tid] : 0.f;
 
     const int n_local = tid % BN;
     const int g0 = __builtin_amdgcn_readfirstlane(tid / BN);
@@ -176,39 +185,56 @@ __global__ __launch_bounds__(NT) void conv_i8_mfma_kernel(ConvI8Dev p)
         ntapmask = ~m;
     }
 
-    v4i a_reg[2][APT];
-    v4i b_reg[2][BPT];
+    v4i a_reg[APT];
+    v4i b_reg[BPT];
+    // TAPPANEL: per-panel state of the NEXT panel to load (all its units share one tap)
+    int pn_soff = 0, pn_tinv = 0;
 
-#define YL_LOAD_A(KB, RS, E)                                                                        \
+#define YL_PANEL_SETUP(KB)                                                                          \
+    if (TAPPANEL) {                                                                                 \
+        const int g = (KB) * BK16;                                                                  \
+        const int tap = g >> p.Gshift;                                                              \
+        const int cg = g & (p.G - 1);                                                               \
+        const int ky = (p.size == 3) ? ((tap * 11) >> 5) : ((p.size == 1) ? 0 : tap / p.size);      \
+        const int kx = tap - ky * p.size;                                                           \
+        pn_soff = (cg * HW + ky * p.W + kx) * 16;                                                   \
+        pn_tinv = __builtin_amdgcn_sbfe((int)ntapmask, tap, 1);                                     \
+    }
+#define YL_LOAD_A(KB, E)                                                                            \
     {                                                                                               \
         const int idx = tid + (E) * NT;                                                             \
         if (A_FULL || idx < A_UNITS) {                                                              \
             const int gr = idx / BM;                                                                \
             const int mm = idx - gr * BM;                                                           \
-            a_reg[RS][E] = *reinterpret_cast<const v4i *>(                                          \
+            a_reg[E] = *reinterpret_cast<const v4i *>(                                              \
                 p.w_q + ((size_t)((KB) * BK16 + gr) * p.Mpad + m0 + mm) * 16);                      \
         }                                                                                           \
     }
-#define YL_LOAD_B(KB, RS, E)                                                                        \
+#define YL_LOAD_B(KB, E)                                                                            \
     {                                                                                               \
-        const int g = (KB) * BK16 + g0 + (E) * G_STEP;            /* wave-uniform */                \
-        const int tap = g >> p.Gshift;                                                              \
-        const int cg = g & (p.G - 1);                                                               \
-        const int ky = (p.size == 3) ? ((tap * 11) >> 5) : ((p.size == 1) ? 0 : tap / p.size);      \
-        const int kx = tap - ky * p.size;                                                           \
-        const int kinv = (g >= p.K16) ? -1 : 0;                                                     \
-        const int soff = kinv ? 0 : (cg * HW + ky * p.W + kx) * 16;                                 \
-        const int tinv = __builtin_amdgcn_sbfe((int)ntapmask, kinv ? 31 : tap, 1);                  \
-        b_reg[RS][E] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(               \
-            rsrc, voff | tinv | kinv, soff, 0));                                                    \
+        int soff, tinv;                                                                             \
+        if (TAPPANEL) {       /* K16 % BK16 == 0 here: no K tail */                                 \
+            soff = pn_soff + (g0 + (E) * G_STEP) * HW * 16;                                         \
+            tinv = pn_tinv;                                                                         \
+        } else {                                                                                    \
+            const int g = (KB) * BK16 + g0 + (E) * G_STEP;        /* wave-uniform */                \
+            const int tap = g >> p.Gshift;                                                          \
+            const int cg = g & (p.G - 1);                                                           \
+            const int ky = (p.size == 3) ? ((tap * 11) >> 5) : ((p.size == 1) ? 0 : tap / p.size);  \
+            const int kx = tap - ky * p.size;                                                       \
+            const int kinv = (g >= p.K16) ? -1 : 0;                                                 \
+            soff = kinv ? 0 : (cg * HW + ky * p.W + kx) * 16;                                       \
+            tinv = __builtin_amdgcn_sbfe((int)ntapmask, kinv ? 31 : tap, 1) | kinv;                 \
+        }                                                                                           \
+        b_reg[E] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff | tinv, soff, 0)); \
     }
-#define YL_STORE_A(BUF, RS, E)                                                                      \
+#define YL_STORE_A(BUF, E)                                                                          \
     {                                                                                               \
         const int idx = tid + (E) * NT;                                                             \
-        if (A_FULL || idx < A_UNITS) As[(BUF) * BK16 * BM + idx] = __builtin_bit_cast(uint4, a_reg[RS][E]); \
+        if (A_FULL || idx < A_UNITS) As[(BUF) * BK16 * BM + idx] = __builtin_bit_cast(uint4, a_reg[E]); \
     }
-#define YL_STORE_B(BUF, RS, E)                                                                      \
-    { Bs[(BUF) * BK16 * BN + (g0 + (E) * G_STEP) * BN + n_local] = __builtin_bit_cast(uint4, b_reg[RS][E]); }
+#define YL_STORE_B(BUF, E)                                                                          \
+    { Bs[(BUF) * BK16 * BN + (g0 + (E) * G_STEP) * BN + n_local] = __builtin_bit_cast(uint4, b_reg[E]); }
 
     v16i acc[TM][TN];
 #pragma unroll
@@ -222,76 +248,73 @@ __global__ __launch_bounds__(NT) void conv_i8_mfma_kernel(ConvI8Dev p)
     const int wm0 = wm * TM * 32, wn0 = wn * TN * 32;
     const int nkb = p.K16pad / BK16;
 
-    // ---- prologue: panel 0 -> LDS[0]; panels 1, 2 -> register ring ----
+    // ---- prologue: panel 0 -> LDS[0]; panel 1 -> registers ----
+    YL_PANEL_SETUP(0)
 #pragma unroll
-    for (int e = 0; e < APT; ++e) YL_LOAD_A(0, 0, e)
+    for (int e = 0; e < APT; ++e) YL_LOAD_A(0, e)
 #pragma unroll
-    for (int e = 0; e < BPT; ++e) YL_LOAD_B(0, 0, e)
+    for (int e = 0; e < BPT; ++e) YL_LOAD_B(0, e)
 #pragma unroll
-    for (int e = 0; e < APT; ++e) YL_STORE_A(0, 0, e)
+    for (int e = 0; e < APT; ++e) YL_STORE_A(0, e)
 #pragma unroll
-    for (int e = 0; e < BPT; ++e) YL_STORE_B(0, 0, e)
+    for (int e = 0; e < BPT; ++e) YL_STORE_B(0, e)
     if (nkb > 1) {
+        YL_PANEL_SETUP(1)
 #pragma unroll
-        for (int e = 0; e < APT; ++e) YL_LOAD_A(1, 1, e)
+        for (int e = 0; e < APT; ++e) YL_LOAD_A(1, e)
 #pragma unroll
-        for (int e = 0; e < BPT; ++e) YL_LOAD_B(1, 1, e)
-    }
-    if (nkb > 2) {
-#pragma unroll
-        for (int e = 0; e < APT; ++e) YL_LOAD_A(2, 0, e)
-#pragma unroll
-        for (int e = 0; e < BPT; ++e) YL_LOAD_B(2, 0, e)
+        for (int e = 0; e < BPT; ++e) YL_LOAD_B(1, e)
     }
     __syncthreads();
 
-    // iteration KB computes from LDS[KB&1]; ring entry RS = (KB+1)&1 holds panel KB+1 (stored to
-    // LDS[(KB+1)&1] in slices) and is then refilled with panel KB+3
-#define YL_ITER(KB, RS)                                                                             \
-    {                                                                                               \
-        const int buf = (KB) & 1;                                                                   \
-        const bool do_store = (KB) + 1 < nkb;                                                       \
-        const bool do_load = (KB) + 3 < nkb;                                                        \
-        const uint4 *Ab = As + buf * BK16 * BM + wm0 + l31;                                         \
-        const uint4 *Bb = Bs + buf * BK16 * BN + wn0 + l31;                                         \
-        v4i av[2][TM], bv[2][TN];                                                                   \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) av[0][i] = __builtin_bit_cast(v4i, Ab[half * BM + i * 32]); \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[0][j] = __builtin_bit_cast(v4i, Bb[half * BN + j * 32]); \
-        _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                     \
-            const int cur = ks & 1, nxt = cur ^ 1;                                                  \
-            _Pragma("unroll") for (int e = ks * APT / KSTEPS; e < (ks + 1) * APT / KSTEPS; ++e) {   \
-                if (do_store) YL_STORE_A(buf ^ 1, RS, e)                                            \
-                if (do_load) YL_LOAD_A((KB) + 3, RS, e)                                             \
-            }                                                                                       \
-            _Pragma("unroll") for (int e = ks * BPT / KSTEPS; e < (ks + 1) * BPT / KSTEPS; ++e) {   \
-                if (do_store) YL_STORE_B(buf ^ 1, RS, e)                                            \
-                if (do_load) YL_LOAD_B((KB) + 3, RS, e)                                             \
-            }                                                                                       \
-            if (ks + 1 < KSTEPS) {                                                                  \
-                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                      \
-                    av[nxt][i] = __builtin_bit_cast(v4i, Ab[(2 * (ks + 1) + half) * BM + i * 32]);  \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                      \
-                    bv[nxt][j] = __builtin_bit_cast(v4i, Bb[(2 * (ks + 1) + half) * BN + j * 32]);  \
-            }                                                                                       \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                          \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                      \
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0); \
-            __builtin_amdgcn_sched_barrier(0);                                                      \
-        }                                                                                           \
-        __syncthreads();                                                                            \
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+        const bool do_store = kb + 1 < nkb;
+        const bool do_load = kb + 2 < nkb;
+        if (do_load) { YL_PANEL_SETUP(kb + 2) }
+        const uint4 *Ab = As + buf * BK16 * BM + wm0 + l31;
+        const uint4 *Bb = Bs + buf * BK16 * BN + wn0 + l31;
+        v4i av[2][TM], bv[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[0][i] = __builtin_bit_cast(v4i, Ab[half * BM + i * 32]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[0][j] = __builtin_bit_cast(v4i, Bb[half * BN + j * 32]);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+#pragma unroll
+            for (int e = ks * APT / KSTEPS; e < (ks + 1) * APT / KSTEPS; ++e) {
+                if (do_store) YL_STORE_A(buf ^ 1, e)
+                if (do_load) YL_LOAD_A(kb + 2, e)
+            }
+#pragma unroll
+            for (int e = ks * BPT / KSTEPS; e < (ks + 1) * BPT / KSTEPS; ++e) {
+                if (do_store) YL_STORE_B(buf ^ 1, e)
+                if (do_load) YL_LOAD_B(kb + 2, e)
+            }
+            if (ks + 1 < KSTEPS) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[nxt][i] = __builtin_bit_cast(v4i, Ab[(2 * (ks + 1) + half) * BM + i * 32]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bv[nxt][j] = __builtin_bit_cast(v4i, Bb[(2 * (ks + 1) + half) * BN + j * 32]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
     }
-
-    for (int kb = 0; kb < nkb; kb += 2) {
-        YL_ITER(kb, 1)
-        if (kb + 1 < nkb) YL_ITER(kb + 1, 0)
-    }
-#undef YL_ITER
+#undef YL_PANEL_SETUP
 #undef YL_LOAD_A
 #undef YL_LOAD_B
 #undef YL_STORE_A
 #undef YL_STORE_B
 
     // ---- exact reference epilogue ----
+    //   o16 = clamp_abs(acc32 / 32 [C truncation], 32767); y = o16*ALPHA1; y += bias; leaky: y/10
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn0 + j * 32 + l31;
@@ -303,17 +326,18 @@ __global__ __launch_bounds__(NT) void conv_i8_mfma_kernel(ConvI8Dev p)
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                if (m < p.M) {
+                const int ml = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (m0 + ml < p.M) {
                     const int a = acc[i][j][e];
                     int o = (a + ((a >> 31) & 31)) >> 5;             // a / 32, C truncation toward zero
                     o = o > 32767 ? 32767 : (o < -32767 ? -32767 : o);   // max_abs(., 256*128-1)
-                    const size_t oi = obase + (size_t)m * p.OHW;
+                    const size_t oi = obase + (size_t)(m0 + ml) * p.OHW;
                     if (p.dbg) p.dbg[oi] = o;
                     float y = __fmul_rn((float)o, p.alpha1);
-                    y = __fadd_rn(y, p.bias[m]);
+                    y = __fadd_rn(y, bias_s[ml]);
                     if (p.act == YL_LEAKY) y = (y > 0.f) ? y : div10_exact(y);
-                    p.out[oi] = y;
+                    if (p.out) p.out[oi] = y;
+                    if (p.add) p.out_add[oi] = __fadd_rn(y, p.add[oi]);
                 }
             }
         }
@@ -326,7 +350,11 @@ static int launch_i8_tile(ConvI8Dev p, hipStream_t s)
     p.tiles_m = (p.M + BM - 1) / BM;
     const long long blocks = (long long)p.tiles_m * ((p.Ntotal + BN - 1) / BN);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(NT), 0, s, p);
+    // a panel of BK16 units lies inside one tap when G is a multiple of BK16 (C >= 128)
+    if (p.G >= BK16)
+        hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, true>), dim3((unsigned)blocks), dim3(NT), 0, s, p);
+    else
+        hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, false>), dim3((unsigned)blocks), dim3(NT), 0, s, p);
     return (int)hipGetLastError();
 }
 
@@ -334,6 +362,7 @@ int launch_conv_i8(const ConvI8Args &a, void *stream)
 {
     ConvI8Dev d;
     d.in_q = a.in_q; d.w_q = a.w_q; d.bias = a.bias; d.out = a.out; d.dbg = a.dbg;
+    d.add = a.add; d.out_add = a.out_add;
     d.B = a.B; d.G = a.Cpad / 16; d.H = a.H; d.W = a.W; d.M = a.M; d.Mpad = a.Mpad; d.OH = a.OH; d.OW = a.OW;
     d.size = a.size; d.stride = a.stride; d.pad = a.pad; d.act = a.act; d.alpha1 = a.alpha1;
     if (d.G <= 0 || (d.G & (d.G - 1)) != 0 || a.size > 5) return (int)hipErrorInvalidValue;
@@ -347,8 +376,10 @@ int launch_conv_i8(const ConvI8Args &a, void *stream)
     d.Ntotal = (int)nt;
     d.tiles_m = 0;
     hipStream_t s = (hipStream_t)stream;
+    // tuning hook: YL_I8_TILE=64 forces the 64x128 tile (49 KB LDS -> 3 workgroups/CU)
+    static const int force = [] { const char *e = getenv("YL_I8_TILE"); return e ? atoi(e) : 0; }();
     if (a.M <= 32) return launch_i8_tile<32, 256, 1, 4>(d, s);
-    if (a.M <= 64) return launch_i8_tile<64, 128, 2, 2>(d, s);
+    if (a.M <= 64 || force == 64) return launch_i8_tile<64, 128, 2, 2>(d, s);
     return launch_i8_tile<128, 128, 2, 2>(d, s);
 }
 

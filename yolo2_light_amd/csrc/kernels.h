@@ -38,6 +38,8 @@ struct ConvI8Args {
     const float *bias;    // [M]
     float *out;           // [B][M][OH][OW]; may be nullptr when only out_add is wanted fp32
     int32_t *dbg;         // optional int16-clamped accumulators [B][M][OH][OW]
+    const float *add;     // optional fused [shortcut] (see ConvF32Args)
+    float *out_add;
     int B, Cpad, H, W, M, Mpad, OH, OW;
     int size, stride, pad;
     int act;

@@ -211,7 +211,7 @@ static int to_device(Network &net, int device)
         for (int i = 1; i < nl; ++i) {
             Layer &sc = net.layers[i];
             Layer &cv = net.layers[i - 1];
-            if (sc.type != YL_SHORTCUT || cv.type != YL_CONVOLUTIONAL || cv.conv_mode != CONV_F32) continue;
+            if (sc.type != YL_SHORTCUT || cv.type != YL_CONVOLUTIONAL || cv.conv_mode == CONV_XNOR) continue;
             if (sc.activation != YL_LINEAR) continue;
             if (!(sc.w == sc.out_w && sc.h == sc.out_h && sc.c == sc.out_c)) continue;   // same-shape add only
             if (sc.index == i - 1) continue;
@@ -267,6 +267,13 @@ static int forward_layer(Network &net, size_t i, const float *input)
                       "quantize_nhwc");
             ConvI8Args a;
             a.in_q = net.d_qbuf; a.w_q = l.d_weights_i8; a.bias = l.d_biases; a.out = l.d_output; a.dbg = l.d_debug;
+            a.add = nullptr; a.out_add = nullptr;
+            if (l.fused_shortcut >= 0) {
+                Layer &sc = net.layers[l.fused_shortcut];
+                a.add = net.layers[sc.index].d_output;
+                a.out_add = sc.d_output;
+                a.out = nullptr;
+            }
             a.B = B; a.Cpad = l.Cpad; a.H = l.h; a.W = l.w; a.M = l.n; a.Mpad = l.Mpad; a.OH = l.out_h; a.OW = l.out_w;
             a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
             // float ALPHA1 = R_MULT / (l.input_quant_multipler * l.weights_quant_multipler);  (quantized.c:596)
