@@ -50,7 +50,7 @@ CONV_SHAPES = [
 
 # (variant, forced tile): variant 0 = v1 burst schedule (tiles 1..8), variant 1 = v2 software-pipelined
 # schedule with tap-major K order where C % 16 == 0 (tiles 11..19); tile 0 = the built-in heuristic
-VARIANT_TILES = [(0, t) for t in range(0, 9)] + [(1, 0)] + [(1, t) for t in range(11, 20)]
+VARIANT_TILES = [(0, t) for t in range(0, 9)] + [(1, 0)] + [(1, t) for t in range(11, 23)]
 
 
 @pytest.mark.parametrize("shape", CONV_SHAPES)

@@ -23,6 +23,7 @@
 #include <cstdio>
 
 #include "kernels.h"
+#include "epilogue.h"
 #include "../../include/yolo2_hip.h"
 
 namespace yl {
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
     constexpr int KSTEPS = BK / 2;
     static_assert(WM * WN == NWAVES, "wave grid");
     static_assert(TM >= 1 && TN >= 1, "tile too small");
+    static_assert(NWAVES * 8 * TN * 32 <= 2 * BK * (BM + BN), "epilogue strips fit in the panel buffers");
     static_assert(BN % 64 == 0 && BN <= NT, "a wave must stay inside one k row of the B panel");
     constexpr int A_F4 = BK * BM / 4;
     constexpr int APT = (A_F4 + NT - 1) / NT;               // float4 per thread per panel
@@ -288,28 +290,26 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
 #undef YL_STORE_A
 #undef YL_STORE_B
 
-    // ---- fused epilogue (identical arithmetic to v1) ----
+    // ---- fused epilogue: +bias, activation (identical arithmetic to v1), then row-wise stores
+    //      through a wave-private LDS strip (epilogue.h); the main loop's last barrier has passed,
+    //      so the panel buffers are dead and are reused as the strips ----
+    float *strip = smem + wave * (8 * TN * 32);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn0 + j * 32 + l31;
-        if (n >= p.Ntotal) continue;
-        const int ob = n / p.OHW;
-        const int opix = n - ob * p.OHW;
-        const size_t obase = (size_t)ob * p.M * p.OHW + opix;
+    for (int i = 0; i < TM; ++i) {
+        float vals[TN][16];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            const float bv = (m < p.M) ? p.bias[m] : 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                if (m < p.M) {
-                    float v = acc[i][j][e] + p.bias[m];
-                    if (p.act == YL_LEAKY) v = (v > 0.f) ? v : (float)(.1 * (double)v);
-                    const size_t o = obase + (size_t)m * p.OHW;
-                    if (p.out) p.out[o] = v;
-                    if (p.add) p.out_add[o] = v + p.add[o];
-                }
+            for (int j = 0; j < TN; ++j) {
+                float v = acc[i][j][e] + bv;
+                if (p.act == YL_LEAKY) v = (v > 0.f) ? v : (float)(.1 * (double)v);
+                vals[j][e] = v;
             }
         }
+        store_rows_via_lds<TN>(strip, vals, m0 + wm0 + i * 32, p.M, n0 + wn0, p.Ntotal, p.OHW,
+                               p.out, p.add, p.out_add, lane);
     }
 }
 
@@ -365,6 +365,9 @@ int launch_conv_f32_v2(const ConvF32Args &a, int cfg, void *stream, char *name, 
     case 7: t = "128x256w8";    rc = launch_pipe<128, 256, 2, 4, 16, 8>(d, ks, a.tapmajor != 0, s); break;
     case 8: t = "256x128w8k32"; rc = launch_pipe<256, 128, 4, 2, 32, 8>(d, ks, a.tapmajor != 0, s); break;
     case 9: t = "128x128w8";    rc = launch_pipe<128, 128, 4, 2, 16, 8>(d, ks, a.tapmajor != 0, s); break;
+    case 10: t = "128x256w8r";  rc = launch_pipe<128, 256, 4, 2, 16, 8>(d, ks, a.tapmajor != 0, s); break;
+    case 11: t = "256x128w8r";  rc = launch_pipe<256, 128, 8, 1, 16, 8>(d, ks, a.tapmajor != 0, s); break;
+    case 12: t = "128x128r";    rc = launch_pipe<128, 128, 4, 1, 16, 4>(d, ks, a.tapmajor != 0, s); break;
     default: return (int)hipErrorInvalidValue;
     }
     if (name) snprintf(name, name_len, "conv_f32_mfma_pipe<%s,ks%d%s>", t, ks, a.tapmajor ? ",tap" : "");

@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "epilogue.h"
 #include "../../include/yolo2_hip.h"
 
 namespace yl {
@@ -313,34 +314,53 @@ __global__ __launch_bounds__(NT) void conv_i8_mfma_kernel(ConvI8Dev p)
 #undef YL_STORE_A
 #undef YL_STORE_B
 
-    // ---- exact reference epilogue ----
+    // ---- exact reference epilogue, then row-wise stores through wave-private LDS strips ----
     //   o16 = clamp_abs(acc32 / 32 [C truncation], 32767); y = o16*ALPHA1; y += bias; leaky: y/10
+    float bias_r[TM][16];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn0 + j * 32 + l31;
-        if (n >= p.Ntotal) continue;
-        const int ob = n / p.OHW;
-        const int opix = n - ob * p.OHW;
-        const size_t obase = (size_t)ob * p.M * p.OHW + opix;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int e = 0; e < 16; ++e) bias_r[i][e] = bias_s[wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half];
+    if (p.dbg) {          // parity hook: int16-clamped accumulators, straight from the C/D layout
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + j * 32 + l31;
+            if (n >= p.Ntotal) continue;
+            const int ob = n / p.OHW;
+            const size_t obase = (size_t)ob * p.M * p.OHW + (n - ob * p.OHW);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    if (m < p.M) {
+                        const int a = acc[i][j][e];
+                        int o = (a + ((a >> 31) & 31)) >> 5;
+                        o = o > 32767 ? 32767 : (o < -32767 ? -32767 : o);
+                        p.dbg[obase + (size_t)m * p.OHW] = o;
+                    }
+                }
+        }
+    }
+    __syncthreads();      // bias_s and the panel buffers are dead from here: reuse as strips
+    float *strip = reinterpret_cast<float *>(smem) + wave * (8 * TN * 32);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float vals[TN][16];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int ml = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                if (m0 + ml < p.M) {
-                    const int a = acc[i][j][e];
-                    int o = (a + ((a >> 31) & 31)) >> 5;             // a / 32, C truncation toward zero
-                    o = o > 32767 ? 32767 : (o < -32767 ? -32767 : o);   // max_abs(., 256*128-1)
-                    const size_t oi = obase + (size_t)(m0 + ml) * p.OHW;
-                    if (p.dbg) p.dbg[oi] = o;
-                    float y = __fmul_rn((float)o, p.alpha1);
-                    y = __fadd_rn(y, bias_s[ml]);
-                    if (p.act == YL_LEAKY) y = (y > 0.f) ? y : div10_exact(y);
-                    if (p.out) p.out[oi] = y;
-                    if (p.add) p.out_add[oi] = __fadd_rn(y, p.add[oi]);
-                }
+                const int a = acc[i][j][e];
+                int o = (a + ((a >> 31) & 31)) >> 5;                 // a / 32, C truncation toward zero
+                o = o > 32767 ? 32767 : (o < -32767 ? -32767 : o);   // max_abs(., 256*128-1)
+                float y = __fmul_rn((float)o, p.alpha1);
+                y = __fadd_rn(y, bias_r[i][e]);
+                if (p.act == YL_LEAKY) y = (y > 0.f) ? y : div10_exact(y);
+                vals[j][e] = y;
             }
-        }
+        store_rows_via_lds<TN>(strip, vals, m0 + wm0 + i * 32, p.M, n0 + wn0, p.Ntotal, p.OHW,
+                               p.out, p.add, p.out_add, lane);
     }
 }
 
@@ -380,7 +400,7 @@ int launch_conv_i8(const ConvI8Args &a, void *stream)
     static const int force = [] { const char *e = getenv("YL_I8_TILE"); return e ? atoi(e) : 0; }();
     if (a.M <= 32) return launch_i8_tile<32, 256, 1, 4>(d, s);
     if (a.M <= 64 || force == 64) return launch_i8_tile<64, 128, 2, 2>(d, s);
-    return launch_i8_tile<128, 128, 2, 2>(d, s);
+    return launch_i8_tile<128, 128, 4, 1>(d, s);
 }
 
 }  // namespace yl

@@ -1,0 +1,85 @@
+// epilogue.h -- shared store path of the MFMA convolution kernels (K1, K2).
+//
+// A 32x32 MFMA accumulator gives each lane ONE pixel column and 16 filter rows, so storing it
+// directly costs one 4-byte store instruction per value and touches only 128 contiguous bytes
+// per row.  Measured on MI355X (profiles/r1_int8_pmc.txt) that store tail -- not the MFMAs --
+// bounds the INT8 kernel and the HBM-bound early FP32 layers.  Here a wave stages 8 filter rows
+// x (TN*32) pixels of finished values in a wave-private LDS strip and writes them back as rows:
+// every store instruction moves 16 bytes per lane, 4x fewer instructions, up to 512 contiguous
+// bytes per row (NCHW: a row is one filter over consecutive pixels).  The optional fused
+// [shortcut] operand is read with the same 16-byte row accesses.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace yl {
+
+// vals[j][e]: finished outputs of one 32-row (TM) block of this wave in MFMA C/D layout:
+//   column n = n_base + j*32 + (lane & 31), row m = m_base + (e & 3) + 8*(e >> 2) + 4*(lane >> 5)
+// strip: wave-private LDS, >= 8 * TN * 32 floats, 16-byte aligned.
+// out may be nullptr (only out_add wanted); add/out_add may be nullptr.
+template <int TN>
+__device__ __forceinline__ void store_rows_via_lds(float *strip, const float (&vals)[TN][16], int m_base, int M,
+                                                   int n_base, int Ntotal, int OHW, float *out,
+                                                   const float *add, float *out_add, int lane)
+{
+    constexpr int ROW = TN * 32;              // floats per staged row
+    constexpr int LPR = TN * 8;               // lanes (float4) per row
+    constexpr int RPI = 64 / LPR;             // rows per store instruction
+    constexpr int NI = 8 / RPI;               // store instructions per 8-row chunk
+    static_assert(RPI >= 1 && NI >= 1, "TN in {1,2,4}");
+    const int l31 = lane & 31, half = lane >> 5;
+    const int c4 = lane % LPR;                // float4 column owned by this lane when storing
+    const int rsub = lane / LPR;
+    const int n = n_base + c4 * 4;            // first of this lane's 4 consecutive pixels
+    // (image, pixel) of the 4 pixels: contiguous in NCHW iff they share the image
+    const int ob = n / OHW;
+    const int opix = n - ob * OHW;
+    const bool in_range = n + 3 < Ntotal;
+    const bool same_img = in_range && (opix + 3 < OHW);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) strip[(r + 4 * half) * ROW + j * 32 + l31] = vals[j][4 * g + r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int t = 0; t < NI; ++t) {
+            const int row = t * RPI + rsub;                    // 0..7 inside the chunk
+            const int m = m_base + 8 * g + row;
+            const float4 v = *reinterpret_cast<const float4 *>(strip + row * ROW + c4 * 4);
+            if (m < M && n < Ntotal) {
+                const size_t o = ((size_t)ob * M + m) * OHW + opix;
+                if (same_img && ((o & 3) == 0)) {
+                    if (out) *reinterpret_cast<float4 *>(out + o) = v;
+                    if (add) {
+                        const float4 a = *reinterpret_cast<const float4 *>(add + o);
+                        float4 s;
+                        s.x = __fadd_rn(v.x, a.x); s.y = __fadd_rn(v.y, a.y);
+                        s.z = __fadd_rn(v.z, a.z); s.w = __fadd_rn(v.w, a.w);
+                        *reinterpret_cast<float4 *>(out_add + o) = s;
+                    }
+                } else {
+                    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int nq = n + q;
+                        if (nq < Ntotal) {
+                            const int obq = nq / OHW;
+                            const size_t oq = ((size_t)obq * M + m) * OHW + (nq - obq * OHW);
+                            if (out) out[oq] = vv[q];
+                            if (add) out_add[oq] = __fadd_rn(vv[q], add[oq]);
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+}  // namespace yl
