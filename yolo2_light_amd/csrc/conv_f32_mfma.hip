@@ -313,14 +313,15 @@ int launch_conv_f32(const ConvF32Args &a, void *stream)
         if (cfg == 0) {
             const long long ntot = (long long)a.B * a.OH * a.OW;
             auto nblocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((ntot + bn - 1) / bn); };
-            // measured on MI355X with tools/sweep_conv.py (profiles/sweep_r1.txt): the 8-wave
-            // 128x256 tile wins every 3x3 shape with M >= 128 (118-125 TF), the 8-wave 128x128
-            // tile the 1x1 shapes, 64x128 / 32x256 the narrow-M early layers; layers too small
-            // to give every CU two workgroups fall back to 64x64 tiles.
+            // measured on MI355X with tools/sweep_conv.py (profiles/r1_sweep_conv_tiles_b64*.txt):
+            // tiles whose waves own 128 consecutive pixels (512-byte rows in the LDS-staged
+            // epilogue) win: 4-wave 128x128 (TM=1,TN=4) for M <= 256 and for 1x1, 8-wave 128x256
+            // (TM=1,TN=4) for wider 3x3 layers; 64x128 / 32x256 for the narrow-M early layers;
+            // layers too small to give every CU two workgroups fall back to 64x64 tiles.
             if (a.M <= 32) cfg = 3;
             else if (a.M <= 64) cfg = 2;
-            else if (a.size == 1) cfg = (nblocks(128, 128) >= 512) ? 9 : 4;
-            else cfg = (nblocks(128, 256) >= 384) ? 7 : ((nblocks(128, 128) >= 512) ? 1 : 4);
+            else if (a.size == 1 || a.M <= 256) cfg = (nblocks(128, 128) >= 512) ? 12 : 4;
+            else cfg = (nblocks(128, 256) >= 384) ? 10 : ((nblocks(128, 128) >= 512) ? 12 : 4);
             if (cfg <= 3 && nblocks(cfg == 2 ? 64 : 32, cfg == 3 ? 256 : 128) < 512) cfg = 4;
         }
         // BK=32 variants need C % 32 == 0 in tap-major order
