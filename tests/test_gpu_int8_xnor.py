@@ -219,3 +219,29 @@ def test_int8_network_vs_reference_library_batch1():
     g = net.get_boxes(0, width, height, 0.24, nms=0.4)
     assert abs(len(r) - len(g)) <= max(2, len(r) // 50)
     net.close()
+
+
+def test_int8_fusion_is_bit_identical():
+    """-quantized yolov3 with yl_network_set_fusion: conv+[shortcut] folded, the next layer's int8
+    input written from the producer's epilogue (no separate quantise pass), unread FP32 tensors
+    skipped.  Every tensor that is still materialised must equal the unfused run bit for bit."""
+    name, width, height, batch = "yolov3", 96, 96, 2
+    cfg, wts = common.model_files(name, width, height)
+    x = common.seeded_input(batch, 3, height, width)
+    plain = Network.load(cfg, wts, batch, 1, device=0)
+    fused = Network.load(cfg, wts, batch, 1, device=0, fuse=True)
+    plain.predict(x)
+    fused.predict(x)
+    infos = plain.layers()
+    checked = 0
+    for i, li in enumerate(infos):
+        if li["type"] in (common.SHORTCUT, common.ROUTE, common.YOLO, common.UPSAMPLE) or \
+                (li["type"] == common.CONV and li["activation"] == D.LINEAR):
+            a, b = plain.layer_output(i), fused.layer_output(i)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "layer %d %r" % (i, li)
+            checked += 1
+    assert checked > 30
+    for b in range(batch):
+        assert np.array_equal(plain.get_boxes(b, width, height, 0.24, nms=0.4),
+                              fused.get_boxes(b, width, height, 0.24, nms=0.4))
+    plain.close(); fused.close()

@@ -49,13 +49,7 @@ __global__ __launch_bounds__(256) void quantize_nc16_kernel(const float *__restr
         for (int j = 0; j < 16; ++j) {
             int q = 0;
             if (cg * 16 + j < C) {
-                const float tv = __fmul_rn(src[(size_t)j * HW], mult);
-                // `int16_t src = float` on x86-64/gcc: cvttss2si (0x80000000 when out of range
-                // or NaN) then keep the low 16 bits
-                int i32 = (fabsf(tv) < 2147483648.f) ? (int)tv : INT_MIN;
-                int s = (int)(short)(i32 & 0xFFFF);
-                // max_abs(src, 127)
-                q = (abs(s) > 127) ? ((s > 0) ? 127 : -127) : s;
+                q = quantize_input_i8(src[(size_t)j * HW], mult);
             }
             w[j >> 2] |= ((unsigned)(q & 0xFF)) << ((j & 3) * 8);
         }
@@ -97,6 +91,9 @@ struct ConvI8Dev {
     float *out_add;
     float *out;
     int32_t *dbg;
+    int8_t *q_out;          // quantised side output for the next INT8 conv (nullptr = none)
+    float q_mult;
+    int q_G;
     int B, G, Gshift, H, W, M, Mpad, OH, OW;
     int size, stride, pad, act;
     int K16, K16pad;
@@ -343,7 +340,7 @@ __global__ __launch_bounds__(NT) void conv_i8_mfma_kernel(ConvI8Dev p)
         }
     }
     __syncthreads();      // bias_s and the panel buffers are dead from here: reuse as strips
-    float *strip = reinterpret_cast<float *>(smem) + wave * (8 * TN * 32);
+    float *strip = reinterpret_cast<float *>(smem) + wave * (16 * TN * 32);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         float vals[TN][16];
@@ -359,8 +356,12 @@ __global__ __launch_bounds__(NT) void conv_i8_mfma_kernel(ConvI8Dev p)
                 if (p.act == YL_LEAKY) y = (y > 0.f) ? y : div10_exact(y);
                 vals[j][e] = y;
             }
-        store_rows_via_lds<TN>(strip, vals, m0 + wm0 + i * 32, p.M, n0 + wn0, p.Ntotal, p.OHW,
-                               p.out, p.add, p.out_add, lane);
+        if (p.q_out)
+            store_rows_via_lds_q<TN>(strip, vals, m0 + wm0 + i * 32, p.M, n0 + wn0, p.Ntotal, p.OHW,
+                                     p.out, p.add, p.out_add, p.q_out, p.q_mult, p.q_G, lane);
+        else
+            store_rows_via_lds<TN>(strip, vals, m0 + wm0 + i * 32, p.M, n0 + wn0, p.Ntotal, p.OHW,
+                                   p.out, p.add, p.out_add, lane);
     }
 }
 
@@ -383,6 +384,7 @@ int launch_conv_i8(const ConvI8Args &a, void *stream)
     ConvI8Dev d;
     d.in_q = a.in_q; d.w_q = a.w_q; d.bias = a.bias; d.out = a.out; d.dbg = a.dbg;
     d.add = a.add; d.out_add = a.out_add;
+    d.q_out = a.q_out; d.q_mult = a.q_mult; d.q_G = a.q_G;
     d.B = a.B; d.G = a.Cpad / 16; d.H = a.H; d.W = a.W; d.M = a.M; d.Mpad = a.Mpad; d.OH = a.OH; d.OW = a.OW;
     d.size = a.size; d.stride = a.stride; d.pad = a.pad; d.act = a.act; d.alpha1 = a.alpha1;
     if (d.G <= 0 || (d.G & (d.G - 1)) != 0 || a.size > 5) return (int)hipErrorInvalidValue;

@@ -40,6 +40,9 @@ struct ConvI8Args {
     int32_t *dbg;         // optional int16-clamped accumulators [B][M][OH][OW]
     const float *add;     // optional fused [shortcut] (see ConvF32Args)
     float *out_add;
+    int8_t *q_out;        // optional quantised side output for the next INT8 conv: act_q[B][q_G][OH][OW][16]
+    float q_mult;         // the next layer's input_quant_multipler
+    int q_G;              // the next layer's channel groups (Cpad/16)
     int B, Cpad, H, W, M, Mpad, OH, OW;
     int size, stride, pad;
     int act;

@@ -202,7 +202,9 @@ static int to_device(Network &net, int device)
             l.host_output = l.host_output_own.data();
         }
     }
-    if (net.qbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_qbuf, net.qbuf_bytes));
+    // three quantised-activation buffers used round-robin (layer j reads ring[j % 3]): a producer
+    // one or two layers earlier can write layer j's input while reading its own
+    if (net.qbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_qbuf, 3 * net.qbuf_bytes));
     if (net.bitbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_bitbuf, net.bitbuf_bytes));
     // ---- optional conv+shortcut fusion plan ----
     for (Layer &l : net.layers) { l.fused_shortcut = -1; l.fused_into_conv = false; }
@@ -225,6 +227,40 @@ static int to_device(Network &net, int device)
             if (referenced) continue;
             cv.fused_shortcut = i;
             sc.fused_into_conv = true;
+        }
+    }
+    // ---- optional quantise-on-store plan (INT8): the producer of an INT8 conv's input emits the
+    //      int8 NC/16HW16 tensor from its own epilogue; its FP32 tensor is skipped if nobody reads it
+    for (Layer &l : net.layers) { l.q_from_producer = false; l.q_out_layer = -1; l.skip_f32_out = false; }
+    if (net.fuse && !net.debug) {
+        const int nl = (int)net.layers.size();
+        auto referenced_elsewhere = [&](int t, int consumer) {
+            // is tensor of layer t read by anything except `consumer` taking it as its running input?
+            if (t == nl - 1) return true;
+            for (int j = t + 1; j < nl; ++j) {
+                const Layer &o = net.layers[j];
+                if (j == t + 1 && j != consumer && !(o.type == YL_ROUTE)) return true;      // running input of t+1
+                if (o.type == YL_SHORTCUT && o.index == t) return true;
+                if (o.type == YL_ROUTE) for (int id : o.input_layers) if (id == t) return true;
+                if ((o.type == YL_YOLO || o.type == YL_REGION) && j == t + 1) return true;
+            }
+            return false;
+        };
+        for (int j = 1; j < nl; ++j) {
+            Layer &cons = net.layers[j];
+            if (cons.type != YL_CONVOLUTIONAL || cons.conv_mode != CONV_INT8) continue;
+            // the tensor layer j consumes is the output of layer j-1
+            int prod = j - 1;                                  // layer whose kernel writes that tensor
+            const Layer &in_l = net.layers[j - 1];
+            if (in_l.type == YL_SHORTCUT && in_l.fused_into_conv) prod = j - 2;
+            Layer &pl = net.layers[prod];
+            if (pl.type != YL_CONVOLUTIONAL || pl.conv_mode != CONV_INT8) continue;
+            if (prod == j - 1 && pl.fused_shortcut >= 0) continue;
+            if (pl.q_out_layer >= 0) continue;
+            if ((pl.n % 16) != 0 || cons.Cpad != pl.n) continue;          // no padded channel groups
+            pl.q_out_layer = j;
+            cons.q_from_producer = true;
+            if (prod == j - 1) pl.skip_f32_out = !referenced_elsewhere(prod, j);
         }
     }
     hipEvent_t e0, e1;
@@ -263,16 +299,26 @@ static int forward_layer(Network &net, size_t i, const float *input)
             YL_LAUNCH(launch_conv_f32(a, s), "conv_f32");
             l.kernel_name = conv_f32_last_tile_name();
         } else if (l.conv_mode == CONV_INT8) {
-            YL_LAUNCH(launch_quantize_nhwc(input, net.d_qbuf, B, l.c, l.h, l.w, l.Cpad, l.input_quant_multipler, s),
-                      "quantize_nhwc");
+            int8_t *q_in = net.d_qbuf + (i % 3) * net.qbuf_bytes;
+            if (!l.q_from_producer)
+                YL_LAUNCH(launch_quantize_nhwc(input, q_in, B, l.c, l.h, l.w, l.Cpad, l.input_quant_multipler, s),
+                          "quantize_nhwc");
             ConvI8Args a;
-            a.in_q = net.d_qbuf; a.w_q = l.d_weights_i8; a.bias = l.d_biases; a.out = l.d_output; a.dbg = l.d_debug;
+            a.in_q = q_in; a.w_q = l.d_weights_i8; a.bias = l.d_biases; a.dbg = l.d_debug;
+            a.out = l.skip_f32_out ? nullptr : l.d_output;
             a.add = nullptr; a.out_add = nullptr;
+            a.q_out = nullptr; a.q_mult = 0.f; a.q_G = 0;
             if (l.fused_shortcut >= 0) {
                 Layer &sc = net.layers[l.fused_shortcut];
                 a.add = net.layers[sc.index].d_output;
-                a.out_add = sc.d_output;
+                a.out_add = sc.d_output;       // always materialised: later shortcuts / routes read it
                 a.out = nullptr;
+            }
+            if (l.q_out_layer >= 0) {
+                const Layer &nx = net.layers[l.q_out_layer];
+                a.q_out = net.d_qbuf + (l.q_out_layer % 3) * net.qbuf_bytes;
+                a.q_mult = nx.input_quant_multipler;
+                a.q_G = nx.Cpad / 16;
             }
             a.B = B; a.Cpad = l.Cpad; a.H = l.h; a.W = l.w; a.M = l.n; a.Mpad = l.Mpad; a.OH = l.out_h; a.OW = l.out_w;
             a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;

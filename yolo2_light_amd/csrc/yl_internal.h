@@ -57,6 +57,9 @@ struct Layer {
     std::string kernel_name;             // dominant kernel of this layer's last launch
     int   fused_shortcut = -1;           // conv: index of the [shortcut] layer folded into its epilogue
     bool  fused_into_conv = false;       // shortcut: produced by the preceding conv's epilogue
+    bool  q_from_producer = false;       // INT8 conv: its quantised input is written by the producing conv
+    int   q_out_layer = -1;              // INT8 conv: also emits the quantised input of this later layer
+    bool  skip_f32_out = false;          // FP32 tensor of this layer has no reader and is not written
 };
 
 struct Network {
