@@ -175,6 +175,20 @@ void oracle_conv_xnor(const float *in, const float *weights, const float *mean_a
     }
 }
 
+/* binarize_cpu  src/additionally.c:128-134 (input of an xnor conv on the FP32 fallback path,
+ * src/yolov2_forward_network.c:46-49) and binarize_weights :113-126 given the per-filter mean */
+void oracle_binarize(const float *in, float *out, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) out[i] = (in[i] > 0) ? 1 : -1;
+}
+
+void oracle_binarize_weights(const float *weights, const float *mean_arr, int n, int size, float *binary)
+{
+    for (int f = 0; f < n; ++f)
+        for (int i = 0; i < size; ++i)
+            binary[(size_t)f * size + i] = (weights[(size_t)f * size + i] > 0) ? mean_arr[f] : -mean_arr[f];
+}
+
 /* forward_maxpool_layer_avx (scalar)  src/additionally.c:1448-1482: window origin -pad/2 */
 void oracle_maxpool(const float *src, float *dst, int size, int w, int h, int out_w, int out_h, int c,
                     int pad, int stride, int batch)

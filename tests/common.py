@@ -55,6 +55,10 @@ def oracle_lib() -> C.CDLL:
     lib.oracle_reorg.argtypes = [_fp, _fp] + [i] * 5
     lib.oracle_fuse_bn.argtypes = [_fp, _fp, _fp, _fp, _fp, i, i]
     lib.oracle_binary_mean.argtypes = [_fp, i, i, _fp]
+    lib.oracle_binarize.argtypes = [_fp, _fp, C.c_size_t]
+    lib.oracle_binarize.restype = None
+    lib.oracle_binarize_weights.argtypes = [_fp, _fp, i, i, _fp]
+    lib.oracle_binarize_weights.restype = None
     lib.oracle_quantize_weights.argtypes = [_fp, C.c_size_t, _i8p]
     lib.oracle_quantize_weights.restype = C.c_float
     for name in ("oracle_conv_f32", "oracle_conv_int8", "oracle_conv_xnor", "oracle_maxpool", "oracle_shortcut",
@@ -102,6 +106,15 @@ def seeded_input(batch: int, c: int, h: int, w: int, seed: int = 2222222) -> np.
     return rng.random((batch, c, h, w), dtype=np.float32)
 
 
+def xnor_fallback_operands(olib, x, weights, mean_arr, li):
+    """(binarised input, binarised weights) of an xnor conv that is NOT on the bit path."""
+    xb = np.empty_like(x)
+    olib.oracle_binarize(fp(x), fp(xb), x.size)
+    wb = np.empty_like(weights)
+    olib.oracle_binarize_weights(fp(weights), fp(mean_arr), li["n"], li["c"] * li["size"] ** 2, fp(wb))
+    return xb, wb
+
+
 # ---------------------------------------------------------------------------
 # oracle network walker
 # ---------------------------------------------------------------------------
@@ -139,7 +152,10 @@ class OracleNet:
                 bias = net.layer_biases(i)
                 mode = li["conv_mode"]
                 if mode == CONV_F32:
-                    o.oracle_conv_f32(fp(cur), fp(wts), fp(bias), fp(out), B, li["c"], li["h"], li["w"], li["n"],
+                    src = cur
+                    if li["xnor"]:      # FP32 fallback of an xnor conv: +-mean weights, +-1 input, zero padding
+                        src, wts = xnor_fallback_operands(o, cur, wts, net.layer_mean_arr(i), li)
+                    o.oracle_conv_f32(fp(src), fp(wts), fp(bias), fp(out), B, li["c"], li["h"], li["w"], li["n"],
                                       li["size"], li["stride"], li["pad"], li["activation"])
                 elif mode == CONV_INT8:
                     wq = net.layer_weights_int8(i)

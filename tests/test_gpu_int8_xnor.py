@@ -132,6 +132,8 @@ def _teacher_forced(olib, name, width, height, batch, quantized):
         if t == common.CONV:
             w_ = net.layer_weights(i); b_ = net.layer_biases(i)
             if li["conv_mode"] == common.CONV_F32:
+                if li["xnor"]:
+                    cur, w_ = common.xnor_fallback_operands(olib, cur, w_, net.layer_mean_arr(i), li)
                 olib.oracle_conv_f32(fp(cur), fp(w_), fp(b_), fp(ref), B, li["c"], li["h"], li["w"], li["n"],
                                      li["size"], li["stride"], li["pad"], li["activation"])
                 exact = False
@@ -165,6 +167,8 @@ def _teacher_forced(olib, name, width, height, batch, quantized):
         elif t == common.REGION:
             olib.oracle_region(fp(cur), fp(ref), B, li["n"], li["classes"], li["coords"], li["w"] * li["h"], li["softmax"])
             exact = False
+        elif t == common.REORG:
+            olib.oracle_reorg(fp(cur), fp(ref), B, li["out_c"], li["out_h"], li["out_w"], li["stride"])
         else:
             raise AssertionError("unexpected layer type %d" % t)
         got = outs[i]
@@ -245,3 +249,89 @@ def test_int8_fusion_is_bit_identical():
         assert np.array_equal(plain.get_boxes(b, width, height, 0.24, nms=0.4),
                               fused.get_boxes(b, width, height, 0.24, nms=0.4))
     plain.close(); fused.close()
+
+
+@pytest.mark.parametrize("name,width,height,batch,quantized", [
+    ("yolov2-voc", 96, 96, 2, 0), ("yolov2-voc", 160, 160, 1, 1), ("tiny-yolo-voc", 96, 64, 2, 0),
+    ("yolov3-spp", 64, 64, 2, 0), ("yolov3-spp", 96, 96, 1, 1),
+])
+def test_network_teacher_forced_other_cfgs(olib, name, width, height, batch, quantized):
+    """The remaining cfgs of the reference's bin/: reorg, region+softmax, SPP max-pools."""
+    stats = _teacher_forced(olib, name, width, height, batch, quantized)
+    assert stats["exact"] > 0
+
+
+XNOR_MIXED_CFG = """[net]
+batch=1
+subdivisions=1
+width=%d
+height=%d
+channels=3
+[convolutional]
+batch_normalize=1
+filters=32
+size=3
+stride=1
+pad=1
+activation=leaky
+[convolutional]
+xnor=1
+batch_normalize=1
+filters=64
+size=3
+stride=2
+pad=1
+activation=leaky
+[convolutional]
+xnor=1
+batch_normalize=1
+filters=32
+size=1
+stride=1
+pad=1
+activation=leaky
+[convolutional]
+xnor=1
+batch_normalize=1
+filters=64
+size=3
+stride=1
+pad=1
+activation=leaky
+[shortcut]
+from=-3
+activation=linear
+[convolutional]
+size=1
+stride=1
+pad=1
+filters=33
+activation=linear
+[region]
+anchors = 1,1, 2,2, 3,3
+classes=6
+coords=4
+num=3
+softmax=1
+"""
+
+
+def _mixed_xnor_files(width, height):
+    import os
+    from yolo2_light_amd import weights as W
+    text = XNOR_MIXED_CFG % (width, height)
+    cfg = os.path.join(common.workdir(), "xnor-mixed-%dx%d.cfg" % (width, height))
+    open(cfg, "w").write(text)
+    wts = cfg[:-4] + ".weights"
+    W.write_synthetic_weights(text, wts, seed=3)
+    return cfg, wts
+
+
+def test_xnor_fallback_layers_teacher_forced(olib):
+    """xnor convs that are NOT 3x3/stride-1 (here 3x3/2 and 1x1) take the reference's FP32
+    fallback on binarised operands; the 3x3/1 one takes the bit path; then a shortcut."""
+    width, height, batch = 64, 48, 2
+    cfg, wts = _mixed_xnor_files(width, height)
+    common._MODEL_CACHE[("xnor-mixed", width, height, 1)] = (cfg, wts)
+    stats = _teacher_forced(olib, "xnor-mixed", width, height, batch, 0)
+    assert stats["exact"] >= 2

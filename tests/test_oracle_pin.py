@@ -61,3 +61,31 @@ def test_maxpool_op_pin(olib):
         rl = refbind._bind(refbind.GOLD)
         rl.ref_maxpool(common.fp(x), common.fp(r), size, w, h, ow, oh, c, pad, stride, b)
         assert np.array_equal(a, r), (size, stride)
+
+
+MORE_CASES = [
+    ("yolov2-voc", 96, 96, 2, 0),          # reorg + region (softmax) + multi-input route
+    ("yolov2-voc", 96, 96, 1, 1),
+    ("tiny-yolo-voc", 96, 64, 2, 0),
+    ("yolov3-spp", 64, 64, 1, 0),          # stride-1 max-pools 5/9/13
+]
+
+
+@pytest.mark.parametrize("name,width,height,batch,quantized", MORE_CASES)
+def test_oracle_matches_reference_other_cfgs(olib, name, width, height, batch, quantized):
+    test_oracle_matches_reference_every_layer(olib, name, width, height, batch, quantized)
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_oracle_matches_reference_xnor_fallback(olib, batch):
+    """custom cfg mixing xnor bit-path and FP32-fallback convs (stride 2, 1x1) + shortcut"""
+    import os
+    from yolo2_light_amd import weights as W
+    sys_path_cfg = os.path.join(common.workdir(), "xnor-mixed-pin.cfg")
+    import test_gpu_int8_xnor as T
+    text = T.XNOR_MIXED_CFG % (64, 48)
+    open(sys_path_cfg, "w").write(text)
+    wts = sys_path_cfg[:-4] + ".weights"
+    W.write_synthetic_weights(text, wts, seed=3)
+    common._MODEL_CACHE[("xnor-mixed-pin", 64, 48, 1)] = (sys_path_cfg, wts)
+    test_oracle_matches_reference_every_layer(olib, "xnor-mixed-pin", 64, 48, batch, 0)

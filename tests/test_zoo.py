@@ -10,7 +10,9 @@ from common import refbind
 from yolo2_light_amd import zoo
 
 REF_BIN = "/root/reference/bin"
-PAIRS = [("yolov3-tiny", "yolov3-tiny.cfg", 416), ("yolov3", "yolov3.cfg", 416), ("tiny-yolo-xnor", "tiny-yolo-obj_xnor.cfg", 416)]
+PAIRS = [("yolov3-tiny", "yolov3-tiny.cfg", 416), ("yolov3", "yolov3.cfg", 416), ("tiny-yolo-xnor", "tiny-yolo-obj_xnor.cfg", 416),
+         ("yolov3-spp", "yolov3-spp.cfg", 608), ("yolov3-openimages", "yolov3-openimages.cfg", 608),
+         ("yolov2-voc", "yolov2-voc.cfg", 416), ("tiny-yolo-voc", "tiny-yolo-voc.cfg", 416)]
 
 
 @pytest.mark.skipif(not (os.path.isdir(REF_BIN) and refbind.available()), reason="reference tree not present")

@@ -76,6 +76,8 @@ int launch_upsample(const float *in, float *out, int B, int C, int H, int W, int
 int launch_copy_rows(const float *src, float *dst, int rows, int row_elems, size_t src_stride, size_t dst_stride, void *stream);
 int launch_yolo(const float *in, float *out, int B, int n, int classes, int wh, void *stream);
 int launch_region(const float *in, float *out, int B, int n, int classes, int coords, int wh, int softmax, void *stream);
+// x -> (x > 0 ? 1 : -1)   binarize_cpu, src/additionally.c:128-134
+int launch_binarize(const float *in, float *out, size_t n, void *stream);
 int launch_reorg(const float *in, float *out, int B, int out_c, int out_h, int out_w, int stride, void *stream);
 
 // ---- K10: detection compaction ----

@@ -288,6 +288,19 @@ int launch_reorg(const float *in, float *out, int B, int out_c, int out_h, int o
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------- binarize (xnor FP32 fallback)
+__global__ __launch_bounds__(256) void binarize_kernel(const float *__restrict__ in, float *__restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (in[i] > 0.f) ? 1.f : -1.f;
+}
+
+int launch_binarize(const float *in, float *out, size_t n, void *stream)
+{
+    hipLaunchKernelGGL(binarize_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, in, out, n);
+    return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------- K10: detection compaction
 struct HeadsDev {
     HeadDesc h[4];

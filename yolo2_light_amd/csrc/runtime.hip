@@ -62,6 +62,8 @@ static void free_device(Network &net)
     if (net.d_input) (void)hipFree(net.d_input);
     if (net.d_qbuf) (void)hipFree(net.d_qbuf);
     if (net.d_bitbuf) (void)hipFree(net.d_bitbuf);
+    if (net.d_binbuf) (void)hipFree(net.d_binbuf);
+    net.d_binbuf = nullptr;
     if (net.h_pinned) (void)hipHostFree(net.h_pinned);
     net.d_input = nullptr; net.d_qbuf = nullptr; net.d_bitbuf = nullptr; net.h_pinned = nullptr;
     for (void *e : net.layer_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
@@ -82,10 +84,15 @@ static int upload_conv(Network &net, Layer &l)
     YL_HIP(hipMalloc((void **)&l.d_biases, sizeof(float) * M));
     YL_HIP(hipMemcpy(l.d_biases, l.biases.data(), sizeof(float) * M, hipMemcpyHostToDevice));
     if (l.conv_mode == CONV_F32) {
-        if (l.xnor) {
-            set_error("xnor conv outside the 3x3/stride-1/pad-1 bit path (FP32 fallback on +-mean weights, "
-                      "src/yolov2_forward_network.c:40-50) is a next-tier row (SURVEY 8f-4)");
-            return YL_ERR_UNSUPPORTED;
+        // xnor conv outside the 3x3/stride-1/pad-1 bit path: the reference falls back to the FP32
+        // GEMM on binarised operands (src/yolov2_forward_network.c:40-50,204-211): weights +-mean
+        // (binarize_weights, src/additionally.c:113-126), input +-1 (binarize_cpu :128-134), ZERO padding.
+        const bool xnor_fallback = l.xnor != 0;
+        if (xnor_fallback && !l.xnor_ready) { set_error("XNOR layer without yl_network_calculate_binary_weights()"); return YL_ERR_STATE; }
+        l.binarize_input = xnor_fallback;
+        if (xnor_fallback) {
+            const size_t bb = (size_t)net.batch * l.c * l.h * l.w * sizeof(float);
+            if (bb > net.binbuf_bytes) net.binbuf_bytes = bb;
         }
         // k-major panel layout [Kpad][Mpad], zero padded
         // K order: (c,ky,kx) like im2col_cpu, or -- for the pipelined kernel when C % 16 == 0 --
@@ -101,7 +108,9 @@ static int upload_conv(Network &net, Layer &l)
                     const int k_ref = c * taps + t;
                     // tap-major inside 16-channel blocks: k = ((c/16)*taps + t)*16 + c%16
                     const int k_dev = l.tapmajor ? (((c / 16) * taps + t) * 16 + (c % 16)) : k_ref;
-                    wt[(size_t)k_dev * l.Mpad + m] = l.weights[(size_t)m * K + k_ref];
+                    float wv = l.weights[(size_t)m * K + k_ref];
+                    if (xnor_fallback) wv = (wv > 0.f) ? l.mean_arr[m] : -l.mean_arr[m];
+                    wt[(size_t)k_dev * l.Mpad + m] = wv;
                 }
         YL_HIP(hipMalloc((void **)&l.d_weights_t, wt.size() * sizeof(float)));
         YL_HIP(hipMemcpy(l.d_weights_t, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -176,7 +185,7 @@ static int to_device(Network &net, int device)
         net.stream = s; net.own_stream = true;
     }
     select_conv_modes(net);
-    net.qbuf_bytes = 0; net.bitbuf_bytes = 0;
+    net.qbuf_bytes = 0; net.bitbuf_bytes = 0; net.binbuf_bytes = 0;
     const size_t in_elems = (size_t)net.batch * net.c * net.h * net.w;
     YL_HIP(hipMalloc((void **)&net.d_input, in_elems * sizeof(float)));
     net.pinned_bytes = in_elems * sizeof(float);
@@ -206,6 +215,7 @@ static int to_device(Network &net, int device)
     // one or two layers earlier can write layer j's input while reading its own
     if (net.qbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_qbuf, 3 * net.qbuf_bytes));
     if (net.bitbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_bitbuf, net.bitbuf_bytes));
+    if (net.binbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_binbuf, net.binbuf_bytes));
     // ---- optional conv+shortcut fusion plan ----
     for (Layer &l : net.layers) { l.fused_shortcut = -1; l.fused_into_conv = false; }
     if (net.fuse && !net.debug) {
@@ -281,7 +291,12 @@ static int forward_layer(Network &net, size_t i, const float *input)
     case YL_CONVOLUTIONAL: {
         if (l.conv_mode == CONV_F32) {
             ConvF32Args a;
-            a.in = input; a.wt = l.d_weights_t; a.bias = l.d_biases; a.add = nullptr; a.out_add = nullptr;
+            const float *conv_in = input;
+            if (l.binarize_input) {
+                YL_LAUNCH(launch_binarize(input, net.d_binbuf, (size_t)B * l.c * l.h * l.w, s), "binarize");
+                conv_in = net.d_binbuf;
+            }
+            a.in = conv_in; a.wt = l.d_weights_t; a.bias = l.d_biases; a.add = nullptr; a.out_add = nullptr;
             a.out = l.d_output;
             if (l.fused_shortcut >= 0) {
                 // conv + [shortcut] in one pass (the reference GPU path fuses the same pair for XNOR

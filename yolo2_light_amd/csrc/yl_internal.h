@@ -59,6 +59,7 @@ struct Layer {
     bool  fused_into_conv = false;       // shortcut: produced by the preceding conv's epilogue
     bool  q_from_producer = false;       // INT8 conv: its quantised input is written by the producing conv
     int   q_out_layer = -1;              // INT8 conv: also emits the quantised input of this later layer
+    bool  binarize_input = false;        // xnor FP32 fallback: input -> +-1 before the conv
     bool  skip_f32_out = false;          // FP32 tensor of this layer has no reader and is not written
 };
 
@@ -81,6 +82,8 @@ struct Network {
     size_t qbuf_bytes = 0;
     uint64_t *d_bitbuf = nullptr;        // XNOR: channel-packed sign bits scratch
     size_t bitbuf_bytes = 0;
+    float *d_binbuf = nullptr;           // XNOR FP32 fallback: +-1 image scratch
+    size_t binbuf_bytes = 0;
     void *h_pinned = nullptr;            // pinned staging for the input
     size_t pinned_bytes = 0;
     void *ev0 = nullptr, *ev1 = nullptr; // hipEvent_t pair for profiling

@@ -22,6 +22,12 @@ _V3_CALIB = [15.497, 12.537] + [40] * 74
 _TINY_CALIB = [15.7342, 4.41852, 9.17237, 9.70713, 13.1849, 14.9823, 15.1913,
                8.62978, 15.7353, 15.6297, 15.6939, 15.4093, 15.8055, 16]
 
+_V2_VOC_CALIB = [15.8025, 11.6111, 10.9857, 14.9883, 11.6514, 14.9023, 15.4301, 13.8702, 15.3739, 15.584, 15.3044,
+                 15.4963, 15.4139, 15.398, 15.7311, 15.2932, 15.7355, 15.2879, 5.79389, 15.6349, 15.5533, 15.453,
+                 15.7935, 16]
+_TINY_VOC_CALIB = [127, 3.88677, 10.5828, 10.3276, 14.3403, 15.2774, 15.2242, 8.08196, 15.7327, 16]
+_V2_VOC_ANCHORS = "1.3221, 1.73145, 3.19275, 4.00944, 5.05587, 8.09892, 9.47112, 4.84053, 11.2364, 10.0071"
+_TINY_VOC_ANCHORS = "1.08,1.19,  3.42,4.41,  6.63,11.38,  9.42,5.11,  16.62,10.52"
 _V3_ANCHORS = "10,13,  16,30,  33,23,  30,61,  62,45,  59,119,  116,90,  156,198,  373,326"
 _TINY_ANCHORS = "10,14,  23,27,  37,58,  81,82,  135,169,  344,319"
 _XNOR_ANCHORS = "5.2367,6.0570, 8.2272,9.1483, 12.4093,10.7904, 9.7655,14.6023, 16.6749,16.0784"
@@ -65,8 +71,9 @@ def _net(c: _Cfg, width: int, height: int, calib=None) -> None:
     c.section("net", **kv)
 
 
-def yolov3_cfg(width: int = 608, height: int = 608, classes: int = 80) -> str:
-    """Darknet-53 backbone + 3 YOLO heads == bin/yolov3.cfg with width/height edited."""
+def yolov3_cfg(width: int = 608, height: int = 608, classes: int = 80, spp: bool = False) -> str:
+    """Darknet-53 backbone + 3 YOLO heads == bin/yolov3.cfg with width/height edited;
+    spp=True inserts the 5/9/13 stride-1 max-pool pyramid of bin/yolov3-spp.cfg into the first head."""
     c = _Cfg()
     _net(c, width, height, _V3_CALIB)
     head_filters = 3 * (classes + 5)
@@ -82,15 +89,23 @@ def yolov3_cfg(width: int = 608, height: int = 608, classes: int = 80) -> str:
         c.conv(ch, 3, stride=2)
         residual(ch, n)
 
-    def head(ch: int, mask: str) -> None:
-        for _ in range(3):
+    def head(ch: int, mask: str, with_spp: bool = False) -> None:
+        for k in range(3):
             c.conv(ch, 1)
+            if with_spp and k == 1:
+                c.section("maxpool", stride=1, size=5)
+                c.section("route", layers="-2")
+                c.section("maxpool", stride=1, size=9)
+                c.section("route", layers="-4")
+                c.section("maxpool", stride=1, size=13)
+                c.section("route", layers="-1,-3,-5,-6")
+                c.conv(ch, 1)
             c.conv(ch * 2, 3)
         c.conv(head_filters, 1, bn=False, act="linear")
         c.section("yolo", mask=mask, anchors=_V3_ANCHORS, classes=classes, num=9,
                   jitter=.3, ignore_thresh=.7, truth_thresh=1, random=1)
 
-    head(512, "6,7,8")
+    head(512, "6,7,8", with_spp=spp)
     c.section("route", layers="-4")
     c.conv(256, 1)
     c.section("upsample", stride=2)
@@ -147,7 +162,56 @@ def tiny_yolo_xnor_cfg(width: int = 416, height: int = 416, classes: int = 6) ->
     return c.text()
 
 
+def yolov2_voc_cfg(width: int = 416, height: int = 416, classes: int = 20) -> str:
+    """== bin/yolov2-voc.cfg (Darknet-19 trunk, passthrough reorg, region head)."""
+    c = _Cfg()
+    _net(c, width, height, _V2_VOC_CALIB)
+    c.conv(32, 3)
+    c.section("maxpool", size=2, stride=2)
+    c.conv(64, 3)
+    c.section("maxpool", size=2, stride=2)
+    for ch in (128, 256):
+        c.conv(ch, 3); c.conv(ch // 2, 1); c.conv(ch, 3)
+        c.section("maxpool", size=2, stride=2)
+    for ch in (512, 1024):
+        c.conv(ch, 3); c.conv(ch // 2, 1); c.conv(ch, 3); c.conv(ch // 2, 1); c.conv(ch, 3)
+        if ch == 512:
+            c.section("maxpool", size=2, stride=2)
+    c.conv(1024, 3)
+    c.conv(1024, 3)
+    c.section("route", layers="-9")
+    c.conv(64, 1)
+    c.section("reorg", stride=2)
+    c.section("route", layers="-1,-4")
+    c.conv(1024, 3)
+    c.conv(5 * (classes + 5), 1, bn=False, act="linear")
+    c.section("region", anchors=_V2_VOC_ANCHORS, bias_match=1, classes=classes, coords=4, num=5, softmax=1,
+              jitter=.3, rescore=1, object_scale=5, noobject_scale=1, class_scale=1, coord_scale=1,
+              absolute=1, thresh=.6, random=1)
+    return c.text()
+
+
+def tiny_yolo_voc_cfg(width: int = 416, height: int = 416, classes: int = 20) -> str:
+    """== bin/tiny-yolo-voc.cfg."""
+    c = _Cfg()
+    _net(c, width, height, _TINY_VOC_CALIB)
+    for i, ch in enumerate((16, 32, 64, 128, 256, 512)):
+        c.conv(ch, 3)
+        c.section("maxpool", size=2, stride=2 if i < 5 else 1)
+    c.conv(1024, 3)
+    c.conv(1024, 3)
+    c.conv(5 * (classes + 5), 1, bn=False, act="linear")
+    c.section("region", anchors=_TINY_VOC_ANCHORS, bias_match=1, classes=classes, coords=4, num=5, softmax=1,
+              jitter=.2, rescore=1, object_scale=5, noobject_scale=1, class_scale=1, coord_scale=1,
+              absolute=1, thresh=.6, random=1)
+    return c.text()
+
+
 MODELS = {
+    "yolov3-spp": lambda w=608, h=608, **kw: yolov3_cfg(w, h, spp=True, **kw),
+    "yolov3-openimages": lambda w=608, h=608, **kw: yolov3_cfg(w, h, classes=601, **kw),
+    "yolov2-voc": yolov2_voc_cfg,
+    "tiny-yolo-voc": tiny_yolo_voc_cfg,
     "yolov3": yolov3_cfg,
     "yolov3-tiny": yolov3_tiny_cfg,
     "tiny-yolo-xnor": tiny_yolo_xnor_cfg,
