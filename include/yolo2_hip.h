@@ -244,11 +244,56 @@ const char *yl_debug_last_conv_tile(void);
  * `objectness > thresh` (src/additionally.c:4341) and box decode
  * (get_yolo_box :4317 / get_region_box_cpu src/yolov2_forward_network.c:653)
  * executed on the GPU into a fixed-capacity record buffer that an RCCL gather
- * can ship: records_dev[batch][cap][6+classes] floats (same row layout as
- * yl_network_get_boxes, boxes relative to the network input, no NMS) and
+ * can ship: records_dev[batch][cap][6+classes] floats (row layout of
+ * yl_network_get_boxes except column 5, which holds the record's position in the
+ * reference's scan order; rows are in arbitrary order; boxes relative to the network
+ * input, no NMS) and
  * counts_dev[batch] ints.  Asynchronous on the network's stream. */
 int yl_network_compact_detections(yl_network *net, float thresh, int cap,
                                   float *records_dev, int *counts_dev);
+
+/* Batched detections on the GPU (new).  For EVERY image b of the batch:
+ *   get_network_boxes(&net, img_w[b], img_h[b], thresh, hier, 0, relative, &num, letter)
+ *                                                       src/additionally.c:4403
+ *   do_nms_sort(dets, num, classes, nms)                src/box.c:296-328
+ * (the reference does both on the host and for batch item 0 only, src/additionally.c:4213,4338).
+ * records_dev[batch][cap][6+classes] floats, row = x y w h objectness sort_class prob[classes];
+ * counts_dev[batch] = number of detections of image b (rows beyond min(count, cap) are not
+ * written).  While count <= cap the rows of image b are bit-identical, order included, to what
+ * yl_network_get_boxes(net, b, ...) -- i.e. the reference -- returns: correct_yolo_boxes
+ * (src/additionally.c:4281) and the class-by-class stable sort + greedy suppression are
+ * replayed exactly (yolo2_light_amd/csrc/detect.hip); nms <= 0 skips the suppression.
+ * img_w/img_h: host int[batch] with the source image sizes, or both NULL when relative=1 and
+ * letter=0 (boxes relative to the network input).  cap <= YL_DETECT_MAX_CAP.
+ * Asynchronous on the network's stream; reads the head outputs of the last forward. */
+#define YL_DETECT_MAX_CAP 2048
+int yl_network_detect_batch(yl_network *net, const int *img_w, const int *img_h, float thresh,
+                            int relative, int letter, float nms, int cap,
+                            float *records_dev, int *counts_dev);
+/* the same, delivered to host buffers rows_host[batch][cap][6+classes], counts_host[batch]
+ * (synchronous; only the filled rows are copied) */
+int yl_network_get_boxes_batch(yl_network *net, const int *img_w, const int *img_h, float thresh,
+                               int relative, int letter, float nms, int cap,
+                               float *rows_host, int *counts_host);
+
+/* ------------------------------------------------------------------ *
+ *  Image front end on the GPU (new).
+ * ------------------------------------------------------------------ */
+
+/* What test_detector_cpu does per image on one host core (src/main.c:187-189):
+ *   load_image_stb's  im[k][y][x] = (float)u8[(y*w+x)*c+k] / 255.     src/additionally.c:3095-3103
+ *   resize_image(im, net.w, net.h)   two-pass bilinear stretch         src/additionally.c:3021-3064
+ * fused into one kernel that writes batch slot `image` of the network input buffer
+ * (yl_network_input_dev) -- bit-identical to the reference's `sized.data`.  `pixels` is the
+ * decoder's output: HWC, 8 bits per channel, c == net.c.  The host variant stages through
+ * pinned memory (3 bytes per source pixel over PCIe instead of 12 per network pixel) and is
+ * asynchronous on the network's stream; `pixels_host` may be reused as soon as it returns.
+ * Follow with yl_network_forward(net, yl_network_input_dev(net)). */
+int yl_network_set_input_u8(yl_network *net, int image, const uint8_t *pixels_host, int w, int h, int c);
+int yl_network_set_input_u8_dev(yl_network *net, int image, const uint8_t *pixels_dev, int w, int h, int c);
+/* copy of the device input buffer, float[batch*c*h*w] (synchronous; what `sized.data` /
+ * the X argument of network_predict would hold, src/main.c:189,193) */
+int yl_network_input_download(yl_network *net, float *dst_host);
 
 #ifdef __cplusplus
 }

@@ -181,6 +181,26 @@ void ref_maxpool(float *src, float *dst, int size, int w, int h, int out_w, int 
     free(idx);
 }
 
+/* the reference's image front end exactly as test_detector_cpu drives it (src/main.c:187-189):
+ * load_image(path, 0, 0, 3) [stb decode + HWC u8 -> CHW float /255., src/additionally.c:3068-3106]
+ * then resize_image(im, w, h) [src/additionally.c:3021-3064].  out = float[3*h*w].
+ * returns 0, or -1 if the file could not be decoded (the reference would exit(0)). */
+int ref_load_resized(const char *path, int w, int h, float *out, int *src_w, int *src_h)
+{
+    FILE *f = fopen(path, "rb");
+    image im, sized;
+    if (!f) return -1;
+    fclose(f);
+    im = load_image((char *)path, 0, 0, 3);
+    if (src_w) *src_w = im.w;
+    if (src_h) *src_h = im.h;
+    sized = resize_image(im, w, h);
+    memcpy(out, sized.data, sizeof(float) * 3 * (size_t)w * h);
+    free_image(im);
+    free_image(sized);
+    return 0;
+}
+
 #ifdef WITH_HIP_ADAPTOR
 /* the drop-in under test: the reference's host code + integration/network_predict_hip.c
  * (the binding a maintainer would add) driving libyolo2hip.so */

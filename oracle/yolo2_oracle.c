@@ -310,6 +310,51 @@ void oracle_reorg(const float *x, float *out, int batch, int out_c, int out_h, i
                 }
 }
 
+/* Image front end of test_detector_cpu (src/main.c:187-189):
+ *   load_image_stb's conversion  src/additionally.c:3095-3103   im[k][j][i] = (float)u8[(j*w+i)*c+k] / 255.
+ *   resize_image                 src/additionally.c:3021-3064   two-pass bilinear stretch: rows first
+ *     into `part` (w x im.h), then columns; the last column/row copy the edge sample, and the
+ *     vertical pass adds its second tap as a separate rounded product.
+ * pix = HWC u8 [sh][sw][sc]; out = CHW float [sc][h][w]. */
+void oracle_load_resized_u8(const unsigned char *pix, int sw, int sh, int sc, int w, int h, float *out)
+{
+    float *im = (float *)malloc(sizeof(float) * (size_t)sw * sh * sc);
+    float *part = (float *)malloc(sizeof(float) * (size_t)w * sh * sc);
+    for (int k = 0; k < sc; ++k)
+        for (int j = 0; j < sh; ++j)
+            for (int i = 0; i < sw; ++i)
+                im[i + sw * j + (size_t)sw * sh * k] = (float)pix[k + sc * i + (size_t)sc * sw * j] / 255.;
+    const float w_scale = (float)(sw - 1) / (w - 1);
+    const float h_scale = (float)(sh - 1) / (h - 1);
+    for (int k = 0; k < sc; ++k)
+        for (int r = 0; r < sh; ++r)
+            for (int c = 0; c < w; ++c) {
+                const float *row = im + (size_t)k * sh * sw + (size_t)r * sw;
+                float val;
+                if (c == w - 1 || sw == 1) val = row[sw - 1];
+                else {
+                    const float sx = c * w_scale;
+                    const int ix = (int)sx;
+                    const float dx = sx - ix;
+                    val = (1 - dx) * row[ix] + dx * row[ix + 1];
+                }
+                part[(size_t)k * sh * w + (size_t)r * w + c] = val;
+            }
+    for (int k = 0; k < sc; ++k)
+        for (int r = 0; r < h; ++r) {
+            const float sy = r * h_scale;
+            const int iy = (int)sy;
+            const float dy = sy - iy;
+            float *dst = out + (size_t)k * h * w + (size_t)r * w;
+            const float *p0 = part + (size_t)k * sh * w + (size_t)iy * w;
+            for (int c = 0; c < w; ++c) dst[c] = (1 - dy) * p0[c];
+            if (r == h - 1 || sh == 1) continue;
+            for (int c = 0; c < w; ++c) dst[c] += dy * p0[w + c];
+        }
+    free(im);
+    free(part);
+}
+
 /* yolov2_fuse_conv_batchnorm  src/additionally.c:67-109 (epsilon outside the sqrt) */
 void oracle_fuse_bn(float *weights, float *biases, const float *scales, const float *mean, const float *var,
                     int n, int filter_size)

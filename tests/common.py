@@ -61,6 +61,8 @@ def oracle_lib() -> C.CDLL:
     lib.oracle_binarize_weights.restype = None
     lib.oracle_quantize_weights.argtypes = [_fp, C.c_size_t, _i8p]
     lib.oracle_quantize_weights.restype = C.c_float
+    lib.oracle_load_resized_u8.argtypes = [C.POINTER(C.c_ubyte)] + [i] * 5 + [_fp]
+    lib.oracle_load_resized_u8.restype = None
     for name in ("oracle_conv_f32", "oracle_conv_int8", "oracle_conv_xnor", "oracle_maxpool", "oracle_shortcut",
                  "oracle_upsample", "oracle_yolo", "oracle_region", "oracle_reorg", "oracle_fuse_bn",
                  "oracle_binary_mean"):
@@ -104,6 +106,23 @@ def seeded_input(batch: int, c: int, h: int, w: int, seed: int = 2222222) -> np.
     """U[0,1) images, seed echoing srand(2222222) (src/main.c:165)."""
     rng = np.random.default_rng(seed)
     return rng.random((batch, c, h, w), dtype=np.float32)
+
+
+def write_ppm(path: str, pix: np.ndarray) -> None:
+    """binary PPM (P6) of an HWC u8 image -- a lossless container the reference's stb decoder reads"""
+    h, w, c = pix.shape
+    assert c == 3 and pix.dtype == np.uint8
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (w, h))
+        f.write(np.ascontiguousarray(pix).tobytes())
+
+
+def oracle_load_resized(olib, pix: np.ndarray, w: int, h: int) -> np.ndarray:
+    sh, sw, sc = pix.shape
+    pix = np.ascontiguousarray(pix)
+    out = np.zeros((sc, h, w), dtype=np.float32)
+    olib.oracle_load_resized_u8(pix.ctypes.data_as(C.POINTER(C.c_ubyte)), sw, sh, sc, w, h, fp(out))
+    return out
 
 
 def xnor_fallback_operands(olib, x, weights, mean_arr, li):

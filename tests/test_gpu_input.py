@@ -1,0 +1,70 @@
+"""the image front end on the GPU (yl_network_set_input_u8, csrc/preprocess.hip)
+against the oracle restatement of load_image_stb's conversion + resize_image
+(oracle_load_resized_u8, pinned bit-for-bit against the reference's own load_image/resize_image in
+tests/test_oracle_pin.py::test_image_front_end_matches_reference).  Bar: bit-exact."""
+import numpy as np
+import pytest
+
+import common
+from common import Network
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(768, 576), (640, 480), (333, 500), (100, 60), (1920, 1080), (1, 7), (9, 1), (37, 23)]
+
+
+@pytest.mark.parametrize("netw,neth", [(416, 416), (608, 608), (96, 64)])
+def test_u8_front_end_bit_exact(olib, netw, neth):
+    cfg, wts = common.model_files("yolov3-tiny", netw, neth)
+    B = len(SIZES) + 1
+    net = Network.load(cfg, wts, B, 0, device=0)
+    rng = np.random.default_rng(netw)
+    imgs = [rng.integers(0, 256, size=(sh, sw, 3), dtype=np.uint8) for sw, sh in SIZES]
+    imgs.append(rng.integers(0, 256, size=(neth, netw, 3), dtype=np.uint8))       # same size as the network
+    for b, pix in enumerate(imgs):
+        net.set_input_u8(b, pix)
+    got = net.input_download()
+    for b, pix in enumerate(imgs):
+        ref = common.oracle_load_resized(olib, pix, netw, neth)
+        assert np.array_equal(got[b].view(np.uint32), ref.view(np.uint32)), (b, pix.shape)
+    net.close()
+
+
+def test_frames_through_the_whole_path(olib):
+    """u8 frames -> GPU front end -> forward -> batched detections  ==  oracle-resized float
+    images -> predict -> host decode, bit for bit; slots are re-staged several times to exercise
+    the staging ring (growth included)."""
+    netw = neth = 416
+    B = 4
+    cfg, wts = common.model_files("yolov3-tiny", netw, neth)
+    net = Network.load(cfg, wts, B, 0, device=0)
+    rng = np.random.default_rng(3)
+    for rnd, (sw, sh) in enumerate([(320, 240), (768, 576), (1280, 720)]):
+        frames = [rng.integers(0, 256, size=(sh, sw, 3), dtype=np.uint8) for _ in range(B)]
+        for b, pix in enumerate(frames):
+            net.set_input_u8(b, pix)
+        net.forward_staged()
+        rows, counts = net.get_boxes_batch(0.1, 0.45, cap=2048, sizes=(sw, sh), relative=0)
+        heads_staged = [net.layer_output(i) for i in range(net.n) if net.layer_info(i)["type"] == common.YOLO]
+        x = np.stack([common.oracle_load_resized(olib, pix, netw, neth) for pix in frames])
+        net.predict(x)
+        heads_ref = [net.layer_output(i) for i in range(net.n) if net.layer_info(i)["type"] == common.YOLO]
+        for a, b_ in zip(heads_staged, heads_ref):
+            assert np.array_equal(a.view(np.uint32), b_.view(np.uint32)), rnd
+        for b in range(B):
+            host = net.get_boxes(b, sw, sh, 0.1, nms=0.45, relative=0)
+            assert counts[b] == len(host)
+            assert np.array_equal(rows[b].view(np.uint32), host.view(np.uint32)), (rnd, b)
+    net.close()
+
+
+def test_front_end_rejects_bad_arguments():
+    cfg, wts = common.model_files("yolov3-tiny", 96, 96)
+    net = Network.load(cfg, wts, 2, 0, device=0)
+    ok = np.zeros((10, 12, 3), dtype=np.uint8)
+    with pytest.raises(Exception):
+        net.set_input_u8(2, ok)                                  # slot out of range
+    with pytest.raises(Exception):
+        net.set_input_u8(0, np.zeros((10, 12, 1), dtype=np.uint8))   # channels != net.c
+    net.set_input_u8(1, ok)
+    net.close()

@@ -89,3 +89,36 @@ def test_oracle_matches_reference_xnor_fallback(olib, batch):
     W.write_synthetic_weights(text, wts, seed=3)
     common._MODEL_CACHE[("xnor-mixed-pin", 64, 48, 1)] = (sys_path_cfg, wts)
     test_oracle_matches_reference_every_layer(olib, "xnor-mixed-pin", 64, 48, batch, 0)
+
+
+IMAGE_CASES = [
+    # source w, h -> network w, h
+    (768, 576, 416, 416),      # the shape of bin/dog.jpg into tiny-416: downscale, aspect change
+    (640, 480, 608, 608),
+    (333, 500, 608, 608),      # upscale one axis, downscale the other
+    (100, 60, 416, 416),       # pure upscale
+    (416, 416, 416, 416),      # same size (resize_image still runs, src/main.c:189)
+    (1920, 1080, 608, 608),
+    (1, 7, 32, 32),            # im.w == 1 edge branch
+    (9, 1, 32, 32),            # im.h == 1 edge branch
+    (37, 23, 64, 96),
+]
+
+
+@pytest.mark.parametrize("sw,sh,w,h", IMAGE_CASES)
+def test_image_front_end_matches_reference(olib, sw, sh, w, h):
+    """u8 HWC -> float CHW /255. -> resize_image, against the reference's own load_image +
+    resize_image run on a PPM of the same pixels."""
+    import ctypes as C
+    import os
+    rng = np.random.default_rng(sw * 1000 + sh)
+    pix = rng.integers(0, 256, size=(sh, sw, 3), dtype=np.uint8)
+    path = os.path.join(common.workdir(), "img_%dx%d.ppm" % (sw, sh))
+    common.write_ppm(path, pix)
+    ref = np.zeros((3, h, w), dtype=np.float32)
+    rw, rh = C.c_int(0), C.c_int(0)
+    rl = refbind._bind(refbind.GOLD)
+    assert rl.ref_load_resized(path.encode(), w, h, common.fp(ref), C.byref(rw), C.byref(rh)) == 0
+    assert (rw.value, rh.value) == (sw, sh)
+    got = common.oracle_load_resized(olib, pix, w, h)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))

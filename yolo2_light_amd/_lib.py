@@ -99,6 +99,13 @@ _SIGS = {
     "yl_debug_last_conv_tile": (C.c_char_p, []),
     "yl_debug_set_conv_variant": (C.c_int, [C.c_int]),
     "yl_network_compact_detections": (C.c_int, [_vp, C.c_float, C.c_int, _vp, _vp]),
+    "yl_network_detect_batch": (C.c_int, [_vp, c_int_p, c_int_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,
+                                          _vp, _vp]),
+    "yl_network_set_input_u8": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int]),
+    "yl_network_set_input_u8_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int]),
+    "yl_network_input_download": (C.c_int, [_vp, c_float_p]),
+    "yl_network_get_boxes_batch": (C.c_int, [_vp, c_int_p, c_int_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,
+                                             c_float_p, c_int_p]),
 }
 
 # every symbol include/yolo2_hip.h declares (tests/test_abi.py cross-checks against the header)

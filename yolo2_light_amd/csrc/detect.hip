@@ -1,0 +1,306 @@
+// detect.hip -- K11: batched correct_yolo_boxes + do_nms_sort on the GPU, one workgroup per image.
+//
+// Reference behaviour reproduced (the reference runs this on the host for batch
+// item 0 only):
+//   correct_yolo_boxes   src/additionally.c:4281-4314   (double arithmetic kept)
+//   do_nms_sort          src/box.c:296-328
+//   nms_comparator       src/box.c:280-294
+//   box_iou & friends    src/box.c:55-97
+//
+// do_nms_sort is a sequential algorithm over classes: for every class k it qsorts ALL
+// detections by prob[k] descending (glibc's qsort is a stable merge sort, so ties keep the order
+// the previous class left behind), then greedily zeroes prob[k] of every later box whose IoU with
+// a surviving earlier box exceeds the threshold.  The final row order is whatever the last sort
+// left.  To return *exactly* the reference's rows (values and order) the kernel carries the
+// permutation through the classes the same way, but does only the work that can change it:
+//   * a class in which no detection has prob > 0 leaves the order untouched (all keys equal,
+//     stable sort) and suppresses nothing -> skipped via a per-image class bitmap;
+//   * otherwise "stable sort by prob desc" == stable partition (prob > 0 first; probabilities are
+//     never negative) + a stable rank sort of the m positive ones, m << count.
+// The greedy pass works on 64 sorted pivots at a time: one wave settles the chunk internally with
+// the dead-set as a 64-bit ballot mask (no barriers), then the whole workgroup applies the chunk's
+// survivors to everything behind it.
+//
+// Input records come from compact_kernel (layers.hip) in atomic-slot order; r[5] carries the
+// reference's scan-order key (head, cell, anchor), which the kernel sorts by first, so the result
+// does not depend on the atomics.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace yl {
+
+namespace {
+
+constexpr int NMS_THREADS = 256;
+
+struct BoxF { float x, y, w, h; };
+
+__device__ __forceinline__ float overlap1d(float x1, float w1, float x2, float w2)
+{
+    const float l1 = __fsub_rn(x1, __fdiv_rn(w1, 2.f));
+    const float l2 = __fsub_rn(x2, __fdiv_rn(w2, 2.f));
+    const float left = l1 > l2 ? l1 : l2;
+    const float r1 = __fadd_rn(x1, __fdiv_rn(w1, 2.f));
+    const float r2 = __fadd_rn(x2, __fdiv_rn(w2, 2.f));
+    const float right = r1 < r2 ? r1 : r2;
+    return __fsub_rn(right, left);
+}
+
+// box_iou(a, b) = box_intersection / box_union, src/box.c:55-97 (float, no contraction)
+__device__ __forceinline__ float box_iou_dev(const BoxF a, const BoxF b)
+{
+    const float w = overlap1d(a.x, a.w, b.x, b.w);
+    const float h = overlap1d(a.y, a.h, b.y, b.h);
+    const float inter = (w < 0 || h < 0) ? 0.f : __fmul_rn(w, h);
+    const float uni = __fsub_rn(__fadd_rn(__fmul_rn(a.w, a.h), __fmul_rn(b.w, b.h)), inter);
+    return __fdiv_rn(inter, uni);
+}
+
+// exclusive prefix sum of one int per thread over the block (NMS_THREADS), result via LDS
+__device__ __forceinline__ int block_exclusive_scan(int v, int *scratch, int *total)
+{
+    const int t = threadIdx.x;
+    scratch[t] = v;
+    __syncthreads();
+    for (int off = 1; off < NMS_THREADS; off <<= 1) {
+        const int add = (t >= off) ? scratch[t - off] : 0;
+        __syncthreads();
+        scratch[t] += add;
+        __syncthreads();
+    }
+    const int incl = scratch[t];
+    *total = scratch[NMS_THREADS - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+}  // namespace
+
+// LDS layout (dynamic, 30 B per record slot), cap <= NMS_MAX_CAP:
+//   float  bx[cap], by[cap], bw[cap], bh[cap]   corrected boxes, indexed by record slot
+//   float  pk[cap]                              prob[k] by position (current class)
+//   float  ps[cap]                              prob[k] of the sorted positive prefix
+//   uint16 perm[2][cap]                         position -> record slot (double buffer)
+//   uint16 sidx[cap]                            sorted positive prefix -> record slot
+//   int    scan[NMS_THREADS], uint32 cmask[(classes+31)/32], misc
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(float *__restrict__ rec, const int *__restrict__ counts,
+                                                          int cap, int classes, int row_stride, float nms,
+                                                          int netw, int neth, ImgDims dims,
+                                                          int relative, int letter,
+                                                          float *__restrict__ rec_out, int *__restrict__ counts_out)
+{
+    extern __shared__ unsigned char smem[];
+    float *bx = (float *)smem;
+    float *by = bx + cap;
+    float *bw = by + cap;
+    float *bh = bw + cap;
+    float *pk = bh + cap;
+    float *ps = pk + cap;
+    uint16_t *permA = (uint16_t *)(ps + cap);
+    uint16_t *permB = permA + cap;
+    uint16_t *sidx = permB + cap;
+    int *scan = (int *)(sidx + cap + (cap & 1));
+    uint32_t *cmask = (uint32_t *)(scan + NMS_THREADS);
+    const int cwords = (classes + 31) >> 5;
+    int *misc = (int *)(cmask + cwords);
+
+    const int b = blockIdx.x;
+    const int t = threadIdx.x;
+    const int raw = counts[b];
+    const int cnt = raw < cap ? raw : cap;
+    float *in = rec + (size_t)b * cap * row_stride;          // scratch rows: prob columns are zeroed in place
+    float *out = rec_out + (size_t)b * cap * row_stride;
+    if (t == 0 && counts_out) counts_out[b] = raw;
+
+    // ---- correct_yolo_boxes parameters (block-uniform), src/additionally.c:4281-4314 ----
+    const uint32_t packed = dims.mode == 2 ? dims.wh[b] : dims.wh[0];
+    const int iw = dims.mode ? (int)(packed & 0xFFFFu) : netw;
+    const int ih = dims.mode ? (int)(packed >> 16) : neth;
+    int new_w, new_h;
+    if (letter) {
+        if (__fdiv_rn((float)netw, (float)iw) < __fdiv_rn((float)neth, (float)ih)) { new_w = netw; new_h = (ih * netw) / iw; }
+        else { new_h = neth; new_w = (iw * neth) / ih; }
+    } else { new_w = netw; new_h = neth; }
+    const double off_x = (double)(netw - new_w) / 2. / (double)netw;
+    const double off_y = (double)(neth - new_h) / 2. / (double)neth;
+    const double sc_x = (double)__fdiv_rn((float)new_w, (float)netw);
+    const double sc_y = (double)__fdiv_rn((float)new_h, (float)neth);
+    const float mul_w = __fdiv_rn((float)netw, (float)new_w);
+    const float mul_h = __fdiv_rn((float)neth, (float)new_h);
+
+    for (int i = t; i < cwords; i += NMS_THREADS) cmask[i] = 0;
+    if (t == 0) misc[0] = 0;
+    __syncthreads();
+
+    // ---- load: corrected boxes, bitmap of classes with any prob > 0, zero-objectness flag ----
+    for (int s = t; s < cnt; s += NMS_THREADS) {
+        const float *r = in + (size_t)s * row_stride;
+        float x = (float)(((double)r[0] - off_x) / sc_x);
+        float y = (float)(((double)r[1] - off_y) / sc_y);
+        float w = __fmul_rn(r[2], mul_w);
+        float h = __fmul_rn(r[3], mul_h);
+        if (!relative) {
+            x = __fmul_rn(x, (float)iw); w = __fmul_rn(w, (float)iw);
+            y = __fmul_rn(y, (float)ih); h = __fmul_rn(h, (float)ih);
+        }
+        bx[s] = x; by[s] = y; bw[s] = w; bh[s] = h;
+        if (r[4] == 0.f) misc[0] = 1;
+        pk[s] = r[5];                                          // scan-order key
+        for (int j = 0; j < classes; ++j)
+            if (r[6 + j] > 0.f) atomicOr(&cmask[j >> 5], 1u << (j & 31));
+    }
+    __syncthreads();
+
+    // ---- initial order = the reference's scan order; rank sort, keys are unique ----
+    for (int s = t; s < cnt; s += NMS_THREADS) {
+        const float key = pk[s];
+        int rank = 0;
+        for (int j = 0; j < cnt; ++j) rank += (pk[j] < key) ? 1 : 0;
+        permA[rank] = (uint16_t)s;
+    }
+    __syncthreads();
+
+    int total = cnt;
+    uint16_t *perm = permA, *perm_nxt = permB;
+    if (nms > 0) {
+        // "move zero-objectness detections to the end" (src/box.c:300-309): sequential swaps.  Only
+        // reachable with thresh < 0 and a logistic that underflowed to 0; kept for exactness.
+        if (misc[0]) {
+            if (t == 0) {
+                int k = cnt - 1;
+                for (int i = 0; i <= k; ++i) {
+                    if (in[(size_t)perm[i] * row_stride + 4] == 0.f) {
+                        const uint16_t sw = perm[i]; perm[i] = perm[k]; perm[k] = sw;
+                        --k; --i;
+                    }
+                }
+                misc[1] = k + 1;
+            }
+            __syncthreads();
+            total = misc[1];
+            for (int p = total + t; p < cnt; p += NMS_THREADS) perm_nxt[p] = perm[p];   // the tail never moves again
+            __syncthreads();
+        }
+
+        for (int k = 0; k < classes; ++k) {
+            if (!((cmask[k >> 5] >> (k & 31)) & 1u)) continue;          // block-uniform
+            // thread t owns positions [p0,p1) so the partition below is stable
+            const int per = (total + NMS_THREADS - 1) / NMS_THREADS;
+            const int p0 = t * per;
+            const int p1 = (p0 + per < total) ? p0 + per : total;
+            int mine = 0;
+            for (int p = p0; p < p1; ++p) {
+                const float v = in[(size_t)perm[p] * row_stride + 6 + k];
+                pk[p] = v;
+                mine += (v > 0.f) ? 1 : 0;
+            }
+            int m = 0;
+            const int before = block_exclusive_scan(mine, scan, &m);
+            {
+                int pos_i = before, neg_i = m + (p0 - before);
+                for (int p = p0; p < p1; ++p) {
+                    if (pk[p] > 0.f) { sidx[pos_i] = perm[p]; ps[pos_i] = pk[p]; ++pos_i; }
+                    else perm_nxt[neg_i++] = perm[p];
+                }
+            }
+            __syncthreads();
+            // stable rank sort of the positive prefix by prob desc -> perm_nxt[0,m), pk[0,m)
+            for (int i = t; i < m; i += NMS_THREADS) {
+                const float v = ps[i];
+                int rank = 0;
+                for (int j = 0; j < m; ++j) {
+                    const float u = ps[j];
+                    rank += (u > v || (u == v && j < i)) ? 1 : 0;
+                }
+                perm_nxt[rank] = sidx[i];
+                pk[rank] = v;
+            }
+            __syncthreads();
+            // greedy suppression over the sorted prefix (positions >= m have prob 0: `continue`),
+            // 64 pivots at a time: wave 0 settles the chunk internally with the dead-set as a
+            // ballot mask (no barriers), then every thread applies the chunk's survivors to the
+            // elements behind it -- one barrier pair per 64 pivots instead of one per pivot.
+            for (int c0 = 0; c0 < m; c0 += 64) {
+                const int cn = (m - c0 < 64) ? m - c0 : 64;
+                if (t < 64) {
+                    const bool valid = t < cn;
+                    const int slot = valid ? perm_nxt[c0 + t] : 0;
+                    const BoxF me = { bx[slot], by[slot], bw[slot], bh[slot] };
+                    // bit j set: element c0+j is dead (suppressed by an earlier chunk, or below)
+                    unsigned long long dead = __ballot(valid && pk[c0 + t] == 0.f);
+                    for (int i = 0; i < cn; ++i) {
+                        if ((dead >> i) & 1ull) continue;
+                        BoxF a;
+                        a.x = __shfl(me.x, i); a.y = __shfl(me.y, i); a.w = __shfl(me.w, i); a.h = __shfl(me.h, i);
+                        const bool kill = valid && t > i && (box_iou_dev(a, me) > nms);
+                        dead |= __ballot(kill);
+                    }
+                    if (valid && ((dead >> t) & 1ull) && pk[c0 + t] != 0.f) {
+                        pk[c0 + t] = 0.f;
+                        in[(size_t)slot * row_stride + 6 + k] = 0.f;
+                    }
+                    if (t == 0) { misc[2] = (int)(unsigned)(dead & 0xFFFFFFFFull); misc[3] = (int)(unsigned)(dead >> 32); }
+                }
+                if (c0 + 64 >= m) break;              // block-uniform: nothing behind this chunk
+                __syncthreads();
+                const unsigned long long dead = ((unsigned long long)(unsigned)misc[3] << 32) | (unsigned)misc[2];
+                for (int j = c0 + 64 + t; j < m; j += NMS_THREADS) {
+                    if (pk[j] == 0.f) continue;
+                    const int sj = perm_nxt[j];
+                    const BoxF me = { bx[sj], by[sj], bw[sj], bh[sj] };
+                    bool kill = false;
+                    for (int i = 0; i < 64 && !kill; ++i) {
+                        if ((dead >> i) & 1ull) continue;
+                        const int si = perm_nxt[c0 + i];
+                        const BoxF a = { bx[si], by[si], bw[si], bh[si] };
+                        kill = box_iou_dev(a, me) > nms;
+                    }
+                    if (kill) { pk[j] = 0.f; in[(size_t)sj * row_stride + 6 + k] = 0.f; }
+                }
+                __syncthreads();
+            }
+            __syncthreads();
+            uint16_t *sw = perm; perm = perm_nxt; perm_nxt = sw;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- emit rows in the final order (coalesced over the flattened [row][column] index) ----
+    const float sort_class = (nms > 0) ? (float)(classes - 1) : 0.f;
+    const int n_out = cnt * row_stride;
+    for (int e = t; e < n_out; e += NMS_THREADS) {
+        const int p = e / row_stride, c = e - p * row_stride;
+        const int s = perm[p];
+        float v;
+        if (c == 0) v = bx[s];
+        else if (c == 1) v = by[s];
+        else if (c == 2) v = bw[s];
+        else if (c == 3) v = bh[s];
+        else if (c == 5) v = (p < total) ? sort_class : 0.f;     // the unsorted tail keeps calloc's 0
+        else v = in[(size_t)s * row_stride + c];
+        out[e] = v;
+    }
+}
+
+size_t nms_lds_bytes(int cap, int classes)
+{
+    size_t n = (size_t)cap * 6 * sizeof(float) + (size_t)(3 * cap + (cap & 1)) * sizeof(uint16_t);
+    n += NMS_THREADS * sizeof(int) + (size_t)((classes + 31) / 32) * sizeof(uint32_t) + 4 * sizeof(int);
+    return n;
+}
+
+int launch_nms(float *rec_scratch, const int *counts, int B, int cap, int classes, float nms, int netw, int neth,
+               const ImgDims &dims, int relative, int letter, float *rec_out, int *counts_out, void *stream)
+{
+    if (cap > NMS_MAX_CAP) return (int)hipErrorInvalidValue;
+    const int row_stride = 6 + classes;
+    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NMS_THREADS), nms_lds_bytes(cap, classes), (hipStream_t)stream,
+                       rec_scratch, counts, cap, classes, row_stride, nms, netw, neth, dims, relative, letter,
+                       rec_out, counts_out);
+    return (int)hipGetLastError();
+}
+
+}  // namespace yl

@@ -90,4 +90,20 @@ struct HeadDesc {
 int launch_compact(const HeadDesc *heads, int n_heads, int B, int netw, int neth, float thresh,
                    int cap, int row_stride, float *records, int *counts, void *stream);
 
+// K11 (detect.hip): per-image correct_yolo_boxes + do_nms_sort over compacted records.
+// rec_scratch[B][cap][6+classes] is consumed (its prob columns are zeroed in place); rows come out
+// in rec_out in the reference's final order.  Source image sizes travel as a kernel argument
+// (w | h << 16): mode 0 = network size, 1 = wh[0] for every image, 2 = wh[b].
+constexpr int NMS_MAX_CAP = 2048;
+constexpr int NMS_MAX_DIMS = 256;
+struct ImgDims {
+    int mode;
+    uint32_t wh[NMS_MAX_DIMS];
+};
+int launch_nms(float *rec_scratch, const int *counts, int B, int cap, int classes, float nms, int netw, int neth,
+               const ImgDims &dims, int relative, int letter, float *rec_out, int *counts_out, void *stream);
+
+// K12 (preprocess.hip): HWC u8 [sh][sw][sc] -> resize_image'd CHW float [sc][h][w] in [0,1]
+int launch_load_resize_u8(const uint8_t *pix, int sw, int sh, int sc, int w, int h, float *out, void *stream);
+
 }  // namespace yl

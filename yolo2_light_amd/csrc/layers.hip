@@ -302,6 +302,43 @@ int launch_binarize(const float *in, float *out, size_t n, void *stream)
 }
 
 // ---------------------------------------------------------------- K10: detection compaction
+// expf as the reference's host computes it.  get_region_box_cpu (src/yolov2_forward_network.c:653-661)
+// calls libm's expf; glibc >= 2.27 evaluates it in double -- k = round(x*32/ln2), a 32-entry table
+// of 2^(i/32), a cubic in the reduced argument, one rounding to float at the end -- and on an
+// FMA-capable x86 host the build it dispatches to contracts every a*b+c.  Restated with explicit
+// f64 fma's; verified against glibc 2.35's expf over every float in (-87, 88) (2 237 530 112
+// inputs, 0 mismatches).  Device expf (<= 1 ulp) differed from it in ~6 % of the boxes.
+__device__ __constant__ unsigned long long kExp2fTab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull,
+};
+
+__device__ __forceinline__ float expf_host_libm(float x)
+{
+    if (!(x > -87.0f && x < 88.0f)) return expf(x);          // overflow/underflow/NaN tails: not boxes anyone keeps
+    const double xd = (double)x;
+    const double inv_ln2_n = 0x1.71547652b82fep+5;           // 32 / ln 2
+    const double shift = 0x1.8p52;
+    const double z = __dmul_rn(inv_ln2_n, xd);
+    double kd = __dadd_rn(z, shift);
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd = __dsub_rn(kd, shift);
+    const double r = __fma_rn(inv_ln2_n, xd, -kd);
+    const unsigned long long t = kExp2fTab[ki & 31] + (ki << 47);
+    const double sc = __longlong_as_double((long long)t);
+    const double q = __fma_rn(0x1.c6af84b912394p-20, r, 0x1.ebfce50fac4f3p-13);
+    const double r2 = __dmul_rn(r, r);
+    double y = __fma_rn(0x1.62e42ff0c52d6p-6, r, 1.0);
+    y = __fma_rn(q, r2, y);
+    return (float)__dmul_rn(y, sc);
+}
+
 struct HeadsDev {
     HeadDesc h[4];
     int n_heads;
@@ -329,15 +366,18 @@ __device__ __forceinline__ int wave_alloc_slot(int *counts, int b, bool pass)
 }
 
 // one lane per (image, head, cell, anchor).  Record row (stride = 6 + classes):
-//   x y w h objectness sort_class(-1) prob[classes]
+//   x y w h objectness scan_key prob[classes]
 // boxes are relative to the network input (== get_network_boxes(net, 1, 1, thresh, ., 0, relative=1, ., 0)).
-// Order inside an image is by atomic slot, i.e. NOT the reference's scan order: consumers sort or
-// treat the set as unordered (NMS re-sorts per class anyway, src/box.c:313).
+// Order inside an image is by atomic slot, i.e. NOT the reference's scan order; scan_key (exact in
+// f32) = position of the (head, cell, anchor) triple in the reference's scan
+// (get_yolo_detections: heads in layer order, cells row-major, anchors fastest), so a consumer can
+// restore that order (nms_kernel in detect.hip does).
 __global__ __launch_bounds__(256) void compact_kernel(HeadsDev hd, int B, int netw, int neth, float thresh,
                                                       int cap, int row_stride, float *__restrict__ records,
                                                       int *__restrict__ counts)
 {
-    for (int hi = 0; hi < hd.n_heads; ++hi) {
+    int key_base = 0;
+    for (int hi = 0; hi < hd.n_heads; key_base += hd.h[hi].w * hd.h[hi].h * hd.h[hi].n, ++hi) {
         const HeadDesc &h = hd.h[hi];
         const int wh = h.w * h.h;
         const size_t total = (size_t)B * wh * h.n;
@@ -366,7 +406,7 @@ __global__ __launch_bounds__(256) void compact_kernel(HeadsDev hd, int B, int ne
                     r[2] = (float)(exp((double)e[2 * (size_t)wh]) * (double)h.anchors_w[n] / (double)netw);
                     r[3] = (float)(exp((double)e[3 * (size_t)wh]) * (double)h.anchors_h[n] / (double)neth);
                     r[4] = objectness;
-                    r[5] = -1.f;
+                    r[5] = (float)(key_base + cell * h.n + n);
                     for (int j = 0; j < h.classes; ++j) {
                         const float prob = __fmul_rn(objectness, e[(size_t)(5 + j) * wh]);
                         r[6 + j] = (prob > thresh) ? prob : 0.f;
@@ -383,10 +423,10 @@ __global__ __launch_bounds__(256) void compact_kernel(HeadsDev hd, int B, int ne
                     const float ly = (float)(1. / (1. + exp((double)(-e[1]))));
                     r[0] = __fdiv_rn(__fadd_rn((float)col, lx), (float)h.w);
                     r[1] = __fdiv_rn(__fadd_rn((float)row, ly), (float)h.h);
-                    r[2] = __fdiv_rn(__fmul_rn(expf(e[2]), h.anchors_w[n]), (float)h.w);
-                    r[3] = __fdiv_rn(__fmul_rn(expf(e[3]), h.anchors_h[n]), (float)h.h);
+                    r[2] = __fdiv_rn(__fmul_rn(expf_host_libm(e[2]), h.anchors_w[n]), (float)h.w);
+                    r[3] = __fdiv_rn(__fmul_rn(expf_host_libm(e[3]), h.anchors_h[n]), (float)h.h);
                     r[4] = 1.f;
-                    r[5] = -1.f;
+                    r[5] = (float)(key_base + cell * h.n + n);
                     for (int j = 0; j < h.classes; ++j) {
                         const float prob = __fmul_rn(scale, e[5 + j]);
                         r[6 + j] = (prob > thresh) ? prob : 0.f;

@@ -65,6 +65,16 @@ static void free_device(Network &net)
     if (net.d_binbuf) (void)hipFree(net.d_binbuf);
     net.d_binbuf = nullptr;
     if (net.h_pinned) (void)hipHostFree(net.h_pinned);
+    if (net.h_u8) (void)hipHostFree(net.h_u8);
+    if (net.d_u8) (void)hipFree(net.d_u8);
+    for (void *e : net.u8_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
+    net.u8_events.clear();
+    net.h_u8 = nullptr; net.d_u8 = nullptr; net.u8_stride = 0;
+    if (net.d_det_scratch) (void)hipFree(net.d_det_scratch);
+    if (net.d_det_out) (void)hipFree(net.d_det_out);
+    if (net.d_det_counts) (void)hipFree(net.d_det_counts);
+    net.d_det_scratch = nullptr; net.d_det_out = nullptr; net.d_det_counts = nullptr;
+    net.det_scratch_bytes = net.det_out_bytes = 0;
     net.d_input = nullptr; net.d_qbuf = nullptr; net.d_bitbuf = nullptr; net.h_pinned = nullptr;
     for (void *e : net.layer_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
     net.layer_events.clear();
@@ -800,13 +810,84 @@ int yl_debug_force_conv_tile(int cfg) { conv_f32_force_tile(cfg); return YL_OK; 
 int yl_debug_set_conv_variant(int v) { conv_f32_set_variant(v); return YL_OK; }
 const char *yl_debug_last_conv_tile(void) { return conv_f32_last_tile_name(); }
 
-int yl_network_compact_detections(yl_network *net, float thresh, int cap, float *records_dev, int *counts_dev)
+static int check_image_args(yl_network *net, int image, const void *pixels, int w, int h, int c)
 {
-    if (!net || !records_dev || !counts_dev || cap <= 0) { set_error("bad argument"); return YL_ERR_ARG; }
+    if (!net || !pixels) { set_error("null argument"); return YL_ERR_ARG; }
+    Network &n = net->net;
+    if (!n.on_device) { set_error("network not on device"); return YL_ERR_STATE; }
+    if (image < 0 || image >= n.batch) { set_error("image index out of range"); return YL_ERR_ARG; }
+    if (w <= 0 || h <= 0) { set_error("image size must be positive"); return YL_ERR_ARG; }
+    if (c != n.c) { set_error("image channels differ from the network's"); return YL_ERR_ARG; }
+    if (n.w < 2 || n.h < 2) { set_error("resize_image needs a network input of at least 2x2"); return YL_ERR_UNSUPPORTED; }
+    return YL_OK;
+}
+
+int yl_network_set_input_u8_dev(yl_network *net, int image, const uint8_t *pixels_dev, int w, int h, int c)
+{
+    const int rc = check_image_args(net, image, pixels_dev, w, h, c);
+    if (rc != YL_OK) return rc;
+    Network &n = net->net;
+    YL_HIP(hipSetDevice(n.device));
+    float *dst = n.d_input + (size_t)image * n.c * n.h * n.w;
+    YL_LAUNCH(launch_load_resize_u8(pixels_dev, w, h, c, n.w, n.h, dst, n.stream), "load_resize_u8");
+    return YL_OK;
+}
+
+int yl_network_set_input_u8(yl_network *net, int image, const uint8_t *pixels_host, int w, int h, int c)
+{
+    const int rc = check_image_args(net, image, pixels_host, w, h, c);
+    if (rc != YL_OK) return rc;
+    Network &n = net->net;
+    YL_HIP(hipSetDevice(n.device));
+    hipStream_t s = (hipStream_t)n.stream;
+    const size_t bytes = (size_t)w * h * c;
+    if (bytes > n.u8_stride) {
+        // grow every slot: earlier stagings must have been consumed first
+        YL_HIP(hipStreamSynchronize(s));
+        size_t stride = n.u8_stride ? n.u8_stride : (size_t)n.w * n.h * n.c;
+        while (stride < bytes) stride += stride / 2;
+        stride = (stride + 4095) & ~(size_t)4095;
+        if (n.h_u8) (void)hipHostFree(n.h_u8);
+        if (n.d_u8) (void)hipFree(n.d_u8);
+        n.h_u8 = nullptr; n.d_u8 = nullptr; n.u8_stride = 0;
+        YL_HIP(hipHostMalloc((void **)&n.h_u8, stride * n.batch, hipHostMallocDefault));
+        YL_HIP(hipMalloc((void **)&n.d_u8, stride * n.batch));
+        n.u8_stride = stride;
+    }
+    if (n.u8_events.size() != (size_t)n.batch) {
+        n.u8_events.assign((size_t)n.batch, nullptr);
+        for (auto &e : n.u8_events) {
+            hipEvent_t ev;
+            YL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            e = ev;
+            YL_HIP(hipEventRecord(ev, s));
+        }
+    }
+    // the slot's staging region may still be the source of the previous frame's copy
+    YL_HIP(hipEventSynchronize((hipEvent_t)n.u8_events[image]));
+    uint8_t *hs = n.h_u8 + (size_t)image * n.u8_stride;
+    uint8_t *ds = n.d_u8 + (size_t)image * n.u8_stride;
+    memcpy(hs, pixels_host, bytes);
+    YL_HIP(hipMemcpyAsync(ds, hs, bytes, hipMemcpyHostToDevice, s));
+    YL_HIP(hipEventRecord((hipEvent_t)n.u8_events[image], s));
+    float *dst = n.d_input + (size_t)image * n.c * n.h * n.w;
+    YL_LAUNCH(launch_load_resize_u8(ds, w, h, c, n.w, n.h, dst, n.stream), "load_resize_u8");
+    return YL_OK;
+}
+
+int yl_network_input_download(yl_network *net, float *dst_host)
+{
+    if (!net || !dst_host) { set_error("null argument"); return YL_ERR_ARG; }
     Network &n = net->net;
     if (!n.on_device) { set_error("network not on device"); return YL_ERR_STATE; }
     YL_HIP(hipSetDevice(n.device));
-    HeadDesc heads[4];
+    YL_HIP(hipStreamSynchronize((hipStream_t)n.stream));
+    YL_HIP(hipMemcpy(dst_host, n.d_input, sizeof(float) * (size_t)n.batch * n.c * n.h * n.w, hipMemcpyDeviceToHost));
+    return YL_OK;
+}
+
+static int collect_heads(Network &n, HeadDesc *heads, int *nh_out, int *classes_out)
+{
     int nh = 0;
     const int classes = n.layers.back().classes;
     for (const Layer &l : n.layers) {
@@ -822,8 +903,105 @@ int yl_network_compact_detections(yl_network *net, float thresh, int cap, float 
         }
     }
     if (nh == 0) { set_error("network has no detection head"); return YL_ERR_STATE; }
+    *nh_out = nh;
+    *classes_out = classes;
+    return YL_OK;
+}
+
+int yl_network_compact_detections(yl_network *net, float thresh, int cap, float *records_dev, int *counts_dev)
+{
+    if (!net || !records_dev || !counts_dev || cap <= 0) { set_error("bad argument"); return YL_ERR_ARG; }
+    Network &n = net->net;
+    if (!n.on_device) { set_error("network not on device"); return YL_ERR_STATE; }
+    YL_HIP(hipSetDevice(n.device));
+    HeadDesc heads[4];
+    int nh = 0, classes = 0;
+    const int rc = collect_heads(n, heads, &nh, &classes);
+    if (rc != YL_OK) return rc;
     YL_LAUNCH(launch_compact(heads, nh, n.batch, n.w, n.h, thresh, cap, 6 + classes, records_dev, counts_dev, n.stream),
               "compact");
+    return YL_OK;
+}
+
+int yl_network_detect_batch(yl_network *net, const int *img_w, const int *img_h, float thresh, int relative,
+                            int letter, float nms, int cap, float *records_dev, int *counts_dev)
+{
+    if (!net || !records_dev || !counts_dev || cap <= 0) { set_error("bad argument"); return YL_ERR_ARG; }
+    if (cap > NMS_MAX_CAP) { set_error("cap exceeds YL_DETECT_MAX_CAP"); return YL_ERR_ARG; }
+    if ((img_w == nullptr) != (img_h == nullptr)) { set_error("img_w and img_h must both be given or both be NULL"); return YL_ERR_ARG; }
+    if (!img_w && (!relative || letter)) { set_error("absolute or letterboxed boxes need the source image sizes"); return YL_ERR_ARG; }
+    Network &n = net->net;
+    if (!n.on_device) { set_error("network not on device"); return YL_ERR_STATE; }
+    YL_HIP(hipSetDevice(n.device));
+    HeadDesc heads[4];
+    int nh = 0, classes = 0;
+    const int rc = collect_heads(n, heads, &nh, &classes);
+    if (rc != YL_OK) return rc;
+    const int B = n.batch;
+    const size_t need = sizeof(float) * (size_t)B * cap * (6 + classes);
+    if (n.det_scratch_bytes < need) {
+        YL_HIP(hipStreamSynchronize((hipStream_t)n.stream));
+        if (n.d_det_scratch) (void)hipFree(n.d_det_scratch);
+        n.d_det_scratch = nullptr; n.det_scratch_bytes = 0;
+        YL_HIP(hipMalloc((void **)&n.d_det_scratch, need));
+        n.det_scratch_bytes = need;
+    }
+    if (!n.d_det_counts) YL_HIP(hipMalloc((void **)&n.d_det_counts, sizeof(int) * 2 * (size_t)B));
+    ImgDims dims;
+    dims.mode = 0;
+    dims.wh[0] = 0;
+    if (img_w) {
+        bool uniform = true;
+        for (int b = 0; b < B; ++b) {
+            if (img_w[b] <= 0 || img_h[b] <= 0 || img_w[b] > 65535 || img_h[b] > 65535) {
+                set_error("image sizes must be in 1..65535"); return YL_ERR_ARG;
+            }
+            uniform = uniform && img_w[b] == img_w[0] && img_h[b] == img_h[0];
+        }
+        if (!uniform && B > NMS_MAX_DIMS) { set_error("per-image sizes are limited to batch <= 256"); return YL_ERR_UNSUPPORTED; }
+        dims.mode = uniform ? 1 : 2;
+        for (int b = 0; b < (uniform ? 1 : B); ++b) dims.wh[b] = (uint32_t)img_w[b] | ((uint32_t)img_h[b] << 16);
+    }
+    YL_LAUNCH(launch_compact(heads, nh, B, n.w, n.h, thresh, cap, 6 + classes, n.d_det_scratch, n.d_det_counts, n.stream),
+              "compact");
+    YL_LAUNCH(launch_nms(n.d_det_scratch, n.d_det_counts, B, cap, classes, nms, n.w, n.h, dims, relative, letter,
+                         records_dev, counts_dev, n.stream), "nms");
+    return YL_OK;
+}
+
+int yl_network_get_boxes_batch(yl_network *net, const int *img_w, const int *img_h, float thresh, int relative,
+                               int letter, float nms, int cap, float *rows_host, int *counts_host)
+{
+    if (!net || !rows_host || !counts_host || cap <= 0) { set_error("bad argument"); return YL_ERR_ARG; }
+    Network &n = net->net;
+    if (!n.on_device) { set_error("network not on device"); return YL_ERR_STATE; }
+    YL_HIP(hipSetDevice(n.device));
+    const int classes = n.layers.back().classes;
+    const int B = n.batch;
+    const size_t need = sizeof(float) * (size_t)B * cap * (6 + classes);
+    if (n.det_out_bytes < need) {
+        YL_HIP(hipStreamSynchronize((hipStream_t)n.stream));
+        if (n.d_det_out) (void)hipFree(n.d_det_out);
+        n.d_det_out = nullptr; n.det_out_bytes = 0;
+        YL_HIP(hipMalloc((void **)&n.d_det_out, need));
+        n.det_out_bytes = need;
+    }
+    if (!n.d_det_counts) YL_HIP(hipMalloc((void **)&n.d_det_counts, sizeof(int) * 2 * (size_t)B));
+    const int rc = yl_network_detect_batch(net, img_w, img_h, thresh, relative, letter, nms, cap, n.d_det_out,
+                                           n.d_det_counts + B);
+    if (rc != YL_OK) return rc;
+    hipStream_t s = (hipStream_t)n.stream;
+    YL_HIP(hipMemcpyAsync(counts_host, n.d_det_counts + B, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, s));
+    YL_HIP(hipStreamSynchronize(s));
+    // only the filled rows travel
+    const size_t row = (size_t)(6 + classes);
+    for (int b = 0; b < B; ++b) {
+        const int c = counts_host[b] < cap ? counts_host[b] : cap;
+        if (c > 0)
+            YL_HIP(hipMemcpyAsync(rows_host + (size_t)b * cap * row, n.d_det_out + (size_t)b * cap * row,
+                                  sizeof(float) * row * c, hipMemcpyDeviceToHost, s));
+    }
+    YL_HIP(hipStreamSynchronize(s));
     return YL_OK;
 }
 

@@ -86,6 +86,15 @@ struct Network {
     size_t binbuf_bytes = 0;
     void *h_pinned = nullptr;            // pinned staging for the input
     size_t pinned_bytes = 0;
+    float *d_det_scratch = nullptr;      // batched detections: compacted records before NMS
+    size_t det_scratch_bytes = 0;
+    float *d_det_out = nullptr;          // batched detections: device staging of yl_network_get_boxes_batch
+    size_t det_out_bytes = 0;
+    int *d_det_counts = nullptr;         // [2][batch]: raw compaction counts, staged output counts
+    uint8_t *h_u8 = nullptr;             // pinned staging of u8 source images, one region per batch slot
+    uint8_t *d_u8 = nullptr;             // the same on the device
+    size_t u8_stride = 0;                // bytes per slot
+    std::vector<void *> u8_events;       // per slot: H2D of the slot's staging region has completed
     void *ev0 = nullptr, *ev1 = nullptr; // hipEvent_t pair for profiling
     std::vector<void *> layer_events;
 };

@@ -229,6 +229,30 @@ class Network:
         p = lib.yl_network_layer_kernel(self._h, i)
         return p.decode() if p else ""
 
+    def set_input_u8(self, image: int, pixels: np.ndarray) -> None:
+        """pixels: uint8 [h][w][c] as a decoder delivers them; converts (/255.), resizes
+        (resize_image) and stores into batch slot `image` of the device input buffer."""
+        pix = np.ascontiguousarray(pixels, dtype=np.uint8)
+        if pix.ndim != 3:
+            raise ValueError("pixels must be [h][w][c]")
+        h, w, c = pix.shape
+        check(lib.yl_network_set_input_u8(self._h, image, pix.ctypes.data_as(C.c_void_p), w, h, c),
+              "yl_network_set_input_u8")
+
+    def set_input_u8_dev(self, image: int, pixels_dev_ptr: int, w: int, h: int, c: int = 3) -> None:
+        check(lib.yl_network_set_input_u8_dev(self._h, image, C.c_void_p(pixels_dev_ptr), w, h, c),
+              "yl_network_set_input_u8_dev")
+
+    def input_download(self) -> np.ndarray:
+        w, h, c = self.input_dims
+        out = np.zeros((self.batch, c, h, w), dtype=np.float32)
+        check(lib.yl_network_input_download(self._h, _fp(out)), "yl_network_input_download")
+        return out
+
+    def forward_staged(self) -> None:
+        """forward over the device input buffer the set_input_* calls filled (asynchronous)"""
+        check(lib.yl_network_forward(self._h, lib.yl_network_input_dev(self._h)), "yl_network_forward")
+
     # ------------------------------------------------------------ detections
     def pull_heads(self) -> None:
         check(lib.yl_network_pull_heads(self._h), "yl_network_pull_heads")
@@ -245,6 +269,42 @@ class Network:
         if n2 < 0:
             raise YoloHipError("yl_network_get_boxes failed: " + _lib.last_error())
         return rows[:n]
+
+    @staticmethod
+    def _dims(sizes, batch):
+        if sizes is None:
+            return None, None
+        wh = np.ascontiguousarray(np.broadcast_to(np.asarray(sizes, dtype=np.int32).reshape(-1, 2), (batch, 2)))
+        w = np.ascontiguousarray(wh[:, 0])
+        h = np.ascontiguousarray(wh[:, 1])
+        return w, h
+
+    def detect_batch(self, thresh: float, nms: float, cap: int, records_dev_ptr: int, counts_dev_ptr: int,
+                     sizes=None, relative: int = 1, letter: int = 0) -> None:
+        """get_network_boxes + do_nms_sort for every image, on the GPU, into device buffers
+        (asynchronous).  sizes = (w, h) or [(w, h)] * batch of the source images, None = relative
+        to the network input."""
+        w, h = self._dims(sizes, self.batch)
+        ip = C.POINTER(C.c_int)
+        check(lib.yl_network_detect_batch(self._h, w.ctypes.data_as(ip) if w is not None else None,
+                                          h.ctypes.data_as(ip) if h is not None else None, thresh, relative, letter,
+                                          nms, cap, C.c_void_p(records_dev_ptr), C.c_void_p(counts_dev_ptr)),
+              "yl_network_detect_batch")
+
+    def get_boxes_batch(self, thresh: float, nms: float = 0.0, cap: int = 1024, sizes=None, relative: int = 1,
+                        letter: int = 0):
+        """list (one entry per image) of row arrays [n][6+classes] -- the batched, on-GPU form of
+        get_boxes(); `counts` (second result) may exceed cap, in which case rows are truncated."""
+        w, h = self._dims(sizes, self.batch)
+        ip = C.POINTER(C.c_int)
+        classes = self.layer_info(self.n - 1)["classes"]
+        rows = np.zeros((self.batch, cap, 6 + classes), dtype=np.float32)
+        counts = np.zeros(self.batch, dtype=np.int32)
+        check(lib.yl_network_get_boxes_batch(self._h, w.ctypes.data_as(ip) if w is not None else None,
+                                             h.ctypes.data_as(ip) if h is not None else None, thresh, relative,
+                                             letter, nms, cap, _fp(rows), counts.ctypes.data_as(ip)),
+              "yl_network_get_boxes_batch")
+        return [rows[b, :min(int(counts[b]), cap)] for b in range(self.batch)], counts
 
     def compact_detections(self, thresh: float, cap: int, records_dev_ptr: int, counts_dev_ptr: int) -> None:
         check(lib.yl_network_compact_detections(self._h, thresh, cap, C.c_void_p(records_dev_ptr),

@@ -32,15 +32,20 @@ _G_PLAIN = 0.917
 _G_RESIDUAL = 0.25
 
 
-def write_synthetic_weights(cfg_text: str, path: str, seed: int = 1, obj_bias: float = -3.0) -> int:
+def write_synthetic_weights(cfg_text: str, path: str, seed: int = 1, obj_bias: float = -3.0,
+                            cls_bias: float = 0.0, head_bias_delta=None) -> int:
     """Write a synthetic weights file for the network described by cfg_text.
 
     The objectness channel of every detection-head conv gets `obj_bias` added so
-    that only some boxes pass the 0.24 threshold.  Returns the number of float32
-    values written.
+    that only some boxes pass the 0.24 threshold; `cls_bias` is added to the class channels
+    (a trained detector is confident about one or two classes per box, an untrained head
+    about half of them); `head_bias_delta` = one float array per detection-head conv (in cfg
+    order) added to its biases after they were drawn -- bench.py uses it to give the random
+    head a detector-like output density.  Returns the number of float32 values written.
     """
     rng = np.random.default_rng(seed)
     total = 0
+    head_i = 0
     with open(path, "wb") as f:
         f.write(struct.pack("<iii", 0, 2, 0))
         f.write(struct.pack("<Q", 0))
@@ -53,6 +58,11 @@ def write_synthetic_weights(cfg_text: str, path: str, seed: int = 1, obj_bias: f
                 for a in range(cv["head_anchors"]):
                     if a * per + 4 < n:
                         bias[a * per + 4] += np.float32(obj_bias)
+                    if cls_bias:
+                        bias[a * per + 5:min((a + 1) * per, n)] += np.float32(cls_bias)
+                if head_bias_delta is not None and head_i < len(head_bias_delta):
+                    bias += np.asarray(head_bias_delta[head_i], dtype=np.float32).reshape(n)
+                head_i += 1
             bias.astype("<f4").tofile(f)
             total += n
             if cv["bn"]:
