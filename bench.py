@@ -328,6 +328,10 @@ def main():
         "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
         "all_conv_tflops": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
         "conv_ms_per_step": conv_ms, "other_layers_ms_per_step": other_ms,
+        # Winograd F(2x2,3x3) issues 16 multiplies per 2x2 output tile instead of 36: `achieved`
+        # stays the ALGORITHMIC rate (2*M*K*N per launch / duration) and can exceed the
+        # matrix peak; `issued_mfma_tflops` is what the MFMA pipe actually executed
+        "issued_mfma_tflops": (achieved / 2.25 if "wino" in dom_name else achieved),
         "detect_ms_per_step": detect_ms,
         "detections_per_image": {"mean": float(det_counts.mean()), "max": int(det_counts.max())},
         "by_kernel": {n: {"tflops": (k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0),

@@ -239,6 +239,11 @@ int yl_debug_force_conv_tile(int cfg);
  * ids are 10 + cfg (conv_f32_mfma_v2.hip). */
 int yl_debug_set_conv_variant(int v);
 const char *yl_debug_last_conv_tile(void);
+/* Tuning/test hook: Winograd F(2x2,3x3) for FP32 3x3 / stride 1 / pad 1 convolutions
+ * (conv_f32_wino.hip): 0 = off, 1 = on (default).  Takes effect for networks uploaded AFTER the
+ * call (the transformed weights are packed at yl_network_to_device); with it on, forced tile id 30
+ * = Winograd, any other forced tile = the direct kernel. */
+int yl_debug_set_winograd(int mode);
 
 /* On-device detection compaction (new): threshold test
  * `objectness > thresh` (src/additionally.c:4341) and box decode

@@ -80,6 +80,74 @@ def test_conv_f32_vs_oracle(olib, shape, variant, tile):
     net.close()
 
 
+# K1w: Winograd F(2x2,3x3) kernel (forced tile 30), 3x3 / stride 1 / pad 1 only
+WINO_SHAPES = [
+    # B, C, H, W, M, act
+    (2, 16, 13, 13, 33, D.LEAKY),          # 2 panels, M tail, odd size, 49 tiles/image: a block spans 2 images
+    (1, 24, 8, 8, 64, D.LEAKY),            # 3 panels, even size, 16 tiles (block mostly empty)
+    (3, 32, 19, 19, 70, D.LINEAR),         # odd size 19 (yolov3-608's last scale), linear
+    (1, 256, 13, 13, 512, D.LEAKY),        # deep K, 8 filter tiles
+    (2, 48, 11, 9, 96, D.LEAKY),           # H != W, both odd
+    (2, 64, 38, 38, 128, D.LEAKY),         # 361 tiles/image
+    (1, 32, 76, 76, 64, D.LEAKY),          # many tile blocks, one filter tile
+    (4, 128, 6, 10, 255, D.LINEAR),        # M = 255
+    (9, 16, 5, 5, 16, D.LEAKY),            # 9 tiles/image: a block spans 8 images
+]
+
+
+@pytest.mark.parametrize("shape", WINO_SHAPES)
+def test_conv_winograd_vs_oracle(olib, shape):
+    B, Cc, H, W, M, act = shape
+    rng = np.random.default_rng(99 + M + H)
+    K = Cc * 9
+    wts = rng.normal(0, np.sqrt(2.0 / K), M * K).astype(np.float32)
+    bias = rng.normal(0, 0.5, M).astype(np.float32)
+    x = (rng.standard_normal((B, Cc, H, W)) + 0.3).astype(np.float32)
+    d = D.conv(B, W, H, Cc, M, 3, 1, 1, act, wts, bias)
+    lib.yl_debug_force_conv_tile(30)
+    try:
+        net = _net_from([d], B, W, H, Cc)
+        got = net.predict(x)
+        assert "wino" in net.layer_kernel(0)
+    finally:
+        lib.yl_debug_force_conv_tile(0)
+    ref = np.zeros(B * d.outputs, dtype=np.float32)
+    olib.oracle_conv_f32(fp(x), fp(wts), fp(bias), fp(ref), B, Cc, H, W, M, 3, 1, 1, act)
+    ok, ratio, worst = fp32_close(got, ref)
+    assert ok, "shape %r: err/allowed %.3g at %d: got %r ref %r" % (shape, ratio, worst, got[worst], ref[worst])
+    assert ratio < 0.2         # measured ~0.03: the transforms add/subtract only
+    # the direct kernel on the same layer agrees to roundoff as well
+    lib.yl_debug_force_conv_tile(14)
+    try:
+        direct = net.predict(x)
+        assert "wino" not in net.layer_kernel(0)
+    finally:
+        lib.yl_debug_force_conv_tile(0)
+    ok2, ratio2, _ = fp32_close(got, direct)
+    assert ok2 and ratio2 < 0.2
+    net.close()
+
+
+def test_winograd_switch_off_keeps_direct_kernel():
+    rng = np.random.default_rng(1)
+    B, Cc, H, W, M = 1, 32, 12, 12, 64
+    wts = rng.normal(0, 0.05, M * Cc * 9).astype(np.float32)
+    d = D.conv(B, W, H, Cc, M, 3, 1, 1, D.LEAKY, wts, np.zeros(M, np.float32))
+    x = rng.standard_normal((B, Cc, H, W)).astype(np.float32)
+    lib.yl_debug_set_winograd(0)
+    try:
+        net = _net_from([d], B, W, H, Cc)
+        net.predict(x)
+        assert "wino" not in net.layer_kernel(0)
+        net.close()
+    finally:
+        lib.yl_debug_set_winograd(1)
+    net = _net_from([d], B, W, H, Cc)
+    net.predict(x)
+    assert "wino" in net.layer_kernel(0)
+    net.close()
+
+
 def test_conv_f32_asymmetric_identity(olib):
     """Transpose-detecting check: A = identity-like 1x1 weights with an asymmetric
     image must come back exactly (catches a swapped C/D fragment map)."""

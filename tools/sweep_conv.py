@@ -30,8 +30,8 @@ SHAPES_608 = [
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--tiles", default="0,11,12,13,16,17,19,20,21,22",
-                    help="forced tile ids: 1..8 = v1 kernel, 11..19 = v2 pipelined kernel, 0 = heuristic")
+    ap.add_argument("--tiles", default="0,12,14,20,22,30",
+                    help="forced tile ids: 1..8 = v1 kernel, 11..19 = v2 pipelined kernel, 0 = heuristic, 30 = Winograd (3x3/1/1 only)")
     ap.add_argument("--variant", type=int, default=1, help="0 = v1 (c-major weights), 1 = v2 (tap-major where possible)")
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--only", default="", help="comma list of shape indices")

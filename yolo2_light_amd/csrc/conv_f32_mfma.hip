@@ -306,8 +306,15 @@ static int g_variant = 1;      // 0 = v1 burst schedule, 1 = v2 software-pipelin
 void conv_f32_set_variant(int v) { g_variant = v; }
 int conv_f32_get_variant() { return g_variant; }
 
+static int g_winograd = 1;
+void conv_f32_set_winograd(int mode) { g_winograd = mode; }
+int conv_f32_get_winograd() { return g_winograd; }
+
 int launch_conv_f32(const ConvF32Args &a, void *stream)
 {
+    if (a.wino_u && ((g_force_tile == 0 && g_winograd) || g_force_tile == 30))
+        return launch_conv_f32_wino(a, a.wino_u, stream, g_last_tile, sizeof(g_last_tile));
+    if (g_force_tile == 30) return (int)hipErrorInvalidValue;      // Winograd forced on a layer without packed U
     if (a.tapmajor || g_variant >= 1) {
         int cfg = g_force_tile >= 10 ? g_force_tile - 10 : 0;
         if (cfg == 0) {

@@ -19,6 +19,7 @@ struct ConvF32Args {
     int size, stride, pad;
     int act;              // YL_LINEAR / YL_LEAKY
     int tapmajor;         // K order of `wt`: 0 = (c,ky,kx) like im2col_cpu, 1 = (ky,kx,c) (needs C % 16 == 0)
+    const float *wino_u;  // Winograd-packed weights (wino_pack_weights) or nullptr: 3x3/1/1 layers only
 };
 int launch_conv_f32(const ConvF32Args &a, void *stream);
 // force a tile config (0 = heuristic): used by the tile sweep in bench/tests
@@ -27,6 +28,15 @@ void conv_f32_set_variant(int v);
 int conv_f32_get_variant();
 int launch_conv_f32_v2(const ConvF32Args &a, int cfg, void *stream, char *name, size_t name_len);
 const char *conv_f32_last_tile_name();
+// K1w (conv_f32_wino.hip): Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 layers.
+// mode: 0 = never, 1 = wherever the packed weights exist (default); forced tile 30 = always, any
+// other forced tile = never (tile sweeps of the direct kernel)
+void conv_f32_set_winograd(int mode);
+int conv_f32_get_winograd();
+bool wino_applicable(int C, int M, int size, int stride, int pad);
+size_t wino_packed_floats(int C, int M);
+void wino_pack_weights(const float *w, int C, int M, float *dst);
+int launch_conv_f32_wino(const ConvF32Args &a, const float *u_packed, void *stream, char *name, size_t name_len);
 
 // ---- K2: INT8 path ----
 // K2a: x_q = clamp_abs((int16)(x*mult), 127), FP32 NCHW -> int8 NHWC(Cpad)   (quantized.c:554-560)

@@ -51,6 +51,8 @@ static void free_device(Network &net)
         if (l.d_output && !l.d_output_alias) (void)hipFree(l.d_output);
         l.d_output = nullptr;
         if (l.d_weights_t) (void)hipFree(l.d_weights_t);
+        if (l.d_wino_u) (void)hipFree(l.d_wino_u);
+        l.d_wino_u = nullptr;
         if (l.d_biases) (void)hipFree(l.d_biases);
         if (l.d_weights_i8) (void)hipFree(l.d_weights_i8);
         if (l.d_weights_bits) (void)hipFree(l.d_weights_bits);
@@ -124,6 +126,16 @@ static int upload_conv(Network &net, Layer &l)
                 }
         YL_HIP(hipMalloc((void **)&l.d_weights_t, wt.size() * sizeof(float)));
         YL_HIP(hipMemcpy(l.d_weights_t, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+        // 3x3 / stride 1 / pad 1: also the Winograd F(2x2,3x3) form of the same weights (K1w).
+        // Not for the xnor fallback: its +-mean weights would pick up G's halves and the layer is
+        // specified by the reference as an exact +-1 GEMM.
+        if (conv_f32_get_winograd() && !xnor_fallback && wino_applicable(l.c, M, l.size, l.stride, l.pad) &&
+            l.out_h == l.h && l.out_w == l.w && l.h >= 4 && l.w >= 4) {
+            std::vector<float> u(wino_packed_floats(l.c, M));
+            wino_pack_weights(l.weights.data(), l.c, M, u.data());
+            YL_HIP(hipMalloc((void **)&l.d_wino_u, u.size() * sizeof(float)));
+            YL_HIP(hipMemcpy(l.d_wino_u, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     } else if (l.conv_mode == CONV_INT8) {
         if (!l.quant_ready) { set_error("INT8 layer without yl_network_quantize()"); return YL_ERR_STATE; }
         // k-major panels of 16-byte units [K16pad][Mpad][16], K16 index = tap*G + cg, zero padded;
@@ -321,6 +333,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.K = l.size * l.size * l.c; a.Kpad = l.Kpad; a.Mpad = l.Mpad;
             a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
             a.tapmajor = l.tapmajor;
+            a.wino_u = l.d_wino_u;
             YL_LAUNCH(launch_conv_f32(a, s), "conv_f32");
             l.kernel_name = conv_f32_last_tile_name();
         } else if (l.conv_mode == CONV_INT8) {
@@ -808,6 +821,7 @@ int yl_network_get_boxes(yl_network *net, int image, int w, int h, float thresh,
 
 int yl_debug_force_conv_tile(int cfg) { conv_f32_force_tile(cfg); return YL_OK; }
 int yl_debug_set_conv_variant(int v) { conv_f32_set_variant(v); return YL_OK; }
+int yl_debug_set_winograd(int mode) { conv_f32_set_winograd(mode); return YL_OK; }
 const char *yl_debug_last_conv_tile(void) { return conv_f32_last_tile_name(); }
 
 static int check_image_args(yl_network *net, int image, const void *pixels, int w, int h, int c)

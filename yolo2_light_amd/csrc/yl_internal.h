@@ -48,6 +48,7 @@ struct Layer {
     float *d_biases = nullptr;
     int   Kpad = 0, Mpad = 0;
     int   tapmajor = 0;                  // K order of d_weights_t (see conv_f32_mfma_v2.hip)
+    float *d_wino_u = nullptr;           // FP32 3x3/1/1: Winograd-packed U (conv_f32_wino.hip), else nullptr
     int8_t *d_weights_i8 = nullptr;      // INT8: [Mpad][taps][Cpad] (channel-fastest)
     int   Cpad = 0;
     uint64_t *d_weights_bits = nullptr;  // XNOR: [Mpad][taps][Cw] 64-bit words
