@@ -96,7 +96,8 @@ WINO_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", WINO_SHAPES)
-def test_conv_winograd_vs_oracle(olib, shape):
+@pytest.mark.parametrize("wtile", [30, 31])        # 64-filter tiling / 32-filter two-workgroups-per-CU tiling
+def test_conv_winograd_vs_oracle(olib, shape, wtile):
     B, Cc, H, W, M, act = shape
     rng = np.random.default_rng(99 + M + H)
     K = Cc * 9
@@ -104,7 +105,7 @@ def test_conv_winograd_vs_oracle(olib, shape):
     bias = rng.normal(0, 0.5, M).astype(np.float32)
     x = (rng.standard_normal((B, Cc, H, W)) + 0.3).astype(np.float32)
     d = D.conv(B, W, H, Cc, M, 3, 1, 1, act, wts, bias)
-    lib.yl_debug_force_conv_tile(30)
+    lib.yl_debug_force_conv_tile(wtile)
     try:
         net = _net_from([d], B, W, H, Cc)
         got = net.predict(x)

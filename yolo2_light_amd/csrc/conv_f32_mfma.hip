@@ -312,9 +312,14 @@ int conv_f32_get_winograd() { return g_winograd; }
 
 int launch_conv_f32(const ConvF32Args &a, void *stream)
 {
-    if (a.wino_u && ((g_force_tile == 0 && g_winograd) || g_force_tile == 30))
+    // measured on MI355X (tools/sweep_conv.py, yolov3-608 shapes, B=64): the 32-filter tiling (two
+    // workgroups per CU) beats the 64-filter one by ~5 % everywhere; with only 32 input channels
+    // (4 panels per workgroup) prologue + epilogue dominate and the direct kernel wins
+    if (a.wino32_u && (g_force_tile == 31 || (g_force_tile == 0 && g_winograd && a.C >= 64)))
+        return launch_conv_f32_wino32(a, a.wino32_u, stream, g_last_tile, sizeof(g_last_tile));
+    if (a.wino_u && g_force_tile == 30)
         return launch_conv_f32_wino(a, a.wino_u, stream, g_last_tile, sizeof(g_last_tile));
-    if (g_force_tile == 30) return (int)hipErrorInvalidValue;      // Winograd forced on a layer without packed U
+    if (g_force_tile == 30 || g_force_tile == 31) return (int)hipErrorInvalidValue;   // forced on a layer without packed U
     if (a.tapmajor || g_variant >= 1) {
         int cfg = g_force_tile >= 10 ? g_force_tile - 10 : 0;
         if (cfg == 0) {

@@ -1,0 +1,388 @@
+// conv_f32_wino32.hip -- K1w, second tiling: Winograd F(2x2,3x3) with TWO workgroups per CU.
+//
+// Same mathematics, transforms and rounding points as conv_f32_wino.hip (read its header first).
+// That kernel gives every wave all 16 planes of a 32x32 block (256 accumulator registers): one
+// wave per SIMD and one workgroup per CU, so nothing overlaps a workgroup's prologue, its epilogue
+// or a memory stall (PMC: matrix pipe busy 47 % of the time).  Here a workgroup is 32 filters x 64
+// tiles, a wave owns HALF of the planes (8 x 16 = 128 AccVGPRs <= 256 registers in total), panels
+// are 4 channels and the LDS stage is 24 KB: two workgroups are resident per CU (2 waves per SIMD)
+// and run out of phase.  Price: the U slice is re-read per 32 instead of 64 filters.
+//
+//   waves: wt = wave & 1 -> tiles [32*wt, +32);  ph = wave >> 1 -> planes [8*ph, +8)
+//   LDS:   A[xi][half][m 32][kk 2]   one ds_read_b64 per plane and panel
+//          B[xi][half][kk 2][t 64]   two ds_read_b32
+//   epilogue: row i of A^T M A needs planes of both halves, so the two waves of a tile half swap
+//          partial row sums through LDS (the dead panel buffers), each finishing 8 of the 16
+//          accumulator rows: tmp0 = (M0 + M1) + M2, tmp1 = M1 - (M2 + M3), then the column pass.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+#include "kernels.h"
+#include "../../include/yolo2_hip.h"
+
+namespace yl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4v __attribute__((__vector_size__(16)));   // see conv_f32_wino.hip
+
+namespace {
+
+constexpr int XBM = 32;
+constexpr int XBT = 64;
+constexpr int XBK = 4;
+constexpr int XPA = 16 * XBK * XBM;      // floats per A panel = 2048 (8 KB)
+constexpr int XPB = 16 * XBK * XBT;      // floats per B panel = 4096 (16 KB)
+
+struct ConvWino32Dev {
+    const float *in;
+    const float *u;        // packed U: [tile_m][panel][xi][half][m 32][kk 2]
+    const float *bias;
+    const float *add;
+    float *out_add;
+    float *out;
+    int B, C, H, W, M;
+    int th, tw, tpi, T;
+    int tiles_m, tiles_t, nkb;
+    int act;
+};
+
+__device__ __forceinline__ void fix_rows32(float (&d)[16], bool left, bool inv2, bool inv3)
+{
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float x = d[r * 4 + 0], y = d[r * 4 + 1], z = d[r * 4 + 2], w = d[r * 4 + 3];
+        d[r * 4 + 0] = left ? 0.f : x;
+        d[r * 4 + 1] = left ? x : y;
+        const float c2 = left ? y : z;
+        const float c3 = left ? z : w;
+        d[r * 4 + 2] = inv2 ? 0.f : c2;
+        d[r * 4 + 3] = inv3 ? 0.f : c3;
+    }
+}
+
+__device__ __forceinline__ void input_transform32(const float (&d)[16], float (&v)[16])
+{
+    float w[16];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        w[0 * 4 + s] = d[0 * 4 + s] - d[2 * 4 + s];
+        w[1 * 4 + s] = d[1 * 4 + s] + d[2 * 4 + s];
+        w[2 * 4 + s] = d[2 * 4 + s] - d[1 * 4 + s];
+        w[3 * 4 + s] = d[1 * 4 + s] - d[3 * 4 + s];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[i * 4 + 0] = w[i * 4 + 0] - w[i * 4 + 2];
+        v[i * 4 + 1] = w[i * 4 + 1] + w[i * 4 + 2];
+        v[i * 4 + 2] = w[i * 4 + 2] - w[i * 4 + 1];
+        v[i * 4 + 3] = w[i * 4 + 1] - w[i * 4 + 3];
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p)
+{
+    __shared__ __attribute__((aligned(16))) float smem[2 * XPA + 2 * XPB];      // 48 KB
+    float *As = smem;
+    float *Bs = smem + 2 * XPA;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    constexpr int GT = 8;
+    const int per_group = GT * p.tiles_m;
+    const int tg = logical / per_group;
+    const int rem_g = logical - tg * per_group;
+    const int t_in_last = p.tiles_t - tg * GT;
+    const int gsz = t_in_last < GT ? t_in_last : GT;
+    const int tile_m = __builtin_amdgcn_readfirstlane(rem_g / gsz);
+    const int tile_t = __builtin_amdgcn_readfirstlane(tg * GT + (rem_g - tile_m * gsz));
+    const int m0 = tile_m * XBM;
+    const int t0 = tile_t * XBT;
+
+    const int HW = p.H * p.W;
+    const int CHW = p.C * HW;
+
+    // ---- staging role: tile t_s, channel `wave` of every panel (half = wave & 1, kk = wave >> 1) ----
+    const int t_s = tid & 63;
+    const int half_s = wave & 1;
+    const int kk_s = wave >> 1;
+    const int tg_s = t0 + t_s;
+    const bool t_ok = tg_s < p.T;
+    const int b_s = t_ok ? tg_s / p.tpi : 0;
+    const int r_s = tg_s - b_s * p.tpi;
+    const int ti_s = r_s / p.tw;
+    const int tj_s = r_s - ti_s * p.tw;
+
+    const int b_first = __builtin_amdgcn_readfirstlane(t0 / p.tpi);
+    const float *tile_base = p.in + (size_t)b_first * CHW - (ptrdiff_t)(p.W + 1);
+    size_t rec = ((size_t)p.B - b_first) * CHW * sizeof(float) + (size_t)(p.W + 1) * sizeof(float);
+    if (rec > 0xFFFFFFFEull) rec = 0xFFFFFFFEull;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void *)tile_base, 0, (int)(unsigned)rec, 0x00020000);
+    int pvr[4];
+    const bool left_s = (tj_s == 0);
+    const bool inv2_s = (2 * tj_s + 1 >= p.W);
+    const bool inv3_s = (2 * tj_s + 2 >= p.W);
+    {
+        const unsigned base = ((unsigned)(b_s - b_first) * (unsigned)CHW + (unsigned)(2 * ti_s) * (unsigned)p.W +
+                               (unsigned)(2 * tj_s) + (left_s ? 1u : 0u)) * 4u;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int iy = 2 * ti_s - 1 + rr;
+            const bool ok = t_ok && iy >= 0 && iy < p.H;
+            pvr[rr] = ok ? (int)(base + (unsigned)(rr * p.W) * 4u) : -1;
+        }
+    }
+    const float *u_tile = p.u + (size_t)tile_m * p.nkb * XPA;
+
+    float xr[16];
+    float ur[2][4];
+
+#define X_LOAD_X(KB)                                                                               \
+    {                                                                                              \
+        const int s0 = ((KB) * XBK + wave) * HW * 4;                                               \
+        _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                         \
+            const u32x4v q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, pvr[rr], s0, 0);         \
+            xr[rr * 4 + 0] = __uint_as_float(q0[0]); xr[rr * 4 + 1] = __uint_as_float(q0[1]);      \
+            xr[rr * 4 + 2] = __uint_as_float(q0[2]); xr[rr * 4 + 3] = __uint_as_float(q0[3]);      \
+        }                                                                                          \
+    }
+#define X_LOAD_U(KB)                                                                               \
+    {                                                                                              \
+        const float4 *src = reinterpret_cast<const float4 *>(u_tile + (size_t)(KB) * XPA);         \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                            \
+            const float4 t4 = src[tid + e * 256];                                                  \
+            ur[e][0] = t4.x; ur[e][1] = t4.y; ur[e][2] = t4.z; ur[e][3] = t4.w;                    \
+        }                                                                                          \
+    }
+#define X_STORE_X(BUF)                                                                             \
+    {                                                                                              \
+        float va[16];                                                                              \
+        fix_rows32(xr, left_s, inv2_s, inv3_s);                                                    \
+        input_transform32(xr, va);                                                                 \
+        float *dst = Bs + (BUF) * XPB + half_s * 128 + kk_s * 64 + t_s;                            \
+        _Pragma("unroll") for (int xi = 0; xi < 16; ++xi) dst[xi * 256] = va[xi];                  \
+    }
+#define X_STORE_U(BUF)                                                                             \
+    {                                                                                              \
+        float4 *dst = reinterpret_cast<float4 *>(As + (BUF) * XPA);                                \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e)                                              \
+            dst[tid + e * 256] = make_float4(ur[e][0], ur[e][1], ur[e][2], ur[e][3]);              \
+    }
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[pp][e] = 0.f;
+
+    const int wt = wave & 1;
+    const int ph = wave >> 1;
+
+    // ---- prologue: panel 0 -> LDS stage 0, panel 1 -> registers ----
+    X_LOAD_X(0)
+    X_LOAD_U(0)
+    X_STORE_X(0)
+    X_STORE_U(0)
+    if (p.nkb > 1) {
+        X_LOAD_X(1)
+        X_LOAD_U(1)
+    }
+    __syncthreads();
+
+    // one panel; DO_STORE: registers (panel kb+1) -> LDS[buf^1]; DO_LOAD: panel kb+2 -> registers
+#define X_ITER(KB, DO_STORE, DO_LOAD)                                                              \
+    {                                                                                              \
+        const int buf = (KB) & 1;                                                                  \
+        const float *Ab = As + buf * XPA + (8 * ph) * 128 + half * 64 + l31 * 2;                   \
+        const float *Bb = Bs + buf * XPB + (8 * ph) * 256 + half * 128 + wt * 32 + l31;            \
+        float2 fa[8];                                                                              \
+        float fb[8][2];                                                                            \
+        _Pragma("unroll") for (int pp = 0; pp < 8; ++pp) {                                         \
+            fa[pp] = *reinterpret_cast<const float2 *>(Ab + pp * 128);                             \
+            fb[pp][0] = Bb[pp * 256];                                                              \
+            fb[pp][1] = Bb[pp * 256 + 64];                                                         \
+        }                                                                                          \
+        if (DO_STORE) X_STORE_X(buf ^ 1)                                                           \
+        _Pragma("unroll") for (int pp = 0; pp < 8; ++pp)                                           \
+            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pp].x, fb[pp][0], acc[pp], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (DO_LOAD) X_LOAD_X((KB) + 2)                                                            \
+        if (DO_STORE) X_STORE_U(buf ^ 1)                                                           \
+        if (DO_LOAD) X_LOAD_U((KB) + 2)                                                            \
+        _Pragma("unroll") for (int pp = 0; pp < 8; ++pp)                                           \
+            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pp].y, fb[pp][1], acc[pp], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        __syncthreads();                                                                           \
+    }
+
+    int kb = 0;
+    for (; kb + 2 < p.nkb; ++kb) X_ITER(kb, true, true)
+    if (kb + 1 < p.nkb) { X_ITER(kb, true, false) ++kb; }
+    if (kb < p.nkb) X_ITER(kb, false, false)
+#undef X_ITER
+#undef X_STORE_U
+#undef X_STORE_X
+#undef X_LOAD_U
+#undef X_LOAD_X
+
+    // ---- epilogue ----
+    // wave (wt, ph) holds M[i][j] for rows i = 2*ph, 2*ph+1 (planes 8*ph + 4*(i&1) + j) of the
+    // 32x32 (m, t) block of tile half wt.  Exchange buffer: xch[wave][32][64] floats (32 KB) in the
+    // dead panel stages (the loop's last barrier has passed).
+    float *xch = smem;
+    const int tg_e = t0 + wt * 32 + l31;
+    const bool t_ok_e = tg_e < p.T;
+    const int b_e = t_ok_e ? tg_e / p.tpi : 0;
+    const int r_e = tg_e - b_e * p.tpi;
+    const int ti_e = r_e / p.tw;
+    const int tj_e = r_e - ti_e * p.tw;
+    const int oy = 2 * ti_e, ox = 2 * tj_e;
+    const bool row1 = oy + 1 < p.H;
+    const bool col1 = ox + 1 < p.W;
+    const bool vec2 = col1 && ((p.W & 1) == 0);
+    float *mine = xch + wave * 2048 + lane;
+    const float *theirs = xch + (wave ^ 2) * 2048 + lane;
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        // send: ph 1 gives (M2, M2 + M3) of rows e = 8*rnd .. +3; ph 0 gives (M0 + M1, M1) of e = 8*rnd+4 .. +7
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+            const int e = 8 * rnd + (ph ? ee : 4 + ee);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = acc[j][e], hi = acc[4 + j][e];
+                mine[(ee * 8 + j) * 64] = ph ? lo : (lo + hi);
+                mine[(ee * 8 + 4 + j) * 64] = ph ? (lo + hi) : hi;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+            const int e = 8 * rnd + (ph ? 4 + ee : ee);
+            const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            float tmp[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float g0 = theirs[(ee * 8 + j) * 64], g1 = theirs[(ee * 8 + 4 + j) * 64];
+                const float lo = acc[j][e], hi = acc[4 + j][e];
+                if (ph) {            // have M2 = lo, M3 = hi; got M0 + M1, M1
+                    tmp[0][j] = g0 + lo;
+                    tmp[1][j] = g1 - (lo + hi);
+                } else {             // have M0 = lo, M1 = hi; got M2, M2 + M3
+                    tmp[0][j] = (lo + hi) + g0;
+                    tmp[1][j] = hi - g1;
+                }
+            }
+            if (m < p.M && t_ok_e) {
+                const float bv = p.bias[m];
+                float y[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    y[i][0] = ((tmp[i][0] + tmp[i][1]) + tmp[i][2]) + bv;
+                    y[i][1] = ((tmp[i][1] - tmp[i][2]) - tmp[i][3]) + bv;
+                    if (p.act == YL_LEAKY) {
+                        y[i][0] = (y[i][0] > 0.f) ? y[i][0] : (float)(.1 * (double)y[i][0]);
+                        y[i][1] = (y[i][1] > 0.f) ? y[i][1] : (float)(.1 * (double)y[i][1]);
+                    }
+                }
+                const size_t o0 = (((size_t)b_e * p.M + m) * p.H + oy) * p.W + ox;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (i == 1 && !row1) break;
+                    const size_t o = o0 + (size_t)i * p.W;
+                    if (vec2) {
+                        if (p.out) *reinterpret_cast<float2 *>(p.out + o) = make_float2(y[i][0], y[i][1]);
+                        if (p.add) {
+                            const float2 a = *reinterpret_cast<const float2 *>(p.add + o);
+                            *reinterpret_cast<float2 *>(p.out_add + o) =
+                                make_float2(__fadd_rn(y[i][0], a.x), __fadd_rn(y[i][1], a.y));
+                        }
+                    } else {
+                        if (p.out) { p.out[o] = y[i][0]; if (col1) p.out[o + 1] = y[i][1]; }
+                        if (p.add) {
+                            p.out_add[o] = __fadd_rn(y[i][0], p.add[o]);
+                            if (col1) p.out_add[o + 1] = __fadd_rn(y[i][1], p.add[o + 1]);
+                        }
+                    }
+                }
+            }
+        }
+        if (rnd == 0) __syncthreads();
+    }
+}
+
+size_t wino32_packed_floats(int C, int M)
+{
+    const int tiles_m = (M + XBM - 1) / XBM;
+    return (size_t)tiles_m * (C / XBK) * XPA;
+}
+
+// U = G g G^T (double, rounded once), packed [tile_m][panel][xi][half][m 32][kk 2]; k = panel*4 + 2*kk + half
+void wino32_pack_weights(const float *w, int C, int M, float *dst)
+{
+    static const double G[4][3] = {{1., 0., 0.}, {.5, .5, .5}, {.5, -.5, .5}, {0., 0., 1.}};
+    const int tiles_m = (M + XBM - 1) / XBM;
+    const int nkb = C / XBK;
+    for (int tm = 0; tm < tiles_m; ++tm)
+        for (int kb = 0; kb < nkb; ++kb) {
+            float *panel = dst + ((size_t)tm * nkb + kb) * XPA;
+            for (int ml = 0; ml < XBM; ++ml) {
+                const int m = tm * XBM + ml;
+                for (int kl = 0; kl < XBK; ++kl) {
+                    const int c = kb * XBK + kl;
+                    const int hf = kl & 1, kk = kl >> 1;
+                    double u[4][4];
+                    if (m < M) {
+                        const float *g = w + ((size_t)m * C + c) * 9;
+                        double t[4][3];
+                        for (int i = 0; i < 4; ++i)
+                            for (int b = 0; b < 3; ++b)
+                                t[i][b] = G[i][0] * g[0 * 3 + b] + G[i][1] * g[1 * 3 + b] + G[i][2] * g[2 * 3 + b];
+                        for (int i = 0; i < 4; ++i)
+                            for (int j = 0; j < 4; ++j)
+                                u[i][j] = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+                    } else {
+                        for (int i = 0; i < 4; ++i)
+                            for (int j = 0; j < 4; ++j) u[i][j] = 0.;
+                    }
+                    for (int xi = 0; xi < 16; ++xi)
+                        panel[xi * 128 + hf * 64 + ml * 2 + kk] = (float)u[xi >> 2][xi & 3];
+                }
+            }
+        }
+}
+
+int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, void *stream, char *name, size_t name_len)
+{
+    if (!wino_applicable(a.C, a.M, a.size, a.stride, a.pad) || a.OH != a.H || a.OW != a.W || a.H < 4 || a.W < 4)
+        return (int)hipErrorInvalidValue;
+    ConvWino32Dev d;
+    d.in = a.in; d.u = u_packed; d.bias = a.bias; d.add = a.add; d.out_add = a.out_add; d.out = a.out;
+    d.B = a.B; d.C = a.C; d.H = a.H; d.W = a.W; d.M = a.M;
+    d.th = (a.H + 1) / 2; d.tw = (a.W + 1) / 2; d.tpi = d.th * d.tw;
+    const long long T = (long long)a.B * d.tpi;
+    if (T > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    d.T = (int)T;
+    d.tiles_m = (a.M + XBM - 1) / XBM;
+    d.tiles_t = (int)((T + XBT - 1) / XBT);
+    d.nkb = a.C / XBK;
+    d.act = a.act;
+    const long long blocks = (long long)d.tiles_m * d.tiles_t;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(conv_f32_wino32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d);
+    if (name) snprintf(name, name_len, "conv_f32_wino<32x64t,f2x2>");
+    return (int)hipGetLastError();
+}
+
+}  // namespace yl

@@ -20,6 +20,7 @@ struct ConvF32Args {
     int act;              // YL_LINEAR / YL_LEAKY
     int tapmajor;         // K order of `wt`: 0 = (c,ky,kx) like im2col_cpu, 1 = (ky,kx,c) (needs C % 16 == 0)
     const float *wino_u;  // Winograd-packed weights (wino_pack_weights) or nullptr: 3x3/1/1 layers only
+    const float *wino32_u; // the same for the 32-filter tiling (wino32_pack_weights) or nullptr
 };
 int launch_conv_f32(const ConvF32Args &a, void *stream);
 // force a tile config (0 = heuristic): used by the tile sweep in bench/tests
@@ -37,6 +38,10 @@ bool wino_applicable(int C, int M, int size, int stride, int pad);
 size_t wino_packed_floats(int C, int M);
 void wino_pack_weights(const float *w, int C, int M, float *dst);
 int launch_conv_f32_wino(const ConvF32Args &a, const float *u_packed, void *stream, char *name, size_t name_len);
+// second tiling (conv_f32_wino32.hip): 32 filters x 64 tiles, two workgroups per CU; forced tile 31
+size_t wino32_packed_floats(int C, int M);
+void wino32_pack_weights(const float *w, int C, int M, float *dst);
+int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, void *stream, char *name, size_t name_len);
 
 // ---- K2: INT8 path ----
 // K2a: x_q = clamp_abs((int16)(x*mult), 127), FP32 NCHW -> int8 NHWC(Cpad)   (quantized.c:554-560)

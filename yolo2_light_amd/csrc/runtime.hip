@@ -52,7 +52,8 @@ static void free_device(Network &net)
         l.d_output = nullptr;
         if (l.d_weights_t) (void)hipFree(l.d_weights_t);
         if (l.d_wino_u) (void)hipFree(l.d_wino_u);
-        l.d_wino_u = nullptr;
+        if (l.d_wino32_u) (void)hipFree(l.d_wino32_u);
+        l.d_wino_u = nullptr; l.d_wino32_u = nullptr;
         if (l.d_biases) (void)hipFree(l.d_biases);
         if (l.d_weights_i8) (void)hipFree(l.d_weights_i8);
         if (l.d_weights_bits) (void)hipFree(l.d_weights_bits);
@@ -135,6 +136,10 @@ static int upload_conv(Network &net, Layer &l)
             wino_pack_weights(l.weights.data(), l.c, M, u.data());
             YL_HIP(hipMalloc((void **)&l.d_wino_u, u.size() * sizeof(float)));
             YL_HIP(hipMemcpy(l.d_wino_u, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice));
+            std::vector<float> u32(wino32_packed_floats(l.c, M));
+            wino32_pack_weights(l.weights.data(), l.c, M, u32.data());
+            YL_HIP(hipMalloc((void **)&l.d_wino32_u, u32.size() * sizeof(float)));
+            YL_HIP(hipMemcpy(l.d_wino32_u, u32.data(), u32.size() * sizeof(float), hipMemcpyHostToDevice));
         }
     } else if (l.conv_mode == CONV_INT8) {
         if (!l.quant_ready) { set_error("INT8 layer without yl_network_quantize()"); return YL_ERR_STATE; }
@@ -334,6 +339,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
             a.tapmajor = l.tapmajor;
             a.wino_u = l.d_wino_u;
+            a.wino32_u = l.d_wino32_u;
             YL_LAUNCH(launch_conv_f32(a, s), "conv_f32");
             l.kernel_name = conv_f32_last_tile_name();
         } else if (l.conv_mode == CONV_INT8) {

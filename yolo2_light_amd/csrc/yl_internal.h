@@ -49,6 +49,7 @@ struct Layer {
     int   Kpad = 0, Mpad = 0;
     int   tapmajor = 0;                  // K order of d_weights_t (see conv_f32_mfma_v2.hip)
     float *d_wino_u = nullptr;           // FP32 3x3/1/1: Winograd-packed U (conv_f32_wino.hip), else nullptr
+    float *d_wino32_u = nullptr;         // the same for conv_f32_wino32.hip
     int8_t *d_weights_i8 = nullptr;      // INT8: [Mpad][taps][Cpad] (channel-fastest)
     int   Cpad = 0;
     uint64_t *d_weights_bits = nullptr;  // XNOR: [Mpad][taps][Cw] 64-bit words
