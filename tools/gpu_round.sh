@@ -60,7 +60,7 @@ if has sweep; then
 fi
 if has prof; then
   echo "== rocprofv3 kernel stats" | tee -a $OUT/summary.txt
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/rocprof -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e > $R/$OUT/rocprof_run.log 2>&1 )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/rocprof -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --raw-head --nms 0 > $R/$OUT/rocprof_run.log 2>&1 )
   echo "rocprof exit $?" | tee -a $OUT/summary.txt
   F=$(find $OUT/rocprof -name "*kernel_stats.csv" | head -1)
   [ -n "$F" ] && head -14 "$F" | cut -c1-200
@@ -71,7 +71,7 @@ if has pmc; then
   rocprofv3 -L > $OUT/pmc_list.txt 2>&1
   for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA"; do
     N=$(echo $C | tr ' ' '_' | cut -c1-40)
-    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmc_$N -o pmc -- python $R/bench.py --steps 1 --warmup 0 --batch 16 --no-cpu-baseline --no-e2e > $R/$OUT/pmc_$N.log 2>&1 )
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmc_$N -o pmc -- python $R/bench.py --steps 1 --warmup 0 --batch 16 --no-cpu-baseline --no-e2e --raw-head --nms 0 > $R/$OUT/pmc_$N.log 2>&1 )
     echo "pmc $N exit $?" | tee -a $OUT/summary.txt
   done
   python tools/pmc_summary.py $OUT > $OUT/pmc_summary.txt 2>&1
@@ -81,7 +81,7 @@ if has pmc; then
 fi
 if has dist1; then
   echo "== bench through torch.distributed.run, world 1 (RCCL all-gather path)" | tee -a $OUT/summary.txt
-  timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-e2e > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err
+  timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --raw-head --nms 0 > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err
   echo "dist1 exit $?" | tee -a $OUT/summary.txt
   tail -2 $OUT/bench_dist1.json | cut -c1-400
   tail -3 $OUT/bench_dist1.err
@@ -89,7 +89,7 @@ fi
 if has pmc64; then
   echo "== rocprofv3 HBM traffic counters at the bench batch (64)" | tee -a $OUT/summary.txt
   for C in "FETCH_SIZE" "WRITE_SIZE"; do
-    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmc64_$C -o pmc -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e > $R/$OUT/pmc64_$C.log 2>&1 )
+    ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmc64_$C -o pmc -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --raw-head --nms 0 > $R/$OUT/pmc64_$C.log 2>&1 )
     echo "pmc64 $C exit $?" | tee -a $OUT/summary.txt
   done
   python tools/pmc_summary.py $OUT > $OUT/pmc64_summary.txt 2>&1
