@@ -55,8 +55,11 @@ def main():
         wts = rng.normal(0, np.sqrt(2.0 / K), M * K).astype(np.float32)
         bias = rng.normal(0, 0.1, M).astype(np.float32)
         d = D.conv(B, H, H, Cc, M, size, stride, pad, D.LEAKY, wts, bias)
+        if 30 in tiles:                    # the 64-filter Winograd tiling is packed only while forced
+            lib.yl_debug_force_conv_tile(30)
         net = Network.from_desc([d], B, H, H, Cc)
         net.to_device(0)
+        lib.yl_debug_force_conv_tile(0)
         x = torch.rand((B, Cc, H, H), device="cuda:0", dtype=torch.float32) - 0.3
         flops = 2.0 * M * K * d.out_h * d.out_w * B
         best = None

@@ -285,6 +285,7 @@ static int g_force_tile = 0;
 static char g_last_tile[64] = "";
 static void set_tile_name(const char *t, int ks) { snprintf(g_last_tile, sizeof(g_last_tile), "conv_f32_mfma<%s,ks%d>", t, ks); }
 void conv_f32_force_tile(int cfg) { g_force_tile = cfg; }
+int conv_f32_forced_tile() { return g_force_tile; }
 const char *conv_f32_last_tile_name() { return g_last_tile; }
 
 template <int BM, int BN, int WM, int WN>
@@ -313,9 +314,9 @@ int conv_f32_get_winograd() { return g_winograd; }
 int launch_conv_f32(const ConvF32Args &a, void *stream)
 {
     // measured on MI355X (tools/sweep_conv.py, yolov3-608 shapes, B=64): the 32-filter tiling (two
-    // workgroups per CU) beats the 64-filter one by ~5 % everywhere; with only 32 input channels
-    // (4 panels per workgroup) prologue + epilogue dominate and the direct kernel wins
-    if (a.wino32_u && (g_force_tile == 31 || (g_force_tile == 0 && g_winograd && a.C >= 64)))
+    // workgroups per CU) beats the 64-filter one by ~5 % everywhere and the direct kernel from 32 input
+    // channels up ([64,288,92416]: 1.59 vs 2.16 ms)
+    if (a.wino32_u && (g_force_tile == 31 || (g_force_tile == 0 && g_winograd && a.C >= 32)))
         return launch_conv_f32_wino32(a, a.wino32_u, stream, g_last_tile, sizeof(g_last_tile));
     if (a.wino_u && g_force_tile == 30)
         return launch_conv_f32_wino(a, a.wino_u, stream, g_last_tile, sizeof(g_last_tile));
@@ -331,7 +332,7 @@ int launch_conv_f32(const ConvF32Args &a, void *stream)
             // (TM=1,TN=4) for wider 3x3 layers; 64x128 / 32x256 for the narrow-M early layers;
             // layers too small to give every CU two workgroups fall back to 64x64 tiles.
             if (a.M <= 32) cfg = 3;
-            else if (a.M <= 64) cfg = 2;
+            else if (a.M <= 64) cfg = (a.size == 3) ? 4 : 2;      // 3x3 stride 2, M = 64: 64x64 2.34 ms vs 64x128 2.54
             else if (a.size == 1 || a.M <= 256) cfg = (nblocks(128, 128) >= 512) ? 12 : 4;
             else cfg = (nblocks(128, 256) >= 384) ? 10 : ((nblocks(128, 128) >= 512) ? 12 : 4);
             if (cfg <= 3 && nblocks(cfg == 2 ? 64 : 32, cfg == 3 ? 256 : 128) < 512) cfg = 4;

@@ -10,7 +10,9 @@
 //
 //   waves: wt = wave & 1 -> tiles [32*wt, +32);  ph = wave >> 1 -> planes [8*ph, +8)
 //   LDS:   A[xi][half][m 32][kk 2]   one ds_read_b64 per plane and panel
-//          B[xi][half][kk 2][t 64]   two ds_read_b32
+//          B[xi/2][half][kk 2][t 64][xi&1]   planes in pairs: the transform stores 8 float2 per patch
+//                                    (ds_write_b32 moves only 64 B/clk) and a wave reads two of its
+//                                    planes per ds_read_b64
 //   epilogue: row i of A^T M A needs planes of both halves, so the two waves of a tile half swap
 //          partial row sums through LDS (the dead panel buffers), each finishing 8 of the 16
 //          accumulator rows: tmp0 = (M0 + M1) + M2, tmp1 = M1 - (M2 + M3), then the column pass.
@@ -19,6 +21,12 @@
 
 #include "kernels.h"
 #include "../../include/yolo2_hip.h"
+
+// X_DBG (build-time timing experiments; results are garbage): 1 no X loads in the K loop, 2 no U loads,
+// 4 no transform / LDS stores, 8 no MFMAs
+#ifndef X_DBG
+#define X_DBG 0
+#endif
 
 namespace yl {
 
@@ -145,39 +153,50 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     }
     const float *u_tile = p.u + (size_t)tile_m * p.nkb * XPA;
 
-    float xr[16];
-    float ur[2][4];
+    // two staging register sets: a panel is loaded TWO iterations before it is transformed/stored,
+    // so an L2 miss (MALL/HBM, ~1-2 us) is covered by two panels of MFMAs of two workgroups
+    float xr0[16], xr1[16];
+    float ur0[2][4], ur1[2][4];
 
-#define X_LOAD_X(KB)                                                                               \
+#define X_LOAD_X(KB, XR)                                                                            \
     {                                                                                              \
         const int s0 = ((KB) * XBK + wave) * HW * 4;                                               \
         _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                         \
             const u32x4v q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, pvr[rr], s0, 0);         \
-            xr[rr * 4 + 0] = __uint_as_float(q0[0]); xr[rr * 4 + 1] = __uint_as_float(q0[1]);      \
-            xr[rr * 4 + 2] = __uint_as_float(q0[2]); xr[rr * 4 + 3] = __uint_as_float(q0[3]);      \
+            XR[rr * 4 + 0] = __uint_as_float(q0[0]); XR[rr * 4 + 1] = __uint_as_float(q0[1]);      \
+            XR[rr * 4 + 2] = __uint_as_float(q0[2]); XR[rr * 4 + 3] = __uint_as_float(q0[3]);      \
         }                                                                                          \
     }
-#define X_LOAD_U(KB)                                                                               \
+#define X_LOAD_U(KB, UR)                                                                               \
     {                                                                                              \
         const float4 *src = reinterpret_cast<const float4 *>(u_tile + (size_t)(KB) * XPA);         \
         _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                            \
             const float4 t4 = src[tid + e * 256];                                                  \
-            ur[e][0] = t4.x; ur[e][1] = t4.y; ur[e][2] = t4.z; ur[e][3] = t4.w;                    \
+            UR[e][0] = t4.x; UR[e][1] = t4.y; UR[e][2] = t4.z; UR[e][3] = t4.w;                    \
         }                                                                                          \
     }
-#define X_STORE_X(BUF)                                                                             \
+#define X_STORE_X(BUF, XR)                                                                             \
     {                                                                                              \
         float va[16];                                                                              \
-        fix_rows32(xr, left_s, inv2_s, inv3_s);                                                    \
-        input_transform32(xr, va);                                                                 \
-        float *dst = Bs + (BUF) * XPB + half_s * 128 + kk_s * 64 + t_s;                            \
-        _Pragma("unroll") for (int xi = 0; xi < 16; ++xi) dst[xi * 256] = va[xi];                  \
+        if (!(X_DBG & 32)) {                                                                       \
+            fix_rows32(XR, left_s, inv2_s, inv3_s);                                                \
+            input_transform32(XR, va);                                                             \
+        } else {                                                                                   \
+            _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) va[e_] = XR[e_];                     \
+        }                                                                                          \
+        float *dst = Bs + (BUF) * XPB + half_s * 256 + kk_s * 128 + t_s * 2;                       \
+        if (!(X_DBG & 16)) {                                                                       \
+            _Pragma("unroll") for (int pr = 0; pr < 8; ++pr)                                       \
+                *reinterpret_cast<float2 *>(dst + pr * 512) = make_float2(va[2 * pr], va[2 * pr + 1]); \
+        } else {                                                                                   \
+            _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) asm volatile("" ::"v"(va[e_]));      \
+        }                                                                                          \
     }
-#define X_STORE_U(BUF)                                                                             \
+#define X_STORE_U(BUF, UR)                                                                             \
     {                                                                                              \
         float4 *dst = reinterpret_cast<float4 *>(As + (BUF) * XPA);                                \
         _Pragma("unroll") for (int e = 0; e < 2; ++e)                                              \
-            dst[tid + e * 256] = make_float4(ur[e][0], ur[e][1], ur[e][2], ur[e][3]);              \
+            dst[tid + e * 256] = make_float4(UR[e][0], UR[e][1], UR[e][2], UR[e][3]);              \
     }
 
     f32x16 acc[8];
@@ -189,48 +208,74 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     const int wt = wave & 1;
     const int ph = wave >> 1;
 
-    // ---- prologue: panel 0 -> LDS stage 0, panel 1 -> registers ----
-    X_LOAD_X(0)
-    X_LOAD_U(0)
-    X_STORE_X(0)
-    X_STORE_U(0)
-    if (p.nkb > 1) {
-        X_LOAD_X(1)
-        X_LOAD_U(1)
-    }
+    // ---- prologue: panels 0, 1 -> register sets 0, 1; panel 0 -> LDS stage 0; panel 2 -> set 0 ----
+    // (nkb = C/4 is even and >= 4: the launcher requires C % 8 == 0, C >= 16)
+    X_LOAD_X(0, xr0)
+    X_LOAD_U(0, ur0)
+    X_LOAD_X(1, xr1)
+    X_LOAD_U(1, ur1)
+    X_STORE_X(0, xr0)
+    X_STORE_U(0, ur0)
+    X_LOAD_X(2, xr0)
+    X_LOAD_U(2, ur0)
     __syncthreads();
 
-    // one panel; DO_STORE: registers (panel kb+1) -> LDS[buf^1]; DO_LOAD: panel kb+2 -> registers
-#define X_ITER(KB, DO_STORE, DO_LOAD)                                                              \
+    // sched_group_barrier masks: 0x008 MFMA, 0x002 VALU, 0x020 VMEM read, 0x100 DS read, 0x200 DS write.
+    // The transform (~70 VALU + 8 LDS stores per panel) must sit INSIDE the shadow of this wave's own
+    // MFMAs: measured, a VALU block in front of the 8 MFMAs costs 0.24 ms of a 1.2 ms layer even with
+    // a second workgroup on the CU.
+#define X_PIPE(MASK, N) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
+#define X_ITER(KB, XR, UR, DO_STORE, DO_LOAD)                                                              \
     {                                                                                              \
         const int buf = (KB) & 1;                                                                  \
         const float *Ab = As + buf * XPA + (8 * ph) * 128 + half * 64 + l31 * 2;                   \
-        const float *Bb = Bs + buf * XPB + (8 * ph) * 256 + half * 128 + wt * 32 + l31;            \
+        const float *Bb = Bs + buf * XPB + (4 * ph) * 512 + half * 256 + (wt * 32 + l31) * 2;      \
         float2 fa[8];                                                                              \
         float fb[8][2];                                                                            \
-        _Pragma("unroll") for (int pp = 0; pp < 8; ++pp) {                                         \
+        _Pragma("unroll") for (int pp = 0; pp < 8; ++pp)                                           \
             fa[pp] = *reinterpret_cast<const float2 *>(Ab + pp * 128);                             \
-            fb[pp][0] = Bb[pp * 256];                                                              \
-            fb[pp][1] = Bb[pp * 256 + 64];                                                         \
+        _Pragma("unroll") for (int pr = 0; pr < 4; ++pr)                                           \
+            _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                     \
+                const float2 v2 = *reinterpret_cast<const float2 *>(Bb + pr * 512 + kk * 128);     \
+                fb[2 * pr][kk] = v2.x;                                                             \
+                fb[2 * pr + 1][kk] = v2.y;                                                         \
+            }                                                                                      \
+        /* first half: weights of panel kb+1 -> LDS, weights of panel kb+2 -> registers */         \
+        if (DO_STORE && !(X_DBG & 4)) X_STORE_U(buf ^ 1, UR)                                           \
+        if (DO_LOAD && !(X_DBG & 2)) X_LOAD_U((KB) + 3, UR)                                            \
+        _Pragma("unroll") for (int pp = 0; pp < 8; ++pp)                                           \
+            if (!(X_DBG & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pp].x, fb[pp][0], acc[pp], 0, 0, 0); \
+        if (DO_STORE && X_DBG == 0) {                                                              \
+            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { X_PIPE(0x220, 1) }                  \
         }                                                                                          \
-        if (DO_STORE) X_STORE_X(buf ^ 1)                                                           \
-        _Pragma("unroll") for (int pp = 0; pp < 8; ++pp)                                           \
-            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pp].x, fb[pp][0], acc[pp], 0, 0, 0); \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (DO_LOAD) X_LOAD_X((KB) + 2)                                                            \
-        if (DO_STORE) X_STORE_U(buf ^ 1)                                                           \
-        if (DO_LOAD) X_LOAD_U((KB) + 2)                                                            \
+        /* second half: patches of panel kb+1 (loaded a whole iteration ago) -> transform -> LDS, */ \
+        /* then the patches of panel kb+2 -> the same registers                                   */ \
+        if (DO_STORE && !(X_DBG & 4)) X_STORE_X(buf ^ 1, XR)                                           \
+        if (DO_LOAD && !(X_DBG & 1)) X_LOAD_X((KB) + 3, XR)                                            \
         _Pragma("unroll") for (int pp = 0; pp < 8; ++pp)                                           \
-            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pp].y, fb[pp][1], acc[pp], 0, 0, 0); \
+            if (!(X_DBG & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pp].y, fb[pp][1], acc[pp], 0, 0, 0); \
+        if (DO_STORE && X_DBG == 0) {                                                              \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                     \
+                X_PIPE(0x002, 9) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                \
+            }                                                                                      \
+        }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         __syncthreads();                                                                           \
     }
 
+    // iteration kb: the set holding panel kb+1 (set 1 for even kb) -> LDS[buf^1], then panel kb+3 -> that set
     int kb = 0;
-    for (; kb + 2 < p.nkb; ++kb) X_ITER(kb, true, true)
-    if (kb + 1 < p.nkb) { X_ITER(kb, true, false) ++kb; }
-    if (kb < p.nkb) X_ITER(kb, false, false)
+    for (; kb + 6 <= p.nkb; kb += 2) {
+        X_ITER(kb, xr1, ur1, true, true)
+        X_ITER(kb + 1, xr0, ur0, true, true)
+    }
+    X_ITER(kb, xr1, ur1, true, true)
+    X_ITER(kb + 1, xr0, ur0, true, false)
+    X_ITER(kb + 2, xr1, ur1, true, false)
+    X_ITER(kb + 3, xr0, ur0, false, false)
 #undef X_ITER
+#undef X_PIPE
 #undef X_STORE_U
 #undef X_STORE_X
 #undef X_LOAD_U
@@ -377,6 +422,7 @@ int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, void *st
     d.tiles_m = (a.M + XBM - 1) / XBM;
     d.tiles_t = (int)((T + XBT - 1) / XBT);
     d.nkb = a.C / XBK;
+    if (d.nkb < 4 || (d.nkb & 1)) return (int)hipErrorInvalidValue;
     d.act = a.act;
     const long long blocks = (long long)d.tiles_m * d.tiles_t;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;

@@ -25,6 +25,7 @@ struct ConvF32Args {
 int launch_conv_f32(const ConvF32Args &a, void *stream);
 // force a tile config (0 = heuristic): used by the tile sweep in bench/tests
 void conv_f32_force_tile(int cfg);
+int conv_f32_forced_tile();
 void conv_f32_set_variant(int v);
 int conv_f32_get_variant();
 int launch_conv_f32_v2(const ConvF32Args &a, int cfg, void *stream, char *name, size_t name_len);

@@ -132,10 +132,14 @@ static int upload_conv(Network &net, Layer &l)
         // specified by the reference as an exact +-1 GEMM.
         if (conv_f32_get_winograd() && !xnor_fallback && wino_applicable(l.c, M, l.size, l.stride, l.pad) &&
             l.out_h == l.h && l.out_w == l.w && l.h >= 4 && l.w >= 4) {
-            std::vector<float> u(wino_packed_floats(l.c, M));
-            wino_pack_weights(l.weights.data(), l.c, M, u.data());
-            YL_HIP(hipMalloc((void **)&l.d_wino_u, u.size() * sizeof(float)));
-            YL_HIP(hipMemcpy(l.d_wino_u, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice));
+            // the first (64-filter) tiling is an A/B and test variant: packed only for networks
+            // uploaded while it is forced (yl_debug_force_conv_tile(30))
+            if (conv_f32_forced_tile() == 30) {
+                std::vector<float> u(wino_packed_floats(l.c, M));
+                wino_pack_weights(l.weights.data(), l.c, M, u.data());
+                YL_HIP(hipMalloc((void **)&l.d_wino_u, u.size() * sizeof(float)));
+                YL_HIP(hipMemcpy(l.d_wino_u, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice));
+            }
             std::vector<float> u32(wino32_packed_floats(l.c, M));
             wino32_pack_weights(l.weights.data(), l.c, M, u32.data());
             YL_HIP(hipMalloc((void **)&l.d_wino32_u, u32.size() * sizeof(float)));
