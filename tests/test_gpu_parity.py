@@ -131,7 +131,7 @@ def test_conv_winograd_vs_oracle(olib, shape, wtile):
 
 def test_winograd_switch_off_keeps_direct_kernel():
     rng = np.random.default_rng(1)
-    B, Cc, H, W, M = 1, 64, 12, 12, 64          # the heuristic takes Winograd from 32 input channels up
+    B, Cc, H, W, M = 1, 64, 12, 12, 64          # the heuristic takes Winograd from 64 input channels up
     wts = rng.normal(0, 0.05, M * Cc * 9).astype(np.float32)
     d = D.conv(B, W, H, Cc, M, 3, 1, 1, D.LEAKY, wts, np.zeros(M, np.float32))
     x = rng.standard_normal((B, Cc, H, W)).astype(np.float32)

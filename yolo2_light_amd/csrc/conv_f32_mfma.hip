@@ -314,9 +314,10 @@ int conv_f32_get_winograd() { return g_winograd; }
 int launch_conv_f32(const ConvF32Args &a, void *stream)
 {
     // measured on MI355X (tools/sweep_conv.py, yolov3-608 shapes, B=64): the 32-filter tiling (two
-    // workgroups per CU) beats the 64-filter one by ~5 % everywhere and the direct kernel from 32 input
-    // channels up ([64,288,92416]: 1.59 vs 2.16 ms)
-    if (a.wino32_u && (g_force_tile == 31 || (g_force_tile == 0 && g_winograd && a.C >= 32)))
+    // workgroups per CU) beats the 64-filter one by ~5 % everywhere.  With 32 input channels
+    // ([64,288,92416]) it wins stand-alone (1.59 vs 2.16 ms) but not in the network, where the layer
+    // carries a fused shortcut and is bound by 3 GB of epilogue traffic (2.31 vs 2.2 ms): C >= 64.
+    if (a.wino32_u && (g_force_tile == 31 || (g_force_tile == 0 && g_winograd && a.C >= 64)))
         return launch_conv_f32_wino32(a, a.wino32_u, stream, g_last_tile, sizeof(g_last_tile));
     if (a.wino_u && g_force_tile == 30)
         return launch_conv_f32_wino(a, a.wino_u, stream, g_last_tile, sizeof(g_last_tile));
