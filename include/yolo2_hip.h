@@ -300,6 +300,28 @@ int yl_network_set_input_u8_dev(yl_network *net, int image, const uint8_t *pixel
  * the X argument of network_predict would hold, src/main.c:189,193) */
 int yl_network_input_download(yl_network *net, float *dst_host);
 
+/* ------------------------------------------------------------------ *
+ *  INT8 calibration tool (new): produces the `input_calibration=` list of a cfg.
+ * ------------------------------------------------------------------ */
+
+/* `darknet detector calibrate` = validate_calibrate_valid (src/additionally.c:4902) ->
+ * network_calibrate_cpu (src/yolov2_forward_network.c:731): for every image, before each
+ * convolutional layer, entropy_calibration(state.input, l.inputs, 1/16, 4096)
+ * (src/yolov2_forward_network_quantized.c:1292) picks the input multiplier 127/threshold that
+ * minimises KL(P || Q); the per-layer values are averaged over the images.
+ * Here: FP32 forward on the GPU for `n_images` images (host float CHW [0,1], a multiple of the batch),
+ * the histogram of every conv layer's input counted on the GPU (exact integers), the KL scan on
+ * the host with the reference's arithmetic, and the reference's averaging reproduced slot for slot
+ * (its mean takes the previous conv layer's last-image value instead of the layer's own: documented
+ * in runtime.hip).  multipliers[k] = value for the k-th convolutional layer, in layer order (the
+ * tool then prints them followed by "16").  Returns the number of values, < 0 on error.
+ * Difference: the reference's loop only knows CONV/MAXPOOL/ROUTE/REORG/REGION and skips every
+ * other layer type (yolov3 cfgs calibrate on garbage there); this runs the real forward pass. */
+int yl_network_calibrate(yl_network *net, const float *images_host, int n_images,
+                         float *multipliers, int max_out);
+/* the KL scan alone, from an exact histogram counts[max_bin] of lround(|x| / bin_width) (host only) */
+float yl_entropy_from_histogram(const uint32_t *counts, int max_bin, float bin_width);
+
 #ifdef __cplusplus
 }
 #endif

@@ -181,6 +181,16 @@ void ref_maxpool(float *src, float *dst, int size, int w, int h, int out_w, int 
     free(idx);
 }
 
+/* entropy_calibration (src/yolov2_forward_network_quantized.c:1292), silenced */
+float ref_entropy_calibration(float *src, size_t size, float bin_width, int max_bin)
+{
+    float m;
+    hush();
+    m = entropy_calibration(src, size, bin_width, max_bin);
+    unhush();
+    return m;
+}
+
 /* the reference's image front end exactly as test_detector_cpu drives it (src/main.c:187-189):
  * load_image(path, 0, 0, 3) [stb decode + HWC u8 -> CHW float /255., src/additionally.c:3068-3106]
  * then resize_image(im, w, h) [src/additionally.c:3021-3064].  out = float[3*h*w].

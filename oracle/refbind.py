@@ -61,6 +61,8 @@ def _bind(path: str) -> C.CDLL:
                                        C.POINTER(C.c_int)]
     lib.ref_maxpool.restype = None
     lib.ref_maxpool.argtypes = [_fp, _fp] + [C.c_int] * 9
+    lib.ref_entropy_calibration.restype = C.c_float
+    lib.ref_entropy_calibration.argtypes = [_fp, C.c_size_t, C.c_float, C.c_int]
     lib.ref_load_resized.restype = C.c_int
     lib.ref_load_resized.argtypes = [C.c_char_p, C.c_int, C.c_int, _fp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.ref_set_quiet.restype = None

@@ -355,6 +355,66 @@ void oracle_load_resized_u8(const unsigned char *pix, int sw, int sh, int sc, in
     free(part);
 }
 
+/* entropy_calibration  src/yolov2_forward_network_quantized.c:1292-1400 -- the INT8 input-multiplier
+ * search of the calibration tool (network_calibrate_cpu, src/yolov2_forward_network.c:784-786, calls
+ * it with bin_width 1/16 and 4096 bins on every conv layer's input):
+ *   H[b] = number of elements with lround(|x| / bin_width) == b (saturated at max_bin-1), float counts;
+ *   for i = 128 .. max_bin-1: P = H[0..i) with the tail mass added to P[i-1]; Q = P squeezed into
+ *   128 bins and expanded back (empty P bins stay empty); m[i] = KL(P || Q); the best i gives
+ *   threshold = (i + 0.5) * bin_width and multiplier = 127 / threshold.
+ * Types and evaluation order are the reference's (float accumulators, the uint64 outlier count that
+ * goes through float on every add, log in double). */
+float oracle_entropy_calibration(const float *src, size_t size, float bin_width, int max_bin)
+{
+    float *m_array = (float *)calloc(max_bin, sizeof(float));
+    float *H = (float *)calloc(max_bin, sizeof(float));
+    float *P = (float *)calloc(max_bin, sizeof(float));
+    float *Q = (float *)calloc(max_bin, sizeof(float));
+    float qQ[128];
+    uint64_t qcount[128];
+    {
+        const int last_bin = max_bin - 1;
+        for (size_t j = 0; j < size; ++j) {
+            const int bin = (int)lround(fabs(src[j]) / bin_width);
+            H[bin >= last_bin ? last_bin : bin]++;
+        }
+    }
+    for (int i = 128; i < max_bin; ++i) {
+        uint64_t outliers = 0;
+        const int last_bin = i - 1;
+        for (int j = 0; j < max_bin; ++j) {
+            if (j <= last_bin) P[j] = H[j];
+            else outliers += H[j];                 /* uint64 + float: evaluated in float, stored back */
+        }
+        const float expand = i / 128.0F;
+        for (int j = 0; j < 128; ++j) { qQ[j] = 0; qcount[j] = 0; }
+        for (int j = 0; j < i; ++j) {
+            int qb = (int)lround(j / expand);
+            if (qb > 127) qb = 127;
+            qQ[qb] += P[j];
+            if (P[j] != 0) qcount[qb]++;
+        }
+        for (int j = 0; j < i; ++j) Q[j] = 0;
+        for (int j = 0; j < i; ++j) {
+            int qb = (int)lround(j / expand);
+            if (qb > 127) qb = 127;
+            if (P[j] != 0) Q[j] = qQ[qb] / qcount[qb];
+        }
+        P[last_bin] += outliers;
+        float sum_P = 0, sum_Q = 0;
+        for (int j = 0; j < i; ++j) { sum_P += P[j]; sum_Q += Q[j]; }
+        for (int j = 0; j < i; ++j) { P[j] /= sum_P; Q[j] /= sum_Q; }
+        for (int j = 0; j < i; ++j) m_array[i] += P[j] * (log((P[j] + FLT_MIN) / (Q[j] + FLT_MIN)));
+    }
+    float m_index = 128, min_m = FLT_MAX;
+    for (int i = 128; i < max_bin; ++i)
+        if (m_array[i] < min_m) { min_m = m_array[i]; m_index = i; }
+    const float threshold = (m_index + 0.5) * bin_width;
+    const float multiplier = 127 / threshold;
+    free(H); free(P); free(Q); free(m_array);
+    return multiplier;
+}
+
 /* yolov2_fuse_conv_batchnorm  src/additionally.c:67-109 (epsilon outside the sqrt) */
 void oracle_fuse_bn(float *weights, float *biases, const float *scales, const float *mean, const float *var,
                     int n, int filter_size)

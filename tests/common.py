@@ -61,6 +61,8 @@ def oracle_lib() -> C.CDLL:
     lib.oracle_binarize_weights.restype = None
     lib.oracle_quantize_weights.argtypes = [_fp, C.c_size_t, _i8p]
     lib.oracle_quantize_weights.restype = C.c_float
+    lib.oracle_entropy_calibration.argtypes = [_fp, C.c_size_t, C.c_float, i]
+    lib.oracle_entropy_calibration.restype = C.c_float
     lib.oracle_load_resized_u8.argtypes = [C.POINTER(C.c_ubyte)] + [i] * 5 + [_fp]
     lib.oracle_load_resized_u8.restype = None
     for name in ("oracle_conv_f32", "oracle_conv_int8", "oracle_conv_xnor", "oracle_maxpool", "oracle_shortcut",

@@ -122,3 +122,24 @@ def test_image_front_end_matches_reference(olib, sw, sh, w, h):
     assert (rw.value, rh.value) == (sw, sh)
     got = common.oracle_load_resized(olib, pix, w, h)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("seed,n,scale,shape", [
+    (0, 200000, 1.0, "halfnormal"), (1, 50000, 6.0, "halfnormal"), (2, 300000, 0.3, "leaky"),
+    (3, 20000, 30.0, "uniform"), (4, 150000, 2.0, "leaky"), (5, 1000, 1.0, "halfnormal"),
+])
+def test_entropy_calibration_matches_reference(olib, seed, n, scale, shape):
+    """the calibration tool's multiplier search (entropy_calibration(x, n, 1/16, 4096)) bit for bit"""
+    rng = np.random.default_rng(seed)
+    if shape == "uniform":
+        x = rng.uniform(0, scale, n)
+    elif shape == "leaky":
+        x = rng.standard_normal(n) * scale
+        x = np.where(x > 0, x, 0.1 * x)
+    else:
+        x = np.abs(rng.standard_normal(n)) * scale
+    x = x.astype(np.float32)
+    rl = refbind._bind(refbind.GOLD)
+    ref = rl.ref_entropy_calibration(common.fp(x), x.size, 1.0 / 16, 4096)
+    got = olib.oracle_entropy_calibration(common.fp(x), x.size, 1.0 / 16, 4096)
+    assert np.float32(got).view(np.uint32) == np.float32(ref).view(np.uint32), (got, ref)

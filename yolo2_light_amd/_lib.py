@@ -105,6 +105,8 @@ _SIGS = {
     "yl_network_set_input_u8": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int]),
     "yl_network_set_input_u8_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int]),
     "yl_network_input_download": (C.c_int, [_vp, c_float_p]),
+    "yl_network_calibrate": (C.c_int, [_vp, c_float_p, C.c_int, c_float_p, C.c_int]),
+    "yl_entropy_from_histogram": (C.c_float, [C.POINTER(C.c_uint32), C.c_int, C.c_float]),
     "yl_network_get_boxes_batch": (C.c_int, [_vp, c_int_p, c_int_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,
                                              c_float_p, c_int_p]),
 }

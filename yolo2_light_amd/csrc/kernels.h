@@ -119,6 +119,9 @@ struct ImgDims {
 int launch_nms(float *rec_scratch, const int *counts, int B, int cap, int classes, float nms, int netw, int neth,
                const ImgDims &dims, int relative, int letter, float *rec_out, int *counts_out, void *stream);
 
+// K13 (layers.hip): per-image histogram of lround(|x| / bin_width), saturated; hist = unsigned[batch][max_bin]
+int launch_hist_abs(const float *x, size_t per_image, int batch, int max_bin, float bin_width, unsigned *hist, void *stream);
+
 // K12 (preprocess.hip): HWC u8 [sh][sw][sc] -> resize_image'd CHW float [sc][h][w] in [0,1]
 int launch_load_resize_u8(const uint8_t *pix, int sw, int sh, int sc, int w, int h, float *out, void *stream);
 

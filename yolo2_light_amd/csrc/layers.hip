@@ -301,6 +301,49 @@ int launch_binarize(const float *in, float *out, size_t n, void *stream)
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------- K13: calibration histogram
+// H[b][bin] = #{ x in image b : lround(fabs(x) / bin_width) == bin }, saturated at max_bin-1: the
+// data-parallel half of entropy_calibration (src/yolov2_forward_network_quantized.c:1306-1313).
+// fabs and the division are done in double like the reference (`fabs(float)` promotes); |x|/bin_width
+// is exact for the power-of-two bin widths the tool uses, and floor(v + 0.5) == lround(v) for v >= 0.
+// One workgroup owns a private LDS histogram (max_bin <= 4096 -> 16 KB) and flushes it with one
+// global atomic per non-empty bin: integer counts, order-independent, exact.
+__global__ __launch_bounds__(256) void hist_abs_kernel(const float *__restrict__ x, size_t per_image, int max_bin,
+                                                       double bin_width, unsigned *__restrict__ hist)
+{
+    __shared__ unsigned lh[4096];
+    for (int i = threadIdx.x; i < max_bin; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int b = blockIdx.y;
+    const float *src = x + (size_t)b * per_image;
+    const int last_bin = max_bin - 1;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < per_image; i += (size_t)gridDim.x * 256) {
+        const double v = __ddiv_rn(fabs((double)src[i]), bin_width);
+        // NaN compares false and lands in the last bin like +inf; the reference's lround(NaN) is
+        // unspecified, a calibration input with NaNs has no defined answer
+        int bin = (v < (double)last_bin) ? (int)floor(v + 0.5) : last_bin;
+        if (bin > last_bin) bin = last_bin;
+        atomicAdd(&lh[bin], 1u);
+    }
+    __syncthreads();
+    unsigned *dst = hist + (size_t)b * max_bin;
+    for (int i = threadIdx.x; i < max_bin; i += 256)
+        if (lh[i]) atomicAdd(&dst[i], lh[i]);
+}
+
+int launch_hist_abs(const float *x, size_t per_image, int batch, int max_bin, float bin_width, unsigned *hist, void *stream)
+{
+    if (max_bin > 4096 || max_bin < 129) return (int)hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(hist, 0, sizeof(unsigned) * (size_t)batch * max_bin, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    size_t blocks = (per_image + 256 * 16 - 1) / (256 * 16);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(hist_abs_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(256), 0, (hipStream_t)stream,
+                       x, per_image, max_bin, (double)bin_width, hist);
+    return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------- K10: detection compaction
 // expf as the reference's host computes it.  get_region_box_cpu (src/yolov2_forward_network.c:653-661)
 // calls libm's expf; glibc >= 2.27 evaluates it in double -- k = round(x*32/ln2), a 32-entry table

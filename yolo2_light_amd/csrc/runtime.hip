@@ -834,6 +834,74 @@ int yl_debug_set_conv_variant(int v) { conv_f32_set_variant(v); return YL_OK; }
 int yl_debug_set_winograd(int mode) { conv_f32_set_winograd(mode); return YL_OK; }
 const char *yl_debug_last_conv_tile(void) { return conv_f32_last_tile_name(); }
 
+// ------------------------------------------------------------------ INT8 calibration tool
+float yl_entropy_from_histogram(const uint32_t *counts, int max_bin, float bin_width)
+{
+    if (!counts || max_bin < 129 || max_bin > (1 << 20) || !(bin_width > 0.f)) { set_error("bad argument"); return -1.f; }
+    return entropy_from_counts(counts, max_bin, bin_width);
+}
+
+int yl_network_calibrate(yl_network *net, const float *images_host, int n_images, float *multipliers, int max_out)
+{
+    if (!net || !images_host || !multipliers || n_images <= 0) { set_error("bad argument"); return YL_ERR_ARG; }
+    Network &n = net->net;
+    if (!n.on_device) { set_error("network not on device"); return YL_ERR_STATE; }
+    if (n.quantized) { set_error("calibration runs the FP32 network: load it with quantized = 0"); return YL_ERR_STATE; }
+    if (n_images % n.batch != 0) { set_error("n_images must be a multiple of the network batch"); return YL_ERR_ARG; }
+    YL_HIP(hipSetDevice(n.device));
+    hipStream_t s = (hipStream_t)n.stream;
+    const int B = n.batch;
+    const int MAX_BIN = 4096;                 // entropy_calibration(state.input, l.inputs, 1.0 / 16, 4096)
+    const float BIN_W = 1.0f / 16;
+    const size_t nl = n.layers.size();
+    std::vector<int> conv_ids;
+    for (size_t i = 0; i < nl; ++i)
+        if (n.layers[i].type == YL_CONVOLUTIONAL) conv_ids.push_back((int)i);
+    if ((int)conv_ids.size() > max_out) { set_error("multipliers[] too small"); return YL_ERR_ARG; }
+    // mult[layer][image], image index 0-based here (the reference's `counter` is 1-based)
+    std::vector<std::vector<float>> mult(nl, std::vector<float>());
+    for (int i : conv_ids) mult[i].assign((size_t)n_images, 0.f);
+    unsigned *d_hist = nullptr;
+    YL_HIP(hipMalloc((void **)&d_hist, sizeof(unsigned) * (size_t)B * MAX_BIN));
+    std::vector<unsigned> h_hist((size_t)B * MAX_BIN);
+    int rc = YL_OK;
+    for (int img0 = 0; img0 < n_images && rc == YL_OK; img0 += B) {
+        memcpy(n.h_pinned, images_host + (size_t)img0 * n.c * n.h * n.w, n.pinned_bytes);
+        if (hipMemcpyAsync(n.d_input, n.h_pinned, n.pinned_bytes, hipMemcpyHostToDevice, s) != hipSuccess) { rc = YL_ERR_DEVICE; break; }
+        const float *input = n.d_input;
+        for (size_t i = 0; i < nl && rc == YL_OK; ++i) {
+            Layer &l = n.layers[i];
+            if (l.type == YL_CONVOLUTIONAL) {
+                // the layer's input as the forward pass sees it (network_calibrate_cpu: state.input, l.inputs)
+                if (launch_hist_abs(input, (size_t)l.inputs, B, MAX_BIN, BIN_W, d_hist, s) != 0 ||
+                    hipMemcpyAsync(h_hist.data(), d_hist, sizeof(unsigned) * h_hist.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                    hipStreamSynchronize(s) != hipSuccess) { set_error("calibration histogram failed"); rc = YL_ERR_DEVICE; break; }
+                for (int b = 0; b < B; ++b)
+                    mult[i][(size_t)img0 + b] = entropy_from_counts(h_hist.data() + (size_t)b * MAX_BIN, MAX_BIN, BIN_W);
+            }
+            rc = forward_layer(n, i, input);
+            input = l.d_output;
+        }
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(d_hist);
+    if (rc != YL_OK) return rc;
+    // The reference's averaging, slot for slot (src/yolov2_forward_network.c:786-797): multipliers go to
+    // input_mult_array[counter + i*max_num] with a 1-based image counter, the mean is taken over slots
+    // 0..max_num-1.  Slot 0 of layer i is slot max_num of layer i-1, i.e. the LAST image's multiplier of
+    // the previous layer if that layer is a convolution and 0 otherwise, and the last image's own
+    // multiplier (slot max_num) is left out.  Reproduced as is so the numbers agree with the tool.
+    for (size_t k = 0; k < conv_ids.size(); ++k) {
+        const int i = conv_ids[k];
+        float res = 0;
+        const bool prev_conv = i > 0 && n.layers[(size_t)i - 1].type == YL_CONVOLUTIONAL;
+        res += prev_conv ? mult[(size_t)i - 1][(size_t)n_images - 1] : 0.f;
+        for (int j = 1; j < n_images; ++j) res += mult[i][(size_t)j - 1];
+        multipliers[k] = res / n_images;
+    }
+    return (int)conv_ids.size();
+}
+
 static int check_image_args(yl_network *net, int image, const void *pixels, int w, int h, int c)
 {
     if (!net || !pixels) { set_error("null argument"); return YL_ERR_ARG; }

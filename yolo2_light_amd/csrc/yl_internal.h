@@ -111,6 +111,8 @@ void fuse_conv_batchnorm(Network &net);
 void calculate_binary_weights(Network &net);
 void quantize_network(Network &net);
 void select_conv_modes(Network &net);
+// host_calib.cpp
+float entropy_from_counts(const uint32_t *counts, int max_bin, float bin_width);
 // host_detect.cpp
 int get_boxes_host(Network &net, int image, int w, int h, float thresh, int relative,
                    int letter, float nms, float *rows, int max_rows, int *classes_out);

@@ -253,6 +253,18 @@ class Network:
         """forward over the device input buffer the set_input_* calls filled (asynchronous)"""
         check(lib.yl_network_forward(self._h, lib.yl_network_input_dev(self._h)), "yl_network_forward")
 
+    def calibrate(self, images: np.ndarray) -> np.ndarray:
+        """`darknet detector calibrate`: input multipliers (one per conv layer) from float32 images
+        [n, c, h, w] in [0,1], n a multiple of the batch; the network must be FP32 and on the device."""
+        x = np.ascontiguousarray(images, dtype=np.float32)
+        w, h, c = self.input_dims
+        n_img = x.size // (c * h * w)
+        out = np.zeros(self.n, dtype=np.float32)
+        k = lib.yl_network_calibrate(self._h, _fp(x), n_img, _fp(out), self.n)
+        if k < 0:
+            raise YoloHipError("yl_network_calibrate failed: " + _lib.last_error())
+        return out[:k]
+
     # ------------------------------------------------------------ detections
     def pull_heads(self) -> None:
         check(lib.yl_network_pull_heads(self._h), "yl_network_pull_heads")
