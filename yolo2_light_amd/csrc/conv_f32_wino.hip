@@ -32,7 +32,6 @@
 // the panel (sched_barrier); one workgroup barrier per panel (64 MFMAs = 4096 pipe cycles apart).
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include <cstdlib>
 
 #include "kernels.h"
 #include "../../include/yolo2_hip.h"
@@ -103,9 +102,6 @@ __device__ __forceinline__ void input_transform(const float (&d)[16], float (&v)
 
 }  // namespace
 
-// DBG (timing experiments only, results are garbage): 1 = no staging inside the K loop,
-// 2 = additionally no fragment reads (MFMA issue only), 3 = staging but no MFMAs
-template <int DBG>
 __global__ __launch_bounds__(256) void conv_f32_wino_kernel(ConvWinoDev p)
 {
     __shared__ __attribute__((aligned(16))) float smem[4 * PANEL];
@@ -254,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_f32_wino_kernel(ConvWinoDev p)
     }
 #define W_READ_FRAGS(SET, G) W_READ_FRAGS_FROM(SET, G, Ab, Bb)
 #define W_MFMA_GROUP(SET, G)                                                                       \
-    if (DBG != 3) {                                                                                              \
+    {                                                                                                            \
         _Pragma("unroll") for (int pp = 0; pp < 4; ++pp)                                           \
             acc[4 * (G) + pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][pp].x, fb[SET][pp][0].x, acc[4 * (G) + pp], 0, 0, 0); \
         _Pragma("unroll") for (int pp = 0; pp < 4; ++pp)                                           \
@@ -279,37 +275,37 @@ __global__ __launch_bounds__(256) void conv_f32_wino_kernel(ConvWinoDev p)
         const int buf = (KB) & 1;                                                                  \
         const float *Ab = As + buf * PANEL + half * 256 + (wm * 32 + l31) * 4;                     \
         const float *Bb = Bs + buf * PANEL + half * 256 + (wt * 32 + l31) * 2;                     \
-        if (DBG != 2) W_READ_FRAGS(1, 1)                                                           \
-        if (DO_STORE && (DBG == 0 || DBG == 3 || DBG == 5)) W_STORE_X(buf ^ 1)                                 \
+        W_READ_FRAGS(1, 1)                                                                  \
+        if (DO_STORE) W_STORE_X(buf ^ 1)                                                                   \
         W_MFMA_GROUP(0, 0)                                                                         \
-        if (DO_STORE && DBG == 0) {                                                                \
+        if (DO_STORE) {                                                                            \
             _Pragma("unroll") for (int i_ = 0; i_ < 12; ++i_) {                                    \
                 W_PIPE(0x002, 10) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);               \
             }                                                                                      \
             _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { W_PIPE(0x200, 4) }                  \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (DBG != 2) W_READ_FRAGS(0, 2)                                                           \
-        if (DO_LOAD && (DBG == 0 || DBG == 3 || DBG == 4)) W_LOAD_X((KB) + 2)                                  \
-        if (DO_STORE && (DBG == 0 || DBG == 3 || DBG == 5)) W_STORE_U(buf ^ 1)                                 \
+        W_READ_FRAGS(0, 2)                                                                  \
+        if (DO_LOAD) W_LOAD_X((KB) + 2)                                                                    \
+        if (DO_STORE) W_STORE_U(buf ^ 1)                                                                   \
         W_MFMA_GROUP(1, 1)                                                                         \
-        if (DO_LOAD && DBG == 0) {                                                                 \
+        if (DO_LOAD) {                                                                             \
             _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                                    \
                 W_PIPE(0x020, 1) __builtin_amdgcn_sched_group_barrier(0x300, 1, 0);                \
             }                                                                                      \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
-        if (DBG != 2) W_READ_FRAGS(1, 3)                                                           \
-        if (DO_LOAD && (DBG == 0 || DBG == 3 || DBG == 4)) W_LOAD_U((KB) + 2)                                  \
+        W_READ_FRAGS(1, 3)                                                                  \
+        if (DO_LOAD) W_LOAD_U((KB) + 2)                                                                    \
         W_MFMA_GROUP(0, 2)                                                                         \
-        if (DO_LOAD && DBG == 0) {                                                                 \
+        if (DO_LOAD) {                                                                             \
             _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {                                    \
                 W_PIPE(0x020, 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                \
             }                                                                                      \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         __syncthreads();                                                                           \
-        if (DO_STORE && DBG != 2) {                                                                \
+        if (DO_STORE) {                                                                            \
             const float *An = As + (buf ^ 1) * PANEL + half * 256 + (wm * 32 + l31) * 4;           \
             const float *Bn = Bs + (buf ^ 1) * PANEL + half * 256 + (wt * 32 + l31) * 2;           \
             W_READ_FRAGS_FROM(0, 0, An, Bn)                                                        \
@@ -337,12 +333,6 @@ __global__ __launch_bounds__(256) void conv_f32_wino_kernel(ConvWinoDev p)
 #undef W_LOAD_U
 #undef W_LOAD_X
 
-    if (DBG == 4) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(xr[0][e]), "v"(xr[1][e]));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(ur[e][0]), "v"(ur[e][3]));
-    }
     // ---- epilogue: Y = A^T M A per (filter, tile), + bias, activation, [shortcut], 2x2 stores.
     //      lane = tile column of the C/D layout: 32 consecutive tiles -> 64 consecutive pixels ----
     const int tg_e = t0 + wt * 32 + l31;
@@ -462,16 +452,7 @@ int launch_conv_f32_wino(const ConvF32Args &a, const float *u_packed, void *stre
     d.act = a.act;
     const long long blocks = (long long)d.tiles_m * d.tiles_t;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    static int dbg = -1;
-    if (dbg < 0) { const char *e = getenv("YL_WINO_DBG"); dbg = e ? atoi(e) : 0; }
-    const dim3 grid((unsigned)blocks), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    if (dbg == 1) hipLaunchKernelGGL(conv_f32_wino_kernel<1>, grid, block, 0, s, d);
-    else if (dbg == 2) hipLaunchKernelGGL(conv_f32_wino_kernel<2>, grid, block, 0, s, d);
-    else if (dbg == 3) hipLaunchKernelGGL(conv_f32_wino_kernel<3>, grid, block, 0, s, d);
-    else if (dbg == 4) hipLaunchKernelGGL(conv_f32_wino_kernel<4>, grid, block, 0, s, d);
-    else if (dbg == 5) hipLaunchKernelGGL(conv_f32_wino_kernel<5>, grid, block, 0, s, d);
-    else hipLaunchKernelGGL(conv_f32_wino_kernel<0>, grid, block, 0, s, d);
+    hipLaunchKernelGGL(conv_f32_wino_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d);
     if (name) snprintf(name, name_len, "conv_f32_wino<64x64t,f2x2>");
     return (int)hipGetLastError();
 }

@@ -106,7 +106,10 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = bid & 7;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    constexpr int GT = 8;
+#ifndef XGT
+#define XGT 8
+#endif
+    constexpr int GT = XGT;
     const int per_group = GT * p.tiles_m;
     const int tg = logical / per_group;
     const int rem_g = logical - tg * per_group;

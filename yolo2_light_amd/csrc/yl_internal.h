@@ -40,6 +40,7 @@ struct Layer {
 
     float *host_output = nullptr;        // borrowed (desc.output) or owned (host_output_own)
     std::vector<float> host_output_own;
+    bool host_registered = false;        // host_output pinned with hipHostRegister (heads: fast D2H)
 
     // ---- device state (owned by runtime.hip) ----
     float *d_output = nullptr;           // [batch][out_c][out_h][out_w]
