@@ -244,6 +244,9 @@ const char *yl_debug_last_conv_tile(void);
  * call (the transformed weights are packed at yl_network_to_device); with it on, forced tile id 30
  * = Winograd, any other forced tile = the direct kernel. */
 int yl_debug_set_winograd(int mode);
+/* Tuning/test hook: yl_network_detect_batch's suppression stage, 1 = one workgroup per
+ * (image, class) (default), 0 = one workgroup per image; same rows either way. */
+int yl_debug_set_nms_mode(int mode);
 
 /* On-device detection compaction (new): threshold test
  * `objectness > thresh` (src/additionally.c:4341) and box decode

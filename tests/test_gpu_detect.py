@@ -144,3 +144,28 @@ def test_detect_batch_is_deterministic_and_independent_of_slot_order():
         for a, b in zip(first, again):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     net.close()
+
+
+def test_parallel_and_sequential_suppression_agree_on_a_dense_head():
+    """an untrained head at a low threshold: ~1000 boxes per image, dozens of positive classes each
+    (every class active, long sorted lists, the m > 64 chunks) -- the (image, class)-parallel path
+    and the one-workgroup-per-image path must produce the same bytes, and both the host rows"""
+    from yolo2_light_amd._lib import lib
+    cfg, wts = common.model_files("yolov3-tiny", 416, 416)
+    net = Network.load(cfg, wts, 3, 0, device=0)
+    x = common.seeded_input(3, 3, 416, 416)
+    net.predict(x)
+    try:
+        lib.yl_debug_set_nms_mode(0)
+        seq, c0 = net.get_boxes_batch(0.02, 0.45, cap=2048)
+        lib.yl_debug_set_nms_mode(1)
+        par, c1 = net.get_boxes_batch(0.02, 0.45, cap=2048)
+    finally:
+        lib.yl_debug_set_nms_mode(1)
+    assert np.array_equal(c0, c1) and max(c0) > 300
+    for b in range(3):
+        assert np.array_equal(seq[b].view(np.uint32), par[b].view(np.uint32)), b
+        if c0[b] <= 2048:
+            host = net.get_boxes(b, 1, 1, 0.02, nms=0.45)
+            _same_rows(par[b], host, ("dense", b))
+    net.close()

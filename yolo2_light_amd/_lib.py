@@ -99,6 +99,7 @@ _SIGS = {
     "yl_debug_last_conv_tile": (C.c_char_p, []),
     "yl_debug_set_conv_variant": (C.c_int, [C.c_int]),
     "yl_debug_set_winograd": (C.c_int, [C.c_int]),
+    "yl_debug_set_nms_mode": (C.c_int, [C.c_int]),
     "yl_network_compact_detections": (C.c_int, [_vp, C.c_float, C.c_int, _vp, _vp]),
     "yl_network_detect_batch": (C.c_int, [_vp, c_int_p, c_int_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,
                                           _vp, _vp]),

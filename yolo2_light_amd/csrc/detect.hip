@@ -85,11 +85,20 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *scratch, int *to
 //   uint16 perm[2][cap]                         position -> record slot (double buffer)
 //   uint16 sidx[cap]                            sorted positive prefix -> record slot
 //   int    scan[NMS_THREADS], uint32 cmask[(classes+31)/32], misc
+// MODE 0: everything in one workgroup per image (sequential over classes).
+// MODE 2 / nms_class_kernel / MODE 1: the same result with the suppression of every (image, class)
+//   pair in its own workgroup -- MODE 2 prepares (corrected boxes back into the rows, position in the
+//   reference's initial order into column 5, class bitmap and `total` into `meta`), nms_class_kernel
+//   suppresses (marks by flipping the sign of the probability, the magnitude stays readable for the
+//   other classes' tie-breaks), MODE 1 replays only the ORDER (partition + rank sort per class on the
+//   original magnitudes) and emits.
+template <int MODE>
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(float *__restrict__ rec, const int *__restrict__ counts,
                                                           int cap, int classes, int row_stride, float nms,
                                                           int netw, int neth, ImgDims dims,
                                                           int relative, int letter,
-                                                          float *__restrict__ rec_out, int *__restrict__ counts_out)
+                                                          float *__restrict__ rec_out, int *__restrict__ counts_out,
+                                                          unsigned *__restrict__ meta)
 {
     extern __shared__ unsigned char smem[];
     float *bx = (float *)smem;
@@ -137,19 +146,22 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(float *__restrict__ re
     // ---- load: corrected boxes, bitmap of classes with any prob > 0, zero-objectness flag ----
     for (int s = t; s < cnt; s += NMS_THREADS) {
         const float *r = in + (size_t)s * row_stride;
-        float x = (float)(((double)r[0] - off_x) / sc_x);
-        float y = (float)(((double)r[1] - off_y) / sc_y);
-        float w = __fmul_rn(r[2], mul_w);
-        float h = __fmul_rn(r[3], mul_h);
-        if (!relative) {
+        float x = r[0], y = r[1], w = r[2], h = r[3];
+        if (MODE != 1) {
+            x = (float)(((double)r[0] - off_x) / sc_x);
+            y = (float)(((double)r[1] - off_y) / sc_y);
+            w = __fmul_rn(r[2], mul_w);
+            h = __fmul_rn(r[3], mul_h);
+        }
+        if (MODE != 1 && !relative) {
             x = __fmul_rn(x, (float)iw); w = __fmul_rn(w, (float)iw);
             y = __fmul_rn(y, (float)ih); h = __fmul_rn(h, (float)ih);
         }
         bx[s] = x; by[s] = y; bw[s] = w; bh[s] = h;
-        if (r[4] == 0.f) misc[0] = 1;
-        pk[s] = r[5];                                          // scan-order key
+        if (MODE != 1 && r[4] == 0.f) misc[0] = 1;
+        pk[s] = r[5];                                          // scan-order key (MODE 1: initial position)
         for (int j = 0; j < classes; ++j)
-            if (r[6 + j] > 0.f) atomicOr(&cmask[j >> 5], 1u << (j & 31));
+            if (r[6 + j] != 0.f) atomicOr(&cmask[j >> 5], 1u << (j & 31));     // suppressed (negated) ones count too
     }
     __syncthreads();
 
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(float *__restrict__ re
     if (nms > 0) {
         // "move zero-objectness detections to the end" (src/box.c:300-309): sequential swaps.  Only
         // reachable with thresh < 0 and a logistic that underflowed to 0; kept for exactness.
-        if (misc[0]) {
+        if (MODE != 1 && misc[0]) {
             if (t == 0) {
                 int k = cnt - 1;
                 for (int i = 0; i <= k; ++i) {
@@ -184,6 +196,23 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(float *__restrict__ re
             __syncthreads();
         }
 
+        if (MODE == 1) {
+            total = (int)meta[(size_t)b * (1 + cwords)];
+            for (int p = total + t; p < cnt; p += NMS_THREADS) perm_nxt[p] = perm[p];
+            __syncthreads();
+        }
+        if (MODE == 2) {
+            for (int s = t; s < cnt; s += NMS_THREADS) {
+                float *r = in + (size_t)s * row_stride;
+                r[0] = bx[s]; r[1] = by[s]; r[2] = bw[s]; r[3] = bh[s];
+            }
+            for (int p = t; p < cnt; p += NMS_THREADS) in[(size_t)perm[p] * row_stride + 5] = (float)p;
+            unsigned *mb = meta + (size_t)b * (1 + cwords);
+            if (t == 0) mb[0] = (unsigned)total;
+            for (int i = t; i < cwords; i += NMS_THREADS) mb[1 + i] = cmask[i];
+            return;
+        }
+
         for (int k = 0; k < classes; ++k) {
             if (!((cmask[k >> 5] >> (k & 31)) & 1u)) continue;          // block-uniform
             // thread t owns positions [p0,p1) so the partition below is stable
@@ -192,7 +221,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(float *__restrict__ re
             const int p1 = (p0 + per < total) ? p0 + per : total;
             int mine = 0;
             for (int p = p0; p < p1; ++p) {
-                const float v = in[(size_t)perm[p] * row_stride + 6 + k];
+                float v = in[(size_t)perm[p] * row_stride + 6 + k];
+                if (MODE == 1) v = fabsf(v);                 // the order is defined on the original values
                 pk[p] = v;
                 mine += (v > 0.f) ? 1 : 0;
             }
@@ -222,7 +252,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(float *__restrict__ re
             // 64 pivots at a time: wave 0 settles the chunk internally with the dead-set as a
             // ballot mask (no barriers), then every thread applies the chunk's survivors to the
             // elements behind it -- one barrier pair per 64 pivots instead of one per pivot.
-            for (int c0 = 0; c0 < m; c0 += 64) {
+            for (int c0 = 0; MODE == 0 && c0 < m; c0 += 64) {
                 const int cn = (m - c0 < 64) ? m - c0 : 64;
                 if (t < 64) {
                     const bool valid = t < cn;
@@ -281,8 +311,117 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(float *__restrict__ re
         else if (c == 3) v = bh[s];
         else if (c == 5) v = (p < total) ? sort_class : 0.f;     // the unsorted tail keeps calloc's 0
         else v = in[(size_t)s * row_stride + c];
+        if (MODE == 1 && c >= 6 && v < 0.f) v = 0.f;               // marked by nms_class_kernel
         out[e] = v;
     }
+}
+
+// Suppression of ONE class of ONE image (grid = classes x batch): the positives of class k are sorted
+// the way the reference's k-th qsort leaves them -- by probability, ties by the order the earlier
+// classes produced, which is a pure function of the ORIGINAL probabilities: a before b iff at the
+// highest class c < k where |p_c| differs a's is larger, else by the initial position -- and the
+// greedy pass runs on that list.  A suppressed probability gets its sign flipped.
+__global__ __launch_bounds__(NMS_THREADS) void nms_class_kernel(float *__restrict__ rec, const int *__restrict__ counts,
+                                                                int cap, int classes, int row_stride, float nms,
+                                                                const unsigned *__restrict__ meta)
+{
+    extern __shared__ unsigned char smem[];
+    float *gp = (float *)smem;                 // gathered probabilities
+    float *gpos = gp + cap;                    // their initial positions
+    float *sp = gpos + cap;                    // sorted probabilities (sign flipped = suppressed)
+    float *pbox = sp + cap;                    // 64 pivot boxes
+    uint16_t *gslot = (uint16_t *)(pbox + 256);
+    uint16_t *sidx = gslot + cap;
+    int *misc = (int *)(sidx + cap + ((2 * cap) & 1));
+
+    const int k = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const int cwords = (classes + 31) >> 5;
+    const unsigned *mb = meta + (size_t)b * (1 + cwords);
+    if (!((mb[1 + (k >> 5)] >> (k & 31)) & 1u)) return;
+    const int total = (int)mb[0];
+    const int raw = counts[b];
+    const int cnt = raw < cap ? raw : cap;
+    float *in = rec + (size_t)b * cap * row_stride;
+
+    if (t == 0) misc[0] = 0;
+    __syncthreads();
+    for (int s = t; s < cnt; s += NMS_THREADS) {
+        const float p = in[(size_t)s * row_stride + 6 + k];
+        const float pos = in[(size_t)s * row_stride + 5];
+        if (p > 0.f && pos < (float)total) {
+            const int i = atomicAdd(&misc[0], 1);
+            gp[i] = p; gpos[i] = pos; gslot[i] = (uint16_t)s;
+        }
+    }
+    __syncthreads();
+    const int m = misc[0];
+    if (m <= 1) return;
+    for (int i = t; i < m; i += NMS_THREADS) {
+        const float v = gp[i];
+        const size_t ri = (size_t)gslot[i] * row_stride;
+        int rank = 0;
+        for (int j = 0; j < m; ++j) {
+            const float u = gp[j];
+            if (u > v) { ++rank; continue; }
+            if (u != v || j == i) continue;
+            // tie: the order class k-1's sort left behind
+            const size_t rj = (size_t)gslot[j] * row_stride;
+            bool before = gpos[j] < gpos[i];
+            for (int c = k - 1; c >= 0; --c) {
+                const float a = fabsf(in[rj + 6 + c]), d = fabsf(in[ri + 6 + c]);
+                if (a != d) { before = a > d; break; }
+            }
+            rank += before ? 1 : 0;
+        }
+        sp[rank] = v;
+        sidx[rank] = gslot[i];
+    }
+    __syncthreads();
+    for (int c0 = 0; c0 < m; c0 += 64) {
+        const int cn = (m - c0 < 64) ? m - c0 : 64;
+        if (t < 64) {
+            const bool valid = t < cn;
+            const int slot = valid ? sidx[c0 + t] : 0;
+            const float *r = in + (size_t)slot * row_stride;
+            const BoxF me = { r[0], r[1], r[2], r[3] };
+            unsigned long long dead = __ballot(valid && sp[c0 + t] < 0.f);
+            for (int i = 0; i < cn; ++i) {
+                if ((dead >> i) & 1ull) continue;
+                BoxF a;
+                a.x = __shfl(me.x, i); a.y = __shfl(me.y, i); a.w = __shfl(me.w, i); a.h = __shfl(me.h, i);
+                const bool kill = valid && t > i && (box_iou_dev(a, me) > nms);
+                dead |= __ballot(kill);
+            }
+            if (valid && ((dead >> t) & 1ull) && sp[c0 + t] > 0.f) {
+                sp[c0 + t] = -sp[c0 + t];
+                in[(size_t)slot * row_stride + 6 + k] = sp[c0 + t];
+            }
+            if (valid) { pbox[t * 4 + 0] = me.x; pbox[t * 4 + 1] = me.y; pbox[t * 4 + 2] = me.w; pbox[t * 4 + 3] = me.h; }
+            if (t == 0) { misc[2] = (int)(unsigned)(dead & 0xFFFFFFFFull); misc[3] = (int)(unsigned)(dead >> 32); }
+        }
+        if (c0 + 64 >= m) break;
+        __syncthreads();
+        const unsigned long long dead = ((unsigned long long)(unsigned)misc[3] << 32) | (unsigned)misc[2];
+        for (int j = c0 + 64 + t; j < m; j += NMS_THREADS) {
+            if (sp[j] < 0.f) continue;
+            const int sj = sidx[j];
+            const float *r = in + (size_t)sj * row_stride;
+            const BoxF me = { r[0], r[1], r[2], r[3] };
+            bool kill = false;
+            for (int i = 0; i < 64 && !kill; ++i) {
+                if ((dead >> i) & 1ull) continue;
+                const BoxF a = { pbox[i * 4 + 0], pbox[i * 4 + 1], pbox[i * 4 + 2], pbox[i * 4 + 3] };
+                kill = box_iou_dev(a, me) > nms;
+            }
+            if (kill) { sp[j] = -sp[j]; in[(size_t)sj * row_stride + 6 + k] = sp[j]; }
+        }
+        __syncthreads();
+    }
+}
+
+static size_t nms_class_lds_bytes(int cap)
+{
+    return (size_t)(3 * cap + 256) * sizeof(float) + (size_t)(2 * cap + 2) * sizeof(uint16_t) + 4 * sizeof(int);
 }
 
 size_t nms_lds_bytes(int cap, int classes)
@@ -292,14 +431,28 @@ size_t nms_lds_bytes(int cap, int classes)
     return n;
 }
 
+static int g_nms_mode = 1;      // 1 = (image, class)-parallel suppression, 0 = one workgroup per image
+void nms_set_mode(int m) { g_nms_mode = m; }
+
 int launch_nms(float *rec_scratch, const int *counts, int B, int cap, int classes, float nms, int netw, int neth,
-               const ImgDims &dims, int relative, int letter, float *rec_out, int *counts_out, void *stream)
+               const ImgDims &dims, int relative, int letter, float *rec_out, int *counts_out, unsigned *meta,
+               void *stream)
 {
     if (cap > NMS_MAX_CAP) return (int)hipErrorInvalidValue;
     const int row_stride = 6 + classes;
-    hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NMS_THREADS), nms_lds_bytes(cap, classes), (hipStream_t)stream,
-                       rec_scratch, counts, cap, classes, row_stride, nms, netw, neth, dims, relative, letter,
-                       rec_out, counts_out);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = nms_lds_bytes(cap, classes);
+    if (g_nms_mode == 0 || !(nms > 0) || !meta) {
+        hipLaunchKernelGGL(nms_kernel<0>, dim3(B), dim3(NMS_THREADS), lds, s, rec_scratch, counts, cap, classes,
+                           row_stride, nms, netw, neth, dims, relative, letter, rec_out, counts_out, meta);
+        return (int)hipGetLastError();
+    }
+    hipLaunchKernelGGL(nms_kernel<2>, dim3(B), dim3(NMS_THREADS), lds, s, rec_scratch, counts, cap, classes,
+                       row_stride, nms, netw, neth, dims, relative, letter, rec_out, counts_out, meta);
+    hipLaunchKernelGGL(nms_class_kernel, dim3(classes, B), dim3(NMS_THREADS), nms_class_lds_bytes(cap), s,
+                       rec_scratch, counts, cap, classes, row_stride, nms, meta);
+    hipLaunchKernelGGL(nms_kernel<1>, dim3(B), dim3(NMS_THREADS), lds, s, rec_scratch, counts, cap, classes,
+                       row_stride, nms, netw, neth, dims, relative, letter, rec_out, counts_out, meta);
     return (int)hipGetLastError();
 }
 

@@ -116,8 +116,12 @@ struct ImgDims {
     int mode;
     uint32_t wh[NMS_MAX_DIMS];
 };
+// meta = unsigned[B][1 + (classes+31)/32] scratch (per image: `total`, class bitmap) for the
+// (image, class)-parallel path; nullptr or nms_set_mode(0) = one workgroup per image
 int launch_nms(float *rec_scratch, const int *counts, int B, int cap, int classes, float nms, int netw, int neth,
-               const ImgDims &dims, int relative, int letter, float *rec_out, int *counts_out, void *stream);
+               const ImgDims &dims, int relative, int letter, float *rec_out, int *counts_out, unsigned *meta,
+               void *stream);
+void nms_set_mode(int m);
 
 // K13 (layers.hip): per-image histogram of lround(|x| / bin_width), saturated; hist = unsigned[batch][max_bin]
 int launch_hist_abs(const float *x, size_t per_image, int batch, int max_bin, float bin_width, unsigned *hist, void *stream);

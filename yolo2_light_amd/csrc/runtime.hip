@@ -79,6 +79,8 @@ static void free_device(Network &net)
     if (net.d_det_scratch) (void)hipFree(net.d_det_scratch);
     if (net.d_det_out) (void)hipFree(net.d_det_out);
     if (net.d_det_counts) (void)hipFree(net.d_det_counts);
+    if (net.d_det_meta) (void)hipFree(net.d_det_meta);
+    net.d_det_meta = nullptr; net.det_meta_bytes = 0;
     net.d_det_scratch = nullptr; net.d_det_out = nullptr; net.d_det_counts = nullptr;
     net.det_scratch_bytes = net.det_out_bytes = 0;
     net.d_input = nullptr; net.d_qbuf = nullptr; net.d_bitbuf = nullptr; net.h_pinned = nullptr;
@@ -876,6 +878,7 @@ int yl_network_get_boxes(yl_network *net, int image, int w, int h, float thresh,
 int yl_debug_force_conv_tile(int cfg) { conv_f32_force_tile(cfg); return YL_OK; }
 int yl_debug_set_conv_variant(int v) { conv_f32_set_variant(v); return YL_OK; }
 int yl_debug_set_winograd(int mode) { conv_f32_set_winograd(mode); return YL_OK; }
+int yl_debug_set_nms_mode(int mode) { nms_set_mode(mode); return YL_OK; }
 const char *yl_debug_last_conv_tile(void) { return conv_f32_last_tile_name(); }
 
 // ------------------------------------------------------------------ INT8 calibration tool
@@ -1083,6 +1086,14 @@ int yl_network_detect_batch(yl_network *net, const int *img_w, const int *img_h,
         n.det_scratch_bytes = need;
     }
     if (!n.d_det_counts) YL_HIP(hipMalloc((void **)&n.d_det_counts, sizeof(int) * 2 * (size_t)B));
+    const size_t meta_need = sizeof(unsigned) * (size_t)B * (1 + (classes + 31) / 32);
+    if (n.det_meta_bytes < meta_need) {
+        YL_HIP(hipStreamSynchronize((hipStream_t)n.stream));
+        if (n.d_det_meta) (void)hipFree(n.d_det_meta);
+        n.d_det_meta = nullptr; n.det_meta_bytes = 0;
+        YL_HIP(hipMalloc((void **)&n.d_det_meta, meta_need));
+        n.det_meta_bytes = meta_need;
+    }
     ImgDims dims;
     dims.mode = 0;
     dims.wh[0] = 0;
@@ -1101,7 +1112,7 @@ int yl_network_detect_batch(yl_network *net, const int *img_w, const int *img_h,
     YL_LAUNCH(launch_compact(heads, nh, B, n.w, n.h, thresh, cap, 6 + classes, n.d_det_scratch, n.d_det_counts, n.stream),
               "compact");
     YL_LAUNCH(launch_nms(n.d_det_scratch, n.d_det_counts, B, cap, classes, nms, n.w, n.h, dims, relative, letter,
-                         records_dev, counts_dev, n.stream), "nms");
+                         records_dev, counts_dev, n.d_det_meta, n.stream), "nms");
     return YL_OK;
 }
 

@@ -94,6 +94,8 @@ struct Network {
     float *d_det_out = nullptr;          // batched detections: device staging of yl_network_get_boxes_batch
     size_t det_out_bytes = 0;
     int *d_det_counts = nullptr;         // [2][batch]: raw compaction counts, staged output counts
+    unsigned *d_det_meta = nullptr;      // [batch][1 + class words]: NMS `total` + class bitmap
+    size_t det_meta_bytes = 0;
     uint8_t *h_u8 = nullptr;             // pinned staging of u8 source images, one region per batch slot
     uint8_t *d_u8 = nullptr;             // the same on the device
     size_t u8_stride = 0;                // bytes per slot
