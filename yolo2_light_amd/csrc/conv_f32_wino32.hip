@@ -24,7 +24,7 @@
 
 // X_DBG (build-time timing experiments, -DX_DBG=<bits>; results are garbage): 1 no patch loads in the
 // K loop, 2 no weight loads, 4 no transform / LDS stores, 8 no MFMAs, 16 transform without the patch
-// stores, 32 patch stores without the transform.  tools/scratch/ab.sh runs such builds side by side
+// stores, 32 patch stores without the transform.  tools/ab_builds.sh runs such builds side by side
 // on one GPU box (DESIGN.md, K1w "what still bounds it").
 #ifndef X_DBG
 #define X_DBG 0
