@@ -84,3 +84,50 @@ def test_hip_reproduces_golden(path):
             got = net.get_boxes(bi, w, h, 0.24, nms=0.4)
             assert abs(len(got) - len(want)) <= 1
     net.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# neighbours of the path: tests/golden/aux/*.npz, tests/golden/make_golden_aux.py
+AUX = os.path.join(common.GOLDEN_DIR, "aux")
+
+
+def test_oracle_front_end_reproduces_golden(olib):
+    g = np.load(os.path.join(AUX, "front_end.npz"))
+    for k in range(int(g["n"])):
+        pix, ref = g["pix_%d" % k], g["ref_%d" % k]
+        got = common.oracle_load_resized(olib, pix, ref.shape[2], ref.shape[1])
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), k
+
+
+def test_entropy_calibration_reproduces_golden(olib):
+    """both the oracle restatement and the library's host-side KL scan (fed the exact histogram)"""
+    import ctypes as C
+    from yolo2_light_amd._lib import lib
+    g = np.load(os.path.join(AUX, "entropy.npz"))
+    for k in range(int(g["n"])):
+        x, want = np.ascontiguousarray(g["x_%d" % k]), np.float32(g["mult_%d" % k])
+        a = np.float32(olib.oracle_entropy_calibration(common.fp(x), x.size, 1.0 / 16, 4096))
+        v = np.abs(x.astype(np.float64)) / np.float64(np.float32(1.0 / 16))
+        h = np.bincount(np.minimum(np.floor(v + 0.5).astype(np.int64), 4095), minlength=4096).astype(np.uint32)
+        b = np.float32(lib.yl_entropy_from_histogram(h.ctypes.data_as(C.POINTER(C.c_uint32)), 4096, 1.0 / 16))
+        assert a.view(np.uint32) == want.view(np.uint32) and b.view(np.uint32) == want.view(np.uint32), (k, a, b, want)
+
+
+@pytest.mark.gpu
+def test_hip_front_end_reproduces_golden():
+    g = np.load(os.path.join(AUX, "front_end.npz"))
+    by_size = {}
+    for k in range(int(g["n"])):
+        ref = g["ref_%d" % k]
+        by_size.setdefault((ref.shape[2], ref.shape[1]), []).append(k)
+    for (w, h), ks in by_size.items():
+        if w % 32 or h % 32 or min(w, h) < 64:          # sizes a yolov3-tiny network can take as input
+            continue
+        cfg, wts = common.model_files("yolov3-tiny", w, h)
+        net = Network.load(cfg, wts, len(ks), 0, device=0)
+        for slot, k in enumerate(ks):
+            net.set_input_u8(slot, g["pix_%d" % k])
+        got = net.input_download()
+        for slot, k in enumerate(ks):
+            assert np.array_equal(got[slot].view(np.uint32), g["ref_%d" % k].view(np.uint32)), k
+        net.close()
