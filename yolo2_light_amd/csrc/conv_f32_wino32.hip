@@ -158,10 +158,8 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     }
     const float *u_tile = p.u + (size_t)tile_m * p.nkb * XPA;
 
-    // two staging register sets: a panel is loaded TWO iterations before it is transformed/stored,
-    // so an L2 miss (MALL/HBM, ~1-2 us) is covered by two panels of MFMAs of two workgroups
-    float xr0[16], xr1[16];
-    float ur0[2][4], ur1[2][4];
+    float xr[16];
+    float ur[2][4];
 
 #define X_LOAD_X(KB, XR)                                                                            \
     {                                                                                              \
@@ -213,53 +211,51 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     const int wt = wave & 1;
     const int ph = wave >> 1;
 
-    // ---- prologue: panels 0, 1 -> register sets 0, 1; panel 0 -> LDS stage 0; panel 2 -> set 0 ----
-    // (nkb = C/4 is even and >= 4: the launcher requires C % 8 == 0, C >= 16)
-    X_LOAD_X(0, xr0)
-    X_LOAD_U(0, ur0)
-    X_LOAD_X(1, xr1)
-    X_LOAD_U(1, ur1)
-    X_STORE_X(0, xr0)
-    X_STORE_U(0, ur0)
-    X_LOAD_X(2, xr0)
-    X_LOAD_U(2, ur0)
-    __syncthreads();
-
-    // sched_group_barrier masks: 0x008 MFMA, 0x002 VALU, 0x020 VMEM read, 0x100 DS read, 0x200 DS write.
-    // The transform (~70 VALU + 8 LDS stores per panel) must sit INSIDE the shadow of this wave's own
-    // MFMAs: measured, a VALU block in front of the 8 MFMAs costs 0.24 ms of a 1.2 ms layer even with
-    // a second workgroup on the CU.
-#define X_PIPE(MASK, N) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
-#define X_ITER(KB, XR, UR, DO_STORE, DO_LOAD)                                                              \
+    float2 fa[2][8];
+    float fb[2][8][2];
+#define X_READ_FRAGS(SET, BUF)                                                                     \
     {                                                                                              \
-        const int buf = (KB) & 1;                                                                  \
-        const float *Ab = As + buf * XPA + (8 * ph) * 128 + half * 64 + l31 * 2;                   \
-        const float *Bb = Bs + buf * XPB + (4 * ph) * 512 + half * 256 + (wt * 32 + l31) * 2;      \
-        float2 fa[8];                                                                              \
-        float fb[8][2];                                                                            \
+        const float *Ab = As + (BUF) * XPA + (8 * ph) * 128 + half * 64 + l31 * 2;                 \
+        const float *Bb = Bs + (BUF) * XPB + (4 * ph) * 512 + half * 256 + (wt * 32 + l31) * 2;    \
         _Pragma("unroll") for (int pp = 0; pp < 8; ++pp)                                           \
-            fa[pp] = *reinterpret_cast<const float2 *>(Ab + pp * 128);                             \
+            fa[SET][pp] = *reinterpret_cast<const float2 *>(Ab + pp * 128);                        \
         _Pragma("unroll") for (int pr = 0; pr < 4; ++pr)                                           \
             _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                     \
                 const float2 v2 = *reinterpret_cast<const float2 *>(Bb + pr * 512 + kk * 128);     \
-                fb[2 * pr][kk] = v2.x;                                                             \
-                fb[2 * pr + 1][kk] = v2.y;                                                         \
+                fb[SET][2 * pr][kk] = v2.x;                                                        \
+                fb[SET][2 * pr + 1][kk] = v2.y;                                                    \
             }                                                                                      \
-        /* first half: weights of panel kb+1 -> LDS, weights of panel kb+2 -> registers */         \
-        if (DO_STORE && !(X_DBG & 4)) X_STORE_U(buf ^ 1, UR)                                           \
-        if (DO_LOAD && !(X_DBG & 2)) X_LOAD_U((KB) + 3, UR)                                            \
+    }
+
+    // ---- prologue: panel 0 -> LDS stage 0 -> fragment set 0; panel 1 -> registers ----
+    // (nkb = C/4 is even and >= 4: the launcher requires C % 8 == 0, C >= 16)
+    X_LOAD_X(0, xr)
+    X_LOAD_U(0, ur)
+    X_STORE_X(0, xr)
+    X_STORE_U(0, ur)
+    X_LOAD_X(1, xr)
+    X_LOAD_U(1, ur)
+    __syncthreads();
+    X_READ_FRAGS(0, 0)
+
+    // sched_group_barrier masks: 0x008 MFMA, 0x002 VALU, 0x020 VMEM read, 0x100 DS read, 0x200 DS write.
+    // The transform (~70 VALU + LDS stores per panel) must sit INSIDE the shadow of this wave's own
+    // MFMAs: measured, a VALU block in front of the 8 MFMAs costs 0.24 ms of a 1.2 ms layer even with
+    // a second workgroup on the CU.
+#define X_PIPE(MASK, N) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
+    // One panel.  Entered with the fragments of panel kb in set SET.
+    //   first half  (8 MFMAs, k 0/1 of the panel): registers (panel kb+1) -> transform -> LDS[buf^1]
+    //   barrier     every wave has written its share of panel kb+1; the last reads of LDS[buf^1]
+    //               (fragments of panel kb-1) completed before the PREVIOUS barrier
+    //   second half (8 MFMAs, k 2/3): fragments of panel kb+1 -> set SET^1, panel kb+2 -> registers
+    // so no LDS latency is exposed in front of an MFMA block.
+#define X_ITER(KB, SET, DO_STORE, DO_LOAD)                                                         \
+    {                                                                                              \
+        const int buf = (KB) & 1;                                                                  \
+        if (DO_STORE && !(X_DBG & 4)) X_STORE_U(buf ^ 1, ur)                                       \
+        if (DO_STORE && !(X_DBG & 4)) X_STORE_X(buf ^ 1, xr)                                       \
         _Pragma("unroll") for (int pp = 0; pp < 8; ++pp)                                           \
-            if (!(X_DBG & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pp].x, fb[pp][0], acc[pp], 0, 0, 0); \
-        if (DO_STORE && X_DBG == 0) {                                                              \
-            _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) { X_PIPE(0x220, 1) }                  \
-        }                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                         \
-        /* second half: patches of panel kb+1 (loaded a whole iteration ago) -> transform -> LDS, */ \
-        /* then the patches of panel kb+2 -> the same registers                                   */ \
-        if (DO_STORE && !(X_DBG & 4)) X_STORE_X(buf ^ 1, XR)                                           \
-        if (DO_LOAD && !(X_DBG & 1)) X_LOAD_X((KB) + 3, XR)                                            \
-        _Pragma("unroll") for (int pp = 0; pp < 8; ++pp)                                           \
-            if (!(X_DBG & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pp].y, fb[pp][1], acc[pp], 0, 0, 0); \
+            if (!(X_DBG & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][pp].x, fb[SET][pp][0], acc[pp], 0, 0, 0); \
         if (DO_STORE && X_DBG == 0) {                                                              \
             _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                     \
                 X_PIPE(0x002, 9) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                \
@@ -267,18 +263,28 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         __syncthreads();                                                                           \
+        if (DO_STORE) X_READ_FRAGS((SET) ^ 1, buf ^ 1)                                             \
+        if (DO_LOAD && !(X_DBG & 1)) X_LOAD_X((KB) + 2, xr)                                        \
+        if (DO_LOAD && !(X_DBG & 2)) X_LOAD_U((KB) + 2, ur)                                        \
+        _Pragma("unroll") for (int pp = 0; pp < 8; ++pp)                                           \
+            if (!(X_DBG & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][pp].y, fb[SET][pp][1], acc[pp], 0, 0, 0); \
+        if (DO_STORE && X_DBG == 0) {                                                              \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                     \
+                X_PIPE(0x100, 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                \
+            }                                                                                      \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
     }
 
-    // iteration kb: the set holding panel kb+1 (set 1 for even kb) -> LDS[buf^1], then panel kb+3 -> that set
     int kb = 0;
-    for (; kb + 6 <= p.nkb; kb += 2) {
-        X_ITER(kb, xr1, ur1, true, true)
-        X_ITER(kb + 1, xr0, ur0, true, true)
+    for (; kb + 4 <= p.nkb; kb += 2) {
+        X_ITER(kb, 0, true, true)
+        X_ITER(kb + 1, 1, true, true)
     }
-    X_ITER(kb, xr1, ur1, true, true)
-    X_ITER(kb + 1, xr0, ur0, true, false)
-    X_ITER(kb + 2, xr1, ur1, true, false)
-    X_ITER(kb + 3, xr0, ur0, false, false)
+    X_ITER(kb, 0, true, false)
+    X_ITER(kb + 1, 1, false, false)
+    __syncthreads();            // the epilogue reuses the stages: every wave must be done reading them
+#undef X_READ_FRAGS
 #undef X_ITER
 #undef X_PIPE
 #undef X_STORE_U
