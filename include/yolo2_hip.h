@@ -247,6 +247,11 @@ int yl_debug_set_winograd(int mode);
 /* Tuning/test hook: yl_network_detect_batch's suppression stage, 1 = one workgroup per
  * (image, class) (default), 0 = one workgroup per image; same rows either way. */
 int yl_debug_set_nms_mode(int mode);
+/* Test hook (host only, no GPU needed): the Winograd weight transform U = G g G^T of a 3x3 layer
+ * (weights[m][c][3][3]) packed the way the kernels read it.  tiling 32: [m/32][c/4][xi 16][half 2][m 32][kk 2]
+ * with channel = panel*4 + 2*kk + half; tiling 64: [m/64][c/8][xi 16][half 2][m 64][kk 4], channel =
+ * panel*8 + 2*kk + half.  dst == NULL returns the number of floats needed. */
+long long yl_debug_wino_pack(const float *weights, int c, int m, int tiling, float *dst, long long dst_floats);
 
 /* On-device detection compaction (new): threshold test
  * `objectness > thresh` (src/additionally.c:4341) and box decode

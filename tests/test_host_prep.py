@@ -96,3 +96,41 @@ def test_cfg_errors_are_reported(tmp_path):
     wfile.write_bytes(b"\0" * 40)
     with pytest.raises(YoloHipError):
         net.load_weights(str(wfile))             # truncated file is refused, not half-loaded
+
+
+@pytest.mark.parametrize("C,M,tiling", [(16, 33, 32), (24, 64, 32), (64, 70, 32), (16, 33, 64), (32, 130, 64)])
+def test_winograd_weight_packing(C, M, tiling):
+    """U = G g G^T (double, rounded once) lands where the K1w kernels read it (conv_f32_wino*.hip);
+    filters beyond M are zero."""
+    import ctypes as Cc
+    from yolo2_light_amd._lib import lib
+    rng = np.random.default_rng(C * 100 + M)
+    w = rng.standard_normal((M, C, 3, 3)).astype(np.float32)
+    fp = Cc.POINTER(Cc.c_float)
+    need = lib.yl_debug_wino_pack(w.ctypes.data_as(fp), C, M, tiling, None, 0)
+    BM = tiling
+    BK = 4 if tiling == 32 else 8
+    tiles_m = (M + BM - 1) // BM
+    assert need == tiles_m * (C // BK) * 16 * BK * BM
+    dst = np.full(need, np.nan, dtype=np.float32)
+    assert lib.yl_debug_wino_pack(w.ctypes.data_as(fp), C, M, tiling, dst.ctypes.data_as(fp), need) == need
+    G = np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=np.float64)
+    g = w.astype(np.float64)
+    # same evaluation order as the C code: t = G g (left to right), u = t G^T (left to right)
+    t = np.zeros((M, C, 4, 3))
+    for i in range(4):
+        t[:, :, i, :] = G[i, 0] * g[:, :, 0, :] + G[i, 1] * g[:, :, 1, :] + G[i, 2] * g[:, :, 2, :]
+    u = np.zeros((M, C, 4, 4))
+    for j in range(4):
+        u[:, :, :, j] = t[:, :, :, 0] * G[j, 0] + t[:, :, :, 1] * G[j, 1] + t[:, :, :, 2] * G[j, 2]
+    u = u.astype(np.float32)
+    KK = BK // 2
+    p = dst.reshape(tiles_m, C // BK, 16, 2, BM, KK)          # [tile_m][panel][xi][half][m][kk]
+    for tm in range(tiles_m):
+        for ml in range(BM):
+            m = tm * BM + ml
+            for c in range(C):
+                kb, kl = divmod(c, BK)
+                got = p[tm, kb, :, kl & 1, ml, kl >> 1]
+                want = u[m, c].reshape(16) if m < M else np.zeros(16, np.float32)
+                assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (tm, ml, c)

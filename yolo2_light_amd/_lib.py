@@ -100,6 +100,7 @@ _SIGS = {
     "yl_debug_set_conv_variant": (C.c_int, [C.c_int]),
     "yl_debug_set_winograd": (C.c_int, [C.c_int]),
     "yl_debug_set_nms_mode": (C.c_int, [C.c_int]),
+    "yl_debug_wino_pack": (C.c_longlong, [c_float_p, C.c_int, C.c_int, C.c_int, c_float_p, C.c_longlong]),
     "yl_network_compact_detections": (C.c_int, [_vp, C.c_float, C.c_int, _vp, _vp]),
     "yl_network_detect_batch": (C.c_int, [_vp, c_int_p, c_int_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,
                                           _vp, _vp]),

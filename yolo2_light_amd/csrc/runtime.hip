@@ -879,6 +879,17 @@ int yl_debug_force_conv_tile(int cfg) { conv_f32_force_tile(cfg); return YL_OK; 
 int yl_debug_set_conv_variant(int v) { conv_f32_set_variant(v); return YL_OK; }
 int yl_debug_set_winograd(int mode) { conv_f32_set_winograd(mode); return YL_OK; }
 int yl_debug_set_nms_mode(int mode) { nms_set_mode(mode); return YL_OK; }
+
+long long yl_debug_wino_pack(const float *weights, int c, int m, int tiling, float *dst, long long dst_floats)
+{
+    if (!weights || c <= 0 || m <= 0 || c % 8 != 0 || (tiling != 32 && tiling != 64)) { set_error("bad argument"); return YL_ERR_ARG; }
+    const size_t need = tiling == 32 ? wino32_packed_floats(c, m) : wino_packed_floats(c, m);
+    if (!dst) return (long long)need;
+    if (dst_floats < (long long)need) { set_error("dst too small"); return YL_ERR_ARG; }
+    if (tiling == 32) wino32_pack_weights(weights, c, m, dst);
+    else wino_pack_weights(weights, c, m, dst);
+    return (long long)need;
+}
 const char *yl_debug_last_conv_tile(void) { return conv_f32_last_tile_name(); }
 
 // ------------------------------------------------------------------ INT8 calibration tool
