@@ -934,8 +934,21 @@ int yl_network_calibrate(yl_network *net, const float *images_host, int n_images
                 if (launch_hist_abs(input, (size_t)l.inputs, B, MAX_BIN, BIN_W, d_hist, s) != 0 ||
                     hipMemcpyAsync(h_hist.data(), d_hist, sizeof(unsigned) * h_hist.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
                     hipStreamSynchronize(s) != hipSuccess) { set_error("calibration histogram failed"); rc = YL_ERR_DEVICE; break; }
-                for (int b = 0; b < B; ++b)
-                    mult[i][(size_t)img0 + b] = entropy_from_counts(h_hist.data() + (size_t)b * MAX_BIN, MAX_BIN, BIN_W);
+                // the KL scans of the B images of this layer are independent: one host thread each
+                // (the reference spends most of its calibration time here, single-threaded)
+                {
+                    unsigned hw = std::thread::hardware_concurrency();
+                    const int nt = (int)(hw == 0 ? 1 : (hw > 16 ? 16 : hw));
+                    std::vector<std::thread> th;
+                    float *dst = mult[i].data() + img0;
+                    const unsigned *hh = h_hist.data();
+                    for (int t0 = 1; t0 < nt && t0 < B; ++t0)
+                        th.emplace_back([=] {
+                            for (int b = t0; b < B; b += nt) dst[b] = entropy_from_counts(hh + (size_t)b * MAX_BIN, MAX_BIN, BIN_W);
+                        });
+                    for (int b = 0; b < B; b += nt) dst[b] = entropy_from_counts(hh + (size_t)b * MAX_BIN, MAX_BIN, BIN_W);
+                    for (auto &x : th) x.join();
+                }
             }
             rc = forward_layer(n, i, input);
             input = l.d_output;
