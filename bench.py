@@ -212,7 +212,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     net.set_stream(stream.cuda_stream)
     if args.tile:
-        lib.yl_debug_force_conv_tile(args.tile)
+        net.set_conv_tile(args.tile)
 
     B = args.batch
     gen = torch.Generator(device=dev)

@@ -58,6 +58,8 @@ typedef struct yl_layer_desc {
     int outputs, inputs;      /* l.outputs, l.inputs (per image) */
     int batch_normalize;      /* 0 once yolov2_fuse_conv_batchnorm has run */
     int xnor;                 /* l.xnor */
+    int quantized;            /* l.quantized: the parser's GPU-path quantisation flag (src/additionally.c:3557-3559);
+                                 only read under YL_QUANT_RULE_GPU */
     int index;                /* shortcut: absolute index of the `from` layer (l.index) */
     const int *input_layers;  /* route: l.input_layers[n] */
     const int *input_sizes;   /* route: l.input_sizes[n]  */
@@ -112,6 +114,19 @@ int yl_network_calculate_binary_weights(yl_network *net);
 /* quantinization_and_get_multipliers(net)             src/yolov2_forward_network_quantized.c:1402 */
 int yl_network_quantize(yl_network *net);
 
+/* Which convolutions `quantized` applies to.  The reference has two rules:
+ *   YL_QUANT_RULE_CPU (default)  yolov2_forward_network_q: every conv with index >= 1 and a non-linear
+ *                                activation (src/yolov2_forward_network_quantized.c:1036)
+ *   YL_QUANT_RULE_GPU            forward_network_gpu_cudnn_quantized: the parser's `l.quantized` --
+ *                                not the first layer, not linear, not 1x1, not strided beyond layer 1, and
+ *                                nothing from the convolution two sections before the first [yolo] on
+ *                                (src/additionally.c:3557-3559, 3996-4004).  The arithmetic of a quantised
+ *                                layer is the CPU path's either way (that is the parity oracle).
+ * Call before yl_network_to_device. */
+#define YL_QUANT_RULE_CPU 0
+#define YL_QUANT_RULE_GPU 1
+int yl_network_set_quant_rule(yl_network *net, int rule);
+
 /* free_network(net)                                   src/additionally.c:2054 */
 void yl_network_destroy(yl_network *net);
 
@@ -124,6 +139,9 @@ int yl_network_input_dims(const yl_network *net, int *dims);
  *           outputs, inputs, activation, xnor, quantized(int8 used), index,
  *           classes, coords, total, softmax, reserved, batch_normalize */
 int yl_network_layer_info(const yl_network *net, int i, int *info);
+/* YOLO/REGION layer i: mask[n] (yolo: l.mask; region: 0..n-1) and anchors[2*total] (l.biases);
+ * either pointer may be NULL.  Returns n (anchors of this head), < 0 on error. */
+int yl_network_layer_head(const yl_network *net, int i, int *mask, float *anchors);
 /* borrowed host pointers to the prepared parameters of conv layer i (NULL if absent) */
 const float  *yl_network_layer_weights(const yl_network *net, int i);
 const float  *yl_network_layer_biases(const yl_network *net, int i);
@@ -179,7 +197,11 @@ int yl_network_synchronize(yl_network *net);
 /* cuda_pull_array(l.output_gpu, l.output, n)           src/gpu.cu:254
  * copies batch*outputs floats of layer i to dst_host (synchronous). */
 int yl_network_layer_output(yl_network *net, int i, float *dst_host);
-/* device pointer of layer i's output [batch][out_c][out_h][out_w] (borrowed) */
+/* the same for ONE batch item: outputs floats of image `image` (large batches: 64 x 608x608 keeps 22 GB
+ * of activations resident, a parity check wants three images of them) */
+int yl_network_layer_output_image(yl_network *net, int i, int image, float *dst_host);
+/* device pointer of layer i's output [batch][out_c][out_h][out_w] (borrowed); NULL (like the copies above:
+ * YL_ERR_STATE) for tensors the fusion plan does not materialise */
 const float *yl_network_layer_output_dev(const yl_network *net, int i);
 /* device pointer of the network input staging buffer (net.input_state_gpu, src/additionally.c:4060) */
 float *yl_network_input_dev(yl_network *net);
@@ -218,39 +240,34 @@ const char *yl_network_layer_kernel(const yl_network *net, int i);
 
 /* get_network_boxes(&net, w, h, thresh, hier, map=0, relative, &num, letter)
  *   + do_nms_sort(dets, num, classes, nms)   src/additionally.c:4403, src/box.c:296
- * computed on the HOST from the YOLO/REGION outputs pulled by yl_network_predict
- * (or yl_network_pull_heads).  rows[max_rows][6+classes]:
- *   x y w h objectness sort_class prob[classes].  Returns the number of
- * detections the reference would return (may exceed max_rows), <0 on error. */
+ * for batch item `image` of the last forward, computed ON THE DEVICE (K10 + K11, the same kernels
+ * as yl_network_detect_batch; the decode of the whole batch is cached, so looping over the images
+ * costs one pass).  rows[max_rows][6+classes]: x y w h objectness sort_class prob[classes], the
+ * reference's rows bit for bit incl. order while the count stays <= YL_DETECT_MAX_CAP.  Returns the
+ * number of detections the reference would return (may exceed max_rows), <0 on error.  Synchronous. */
 int yl_network_get_boxes(yl_network *net, int image, int w, int h, float thresh,
                          int relative, int letter, float nms,
                          float *rows, int max_rows, int *classes_out);
 
-/* D2H of every YOLO/REGION layer output (what src/yolov2_forward_network_gpu.cu:438
+/* (yl_network_get_boxes no longer needs it) D2H of every YOLO/REGION layer output (what src/yolov2_forward_network_gpu.cu:438
  * does per YOLO layer) after a yl_network_forward. */
 int yl_network_pull_heads(yl_network *net);
 
-/* Tuning/test hook: force the K1 tile configuration used by every subsequent FP32
- * conv launch in this process (0 = built-in heuristic; 1..8 see conv_f32_mfma.hip).
- * yl_debug_last_conv_tile returns the name of the tile the last launch used. */
-int yl_debug_force_conv_tile(int cfg);
-/* Tuning/test hook: K1 schedule used by networks uploaded AFTER this call:
- * 0 = v1 burst schedule, 1 = v2 software-pipelined schedule (default); with v2, forced tile
- * ids are 10 + cfg (conv_f32_mfma_v2.hip). */
-int yl_debug_set_conv_variant(int v);
-const char *yl_debug_last_conv_tile(void);
-/* Tuning/test hook: Winograd F(2x2,3x3) for FP32 3x3 / stride 1 / pad 1 convolutions
- * (conv_f32_wino.hip): 0 = off, 1 = on (default).  Takes effect for networks uploaded AFTER the
- * call (the transformed weights are packed at yl_network_to_device); with it on, forced tile id 30
- * = Winograd, any other forced tile = the direct kernel. */
-int yl_debug_set_winograd(int mode);
-/* Tuning/test hook: yl_network_detect_batch's suppression stage, 1 = one workgroup per
- * (image, class) (default), 0 = one workgroup per image; same rows either way. */
-int yl_debug_set_nms_mode(int mode);
+/* Tuning/test hooks, PER NETWORK (two networks driven from two host threads share no launch state).
+ * yl_network_set_conv_tile: force the K1 kernel of every FP32 convolution of this network, any time:
+ *   0 = built-in heuristic (default), 11..22 = direct implicit-GEMM tile 1..12 (conv_f32_mfma.hip),
+ *   31 = Winograd F(2x2,3x3) (conv_f32_wino32.hip; a launch fails on layers it does not apply to).
+ * yl_network_set_winograd: 0 = never pick Winograd heuristically and do not pack its weights, 1 = default;
+ *   BEFORE yl_network_to_device.
+ * yl_network_set_nms_mode: yl_network_detect_batch's suppression stage, 1 = one workgroup per
+ *   (image, class) (default), 0 = one workgroup per image; same rows either way. */
+int yl_network_set_conv_tile(yl_network *net, int cfg);
+int yl_network_set_winograd(yl_network *net, int on);
+int yl_network_set_nms_mode(yl_network *net, int mode);
 /* Test hook (host only, no GPU needed): the Winograd weight transform U = G g G^T of a 3x3 layer
- * (weights[m][c][3][3]) packed the way the kernels read it.  tiling 32: [m/32][c/4][xi 16][half 2][m 32][kk 2]
- * with channel = panel*4 + 2*kk + half; tiling 64: [m/64][c/8][xi 16][half 2][m 64][kk 4], channel =
- * panel*8 + 2*kk + half.  dst == NULL returns the number of floats needed. */
+ * (weights[m][c][3][3]) packed the way the kernel reads it: tiling must be 32,
+ * [m/32][c/4][xi 16][half 2][m 32][kk 2] with channel = panel*4 + 2*kk + half.
+ * dst == NULL returns the number of floats needed. */
 long long yl_debug_wino_pack(const float *weights, int c, int m, int tiling, float *dst, long long dst_floats);
 
 /* On-device detection compaction (new): threshold test

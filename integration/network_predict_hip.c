@@ -54,6 +54,7 @@ static yl_network *hip_build(network *net)
         d[i].outputs = l->outputs; d[i].inputs = l->inputs;
         d[i].batch_normalize = l->batch_normalize;
         d[i].xnor = l->xnor;
+        d[i].quantized = l->quantized;
         d[i].index = l->index;
         d[i].input_layers = l->input_layers; d[i].input_sizes = l->input_sizes;
         d[i].classes = l->classes; d[i].coords = l->coords; d[i].total = l->total; d[i].softmax = l->softmax;
@@ -76,6 +77,8 @@ static yl_network *hip_build(network *net)
                                     net->input_calibration, net->input_calibration_size, &h) != YL_OK)
         hip_fail("yl_network_create_from_desc");
     free(d);
+    /* conv+[shortcut] epilogue fusion and quantise-on-store: bit-identical head tensors, fewer kernels */
+    if (yl_network_set_fusion(h, 1) != YL_OK) hip_fail("yl_network_set_fusion");
     if (yl_network_to_device(h, gpu_index >= 0 ? gpu_index : 0) != YL_OK) hip_fail("yl_network_to_device");
     return h;
 }

@@ -32,9 +32,15 @@ CONV, MAXPOOL, ROUTE, SHORTCUT, REGION, YOLO, UPSAMPLE, REORG = 0, 3, 8, 13, 21,
 CONV_F32, CONV_INT8, CONV_XNOR = 0, 1, 2
 
 
+class OracleHead(C.Structure):
+    """struct oracle_head (oracle/detect_oracle.c)"""
+    _fields_ = [("type", C.c_int), ("w", C.c_int), ("h", C.c_int), ("n", C.c_int), ("classes", C.c_int),
+                ("outputs", C.c_int), ("output", _fp), ("mask", C.POINTER(C.c_int)), ("anchors", _fp)]
+
+
 def _build_oracle() -> None:
-    src = os.path.join(ROOT, "oracle", "yolo2_oracle.c")
-    if os.path.exists(ORACLE_SO) and os.path.getmtime(ORACLE_SO) >= os.path.getmtime(src):
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("yolo2_oracle.c", "detect_oracle.c")]
+    if os.path.exists(ORACLE_SO) and all(os.path.getmtime(ORACLE_SO) >= os.path.getmtime(s) for s in srcs):
         return
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"],
                           stdout=subprocess.DEVNULL)
@@ -65,10 +71,28 @@ def oracle_lib() -> C.CDLL:
     lib.oracle_entropy_calibration.restype = C.c_float
     lib.oracle_load_resized_u8.argtypes = [C.POINTER(C.c_ubyte)] + [i] * 5 + [_fp]
     lib.oracle_load_resized_u8.restype = None
+    lib.oracle_get_boxes.restype = C.c_int
+    lib.oracle_get_boxes.argtypes = [C.POINTER(OracleHead), i, i, i, i, i, i, C.c_float, i, i, C.c_float, _fp, i]
     for name in ("oracle_conv_f32", "oracle_conv_int8", "oracle_conv_xnor", "oracle_maxpool", "oracle_shortcut",
                  "oracle_upsample", "oracle_yolo", "oracle_region", "oracle_reorg", "oracle_fuse_bn",
                  "oracle_binary_mean"):
         getattr(lib, name).restype = None
+    return lib
+
+
+ORACLE_FAST_SO = os.path.join(ROOT, "oracle", "liboracle_fast.so")
+
+
+def oracle_fast_lib() -> C.CDLL:
+    """oracle/fast_oracle.c: the INT8 convolution of the oracle with an exact (integer) reordering +
+    OpenMP, pinned bit for bit against oracle_conv_int8 (tests/test_oracle_pin.py)."""
+    src = os.path.join(ROOT, "oracle", "fast_oracle.c")
+    if not (os.path.exists(ORACLE_FAST_SO) and os.path.getmtime(ORACLE_FAST_SO) >= os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle_fast.so"],
+                              stdout=subprocess.DEVNULL)
+    lib = C.CDLL(ORACLE_FAST_SO)
+    lib.oracle_conv_int8_fast.argtypes = [_fp, _i8p, _fp, _fp, _i32p] + [C.c_int] * 9 + [C.c_float, C.c_float]
+    lib.oracle_conv_int8_fast.restype = None
     return lib
 
 
@@ -244,6 +268,47 @@ def fp32_close(got: np.ndarray, ref: np.ndarray, rtol: float = FP32_RTOL):
     worst = int(np.argmax(ratio)) if ratio.size else 0
     return bool(np.all(np.isfinite(got)) and (ratio.size == 0 or ratio[worst] <= 1.0)), \
         float(ratio[worst]) if ratio.size else 0.0, worst
+
+
+class OracleHeads:
+    """The detection heads of a network as the oracle's decode wants them.  `outputs[i]` = the head
+    tensor of layer i ([batch*outputs] float32): by default downloaded from the device network."""
+
+    def __init__(self, net, outputs: dict = None):
+        self.netw, self.neth, _ = net.input_dims
+        self.keep = []
+        heads = []
+        for i, li in enumerate(net.layers()):
+            if li["type"] not in (YOLO, REGION):
+                continue
+            mask, anchors = net.layer_head(i)
+            out = np.ascontiguousarray(outputs[i] if outputs is not None else net.layer_output(i), dtype=np.float32)
+            mask = np.ascontiguousarray(mask, dtype=np.int32)
+            anchors = np.ascontiguousarray(anchors, dtype=np.float32)
+            self.keep += [out, mask, anchors]
+            heads.append(OracleHead(li["type"], li["w"], li["h"], li["n"], li["classes"], li["outputs"], fp(out),
+                                    mask.ctypes.data_as(C.POINTER(C.c_int)), fp(anchors)))
+        self.classes = heads[-1].classes
+        self.arr = (OracleHead * len(heads))(*heads)
+        self.n = len(heads)
+
+
+_OLIB = None
+
+
+def oracle_boxes(net_or_heads, image: int, w: int, h: int, thresh: float, nms: float = 0.0, relative: int = 1,
+                 letter: int = 0, max_rows: int = 200000) -> np.ndarray:
+    """get_network_boxes + do_nms_sort of batch item `image` by the oracle (oracle/detect_oracle.c, pinned
+    row for row against the reference in tests/test_detect_host.py) on the network's head tensors."""
+    global _OLIB
+    if _OLIB is None:
+        _OLIB = oracle_lib()
+    hd = net_or_heads if isinstance(net_or_heads, OracleHeads) else OracleHeads(net_or_heads)
+    rows = np.zeros((max_rows, 6 + hd.classes), dtype=np.float32)
+    n = _OLIB.oracle_get_boxes(hd.arr, hd.n, hd.netw, hd.neth, image, w, h, thresh, relative, letter, nms,
+                               fp(rows), max_rows)
+    assert n >= 0
+    return rows[:min(n, max_rows)].copy()
 
 
 def have_gpu() -> bool:

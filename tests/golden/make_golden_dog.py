@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""BASELINE config 1 ("yolov3-tiny.cfg 416x416 batch=1 on dog.jpg via the CPU path") as a fixture.
+
+Run in the build container (where /root/reference exists):
+    python tests/golden/make_golden_dog.py
+Everything is produced by the REFERENCE ITSELF (oracle/_ref/libyolo2ref.so = its unmodified sources):
+  pixels        the photo as the reference's stb decoder delivers it (load_image, src/additionally.c:3068),
+                HWC u8 -- (float)u8/255. reproduces load_image's tensor exactly (checked here)
+  sized_sha256  sha256 of resize_image(im, 416, 416) (src/main.c:187-189), the tensor network_predict sees
+  fp32 / int8   network_predict_cpu / network_predict_quantized on that tensor with the deterministic
+                synthetic weights (no trained weights exist offline): float64 sum / abs-sum of every layer
+                output, and the detections of src/main.c:228-229 (thresh .24, nms .4)
+"""
+import ctypes as C
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import common  # noqa: E402
+from common import refbind  # noqa: E402
+
+DOG = "/root/reference/bin/dog.jpg"
+NAME, W, H = "yolov3-tiny", 416, 416
+LOW_THRESH = 0.1
+
+
+def load_resized(lib, path, w, h):
+    out = np.zeros((3, h, w), np.float32)
+    sw, sh = C.c_int(0), C.c_int(0)
+    assert lib.ref_load_resized(path.encode(), w, h, common.fp(out), C.byref(sw), C.byref(sh)) == 0
+    return out, sw.value, sh.value
+
+
+def main():
+    lib = refbind._bind(refbind.GOLD)
+    sized, sw, sh = load_resized(lib, DOG, W, H)
+    full, _, _ = load_resized(lib, DOG, sw, sh)            # resize to its own size = identity
+    pixels = np.rint(full.astype(np.float64) * 255.0).astype(np.uint8).transpose(1, 2, 0).copy()     # HWC
+    again = (pixels.transpose(2, 0, 1).astype(np.float32) / np.float32(255.0))
+    assert np.array_equal(again.view(np.uint32), full.view(np.uint32)), "u8 round trip is not exact"
+    olib = common.oracle_lib()
+    mine = common.oracle_load_resized(olib, pixels, W, H)
+    assert np.array_equal(mine.view(np.uint32), sized.view(np.uint32)), "oracle front end != reference on dog.jpg"
+    keep = {}
+    cfg, wts = common.model_files(NAME, W, H)
+    for q, tag in ((0, "fp32"), (1, "int8")):
+        ref = refbind.RefNetwork(cfg, wts, 1, q)
+        ref.predict(sized[None])
+        sums = np.zeros((ref.n, 2), np.float64)
+        for i in range(ref.n):
+            o = ref.layer_output(i).astype(np.float64)
+            sums[i] = (o.sum(), np.abs(o).sum())
+        dets = ref.get_detections(0, sw, sh, 0.24, nms=0.4, relative=1)
+        keep[tag + "_layer_sums"] = sums
+        keep[tag + "_dets"] = dets
+        # random weights leave few boxes above .24: a second, dense set at a low threshold
+        lo = ref.get_detections(0, sw, sh, LOW_THRESH, nms=0.4, relative=1)
+        keep[tag + "_dets_low"] = lo
+        print(tag, len(dets), "detections,", len(lo), "at thresh", LOW_THRESH)
+    out = os.path.join(HERE, "dog", "dog_yolov3-tiny_416.npz")
+    np.savez_compressed(out, pixels=pixels, src_wh=np.array([sw, sh]),
+                        sized_sha256=np.array(hashlib.sha256(sized.tobytes()).hexdigest()),
+                        low_thresh=np.array(LOW_THRESH),
+                        weights_sha256=np.array(hashlib.sha256(open(wts, "rb").read()).hexdigest()), **keep)
+    print(out, os.path.getsize(out), "bytes")
+
+
+if __name__ == "__main__":
+    main()

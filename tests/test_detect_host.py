@@ -1,6 +1,6 @@
-"""Host detection decode + NMS (yl_network_get_boxes) against the reference's
-get_network_boxes + do_nms_sort on the SAME head tensors: bit-exact, same order.
-CPU only: the head tensors come from the reference CPU path."""
+"""Pins the oracle's detection decode + NMS (oracle/detect_oracle.c, the checker of the GPU
+kernels K10/K11) against the reference's own get_network_boxes + do_nms_sort on the SAME head
+tensors: bit-exact, same order.  CPU only: the head tensors come from the reference CPU path."""
 import numpy as np
 import pytest
 
@@ -47,11 +47,12 @@ def test_get_boxes_equals_reference(name, width, height, batch, nms):
     ref.predict(x)
     keep = []
     net = _head_only_network(ref, open(cfg).read(), batch, keep)
+    heads = common.OracleHeads(net, outputs={i: keep[i] for i in range(len(keep))})
     total = 0
     for b in range(batch):
         for (iw, ih, rel) in [(width, height, 1), (768, 576, 0)]:
             r = ref.get_detections(b, iw, ih, 0.24, nms=nms, relative=rel)
-            g = net.get_boxes(b, iw, ih, 0.24, nms=nms, relative=rel)
+            g = common.oracle_boxes(heads, b, iw, ih, 0.24, nms=nms, relative=rel)
             assert r.shape == g.shape, (b, r.shape, g.shape)
             assert np.array_equal(r.view(np.uint32), g.view(np.uint32)), "image %d" % b
             total += len(r)

@@ -131,3 +131,16 @@ def test_hip_front_end_reproduces_golden():
         for slot, k in enumerate(ks):
             assert np.array_equal(got[slot].view(np.uint32), g["ref_%d" % k].view(np.uint32)), k
         net.close()
+
+
+def test_dog_fixture_front_end(olib):
+    """tests/golden/dog (BASELINE config 1): the photo as the reference's decoder delivered it, through the
+    oracle's load_image + resize_image restatement, is the tensor the reference fed its network (sha256)."""
+    import hashlib
+    z = np.load(os.path.join(common.GOLDEN_DIR, "dog", "dog_yolov3-tiny_416.npz"))
+    pixels = z["pixels"]
+    sw, sh = (int(v) for v in z["src_wh"])
+    assert pixels.shape == (sh, sw, 3) and pixels.dtype == np.uint8
+    sized = common.oracle_load_resized(olib, pixels, 416, 416)
+    assert hashlib.sha256(sized.tobytes()).hexdigest() == str(z["sized_sha256"])
+    assert len(z["fp32_dets_low"]) > 100 and z["fp32_dets_low"].shape[1] == 86

@@ -1,7 +1,7 @@
 """batched get_network_boxes + do_nms_sort on the GPU (yl_network_detect_batch /
-yl_network_get_boxes_batch, csrc/detect.hip) against the host decode + qsort NMS
-(yl_network_get_boxes = csrc/host_detect.cpp, itself pinned row for row against the reference's
-get_network_boxes/do_nms_sort in tests/test_detect_host.py).
+yl_network_get_boxes_batch / yl_network_get_boxes, csrc/detect.hip) against the oracle's decode +
+qsort NMS (common.oracle_boxes = oracle/detect_oracle.c, itself pinned row for row against the
+reference's get_network_boxes/do_nms_sort in tests/test_detect_host.py) on the same head tensors.
 
 Bar: rows bit-identical INCLUDING ORDER -- the kernel replays the reference's class-by-class
 stable sort, so ties and the order the last class leaves behind must come out the same.
@@ -46,17 +46,20 @@ def test_detect_batch_rows_equal_reference_rows(name, width, height, batch, thre
     x = common.seeded_input(batch, 3, height, width)
     net.predict(x)                                   # also pulls the heads for the host decode
     rows, counts = net.get_boxes_batch(thresh, nms, cap=2048, sizes=sizes, relative=relative, letter=letter)
+    heads = common.OracleHeads(net)
     suppressed = 0
     for b in range(batch):
         if sizes is None:
             w, h = 1, 1
         else:
             w, h = sizes if isinstance(sizes, tuple) else sizes[b]
-        host = net.get_boxes(b, w, h, thresh, nms=nms, relative=relative, letter=letter)
+        host = common.oracle_boxes(heads, b, w, h, thresh, nms=nms, relative=relative, letter=letter)
         assert counts[b] == len(host)
         _same_rows(rows[b], host, (name, "image", b))
+        # the single-image entry point (the reference's get_network_boxes + do_nms_sort call) is the same pass
+        _same_rows(net.get_boxes(b, w, h, thresh, nms=nms, relative=relative, letter=letter), host, (name, "get_boxes", b))
         if nms > 0:
-            plain = net.get_boxes(b, w, h, thresh, nms=0.0, relative=relative, letter=letter)
+            plain = common.oracle_boxes(heads, b, w, h, thresh, nms=0.0, relative=relative, letter=letter)
             suppressed += int((plain[:, 6:] > 0).sum() - (host[:, 6:] > 0).sum())
     assert sum(counts) > 0, "threshold too high for the synthetic weights: test is vacuous"
     if nms > 0:
@@ -91,7 +94,7 @@ def test_ties_and_large_class_follow_the_stable_sort():
     for nms in (0.45, 0.2, 0.8):
         rows, counts = net.get_boxes_batch(0.3, nms, cap=256)
         for b in range(B):
-            host = net.get_boxes(b, 1, 1, 0.3, nms=nms)
+            host = common.oracle_boxes(net, b, 1, 1, 0.3, nms=nms)
             assert counts[b] == len(host) == n * w * h
             _same_rows(rows[b], host, ("ties", nms, b))
     net.close()
@@ -108,7 +111,7 @@ def test_zero_objectness_detections_move_to_the_end():
     net = _yolo_only_net(B, w, h, n, classes, [2.0, 2.0, 3.0, 1.5])
     net.predict(x.reshape(B, -1))
     rows, counts = net.get_boxes_batch(-1.0, 0.45, cap=64)
-    host = net.get_boxes(0, 1, 1, -1.0, nms=0.45)
+    host = common.oracle_boxes(net, 0, 1, 1, -1.0, nms=0.45)
     assert (host[:, 4] == 0).any()
     assert counts[0] == len(host)
     _same_rows(rows[0], host, "zero objectness")
@@ -150,22 +153,18 @@ def test_parallel_and_sequential_suppression_agree_on_a_dense_head():
     """an untrained head at a low threshold: ~1000 boxes per image, dozens of positive classes each
     (every class active, long sorted lists, the m > 64 chunks) -- the (image, class)-parallel path
     and the one-workgroup-per-image path must produce the same bytes, and both the host rows"""
-    from yolo2_light_amd._lib import lib
     cfg, wts = common.model_files("yolov3-tiny", 416, 416)
     net = Network.load(cfg, wts, 3, 0, device=0)
     x = common.seeded_input(3, 3, 416, 416)
     net.predict(x)
-    try:
-        lib.yl_debug_set_nms_mode(0)
-        seq, c0 = net.get_boxes_batch(0.02, 0.45, cap=2048)
-        lib.yl_debug_set_nms_mode(1)
-        par, c1 = net.get_boxes_batch(0.02, 0.45, cap=2048)
-    finally:
-        lib.yl_debug_set_nms_mode(1)
+    net.set_nms_mode(0)
+    seq, c0 = net.get_boxes_batch(0.02, 0.45, cap=2048)
+    net.set_nms_mode(1)
+    par, c1 = net.get_boxes_batch(0.02, 0.45, cap=2048)
     assert np.array_equal(c0, c1) and max(c0) > 300
     for b in range(3):
         assert np.array_equal(seq[b].view(np.uint32), par[b].view(np.uint32)), b
         if c0[b] <= 2048:
-            host = net.get_boxes(b, 1, 1, 0.02, nms=0.45)
+            host = common.oracle_boxes(net, b, 1, 1, 0.02, nms=0.45)
             _same_rows(par[b], host, ("dense", b))
     net.close()

@@ -1,0 +1,229 @@
+"""Parity on the configurations the metric is quoted on (BASELINE.json configs 1, 3, 4):
+
+  * yolov3 608x608 batch 64 FP32 with fusion on (= the benched setup): images 0, 31, 63 equal, bit for
+    bit on every materialised tensor and on the detection rows, a batch-1 run of the same image; the
+    batch-1 fused run equals the batch-1 unfused run, which tests/test_gpu_parity.py pins to the
+    reference library at this size.  At batch 64 tile counts, 32-bit buffer offsets (layer 0 writes
+    3.03 GB > 2^31) and the fused-shortcut / Winograd dispatch differ from batch 1.
+  * the same for `-quantized` at 608, plus every layer of a 608x608 batch-1 INT8 run checked
+    teacher-forced (each layer against the oracle applied to the GPU's own input of that layer):
+    accumulators and outputs bit-exact.  The INT8 convolutions use oracle/fast_oracle.c (exact
+    integer reordering of oracle_conv_int8, pinned to it in tests/test_oracle_pin.py).
+  * dog.jpg (config 1): the reference's decoded photo -> GPU front end -> yolov3-tiny 416 against the
+    fixture the reference CPU path produced (tests/golden/make_golden_dog.py), and through the
+    reference's own host code + network_predict_hip when oracle/_ref is present.
+"""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import common
+from common import Network, fp, fp32_close, refbind
+
+pytestmark = pytest.mark.gpu
+
+_i8p = C.POINTER(C.c_int8)
+_i32p = C.POINTER(C.c_int32)
+IMAGES = (0, 31, 63)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def _batch64_equals_batch1(quantized):
+    name, size, B = "yolov3", 608, 64
+    cfg, wts = common.model_files(name, size, size)
+    x = common.seeded_input(B, 3, size, size)
+    big = Network.load(cfg, wts, B, quantized, device=0, fuse=True)
+    big.predict(x)
+    one = Network.load(cfg, wts, 1, quantized, device=0, fuse=True)
+    plain = Network.load(cfg, wts, 1, quantized, device=0, fuse=False)
+    n_checked = 0
+    for b in IMAGES:
+        one.predict(x[b:b + 1])
+        for i in range(one.n):
+            if not one.layer_materialised(i):
+                assert not big.layer_materialised(i)
+                continue
+            a = big.layer_output_image(i, b)
+            r = one.layer_output(i)
+            assert np.array_equal(_bits(a), _bits(r)), "image %d layer %d %r: batch-64 != batch-1" % (b, i, one.layer_info(i))
+            n_checked += 1
+        rows64 = big.get_boxes(b, size, size, 0.24, nms=0.4)
+        rows1 = one.get_boxes(0, size, size, 0.24, nms=0.4)
+        assert rows64.shape == rows1.shape and np.array_equal(_bits(rows64), _bits(rows1)), "image %d detection rows" % b
+        rows64 = big.get_boxes(b, size, size, 0.005, nms=0.45)          # a dense set
+        rows1 = one.get_boxes(0, size, size, 0.005, nms=0.45)
+        assert len(rows1) > 50
+        assert rows64.shape == rows1.shape and np.array_equal(_bits(rows64), _bits(rows1)), "image %d dense rows" % b
+    # fused == unfused at batch 1 (the unfused FP32 run is what is pinned to the reference library)
+    plain.predict(x[IMAGES[-1]:IMAGES[-1] + 1])
+    for i in range(one.n):
+        if one.layer_materialised(i):
+            assert np.array_equal(_bits(plain.layer_output(i)), _bits(one.layer_output(i))), "fused != unfused, layer %d" % i
+    assert n_checked > 3 * 60
+    big.close(); one.close(); plain.close()
+
+
+def test_yolov3_608_batch64_fp32_fused_equals_batch1():
+    _batch64_equals_batch1(0)
+
+
+def test_yolov3_608_batch64_int8_fused_equals_batch1():
+    _batch64_equals_batch1(1)
+
+
+def test_yolov3_608_int8_every_layer_teacher_forced(olib):
+    name, size = "yolov3", 608
+    fast = common.oracle_fast_lib()
+    cfg, wts = common.model_files(name, size, size)
+    net = Network.load(cfg, wts, 1, 1, device=0, debug=True)
+    x = common.seeded_input(1, 3, size, size, seed=77)
+    net.predict(x)
+    infos = net.layers()
+    from yolo2_light_amd import zoo
+    route_inputs = {}
+    for i, (typ, o) in enumerate(zoo.parse_sections(open(cfg).read())[1:]):
+        if typ == "route":
+            ids = [int(v) for v in o["layers"].split(",")]
+            route_inputs[i] = [j + i if j < 0 else j for j in ids]
+    outs = {}
+
+    def out(i):
+        if i not in outs:
+            outs[i] = net.layer_output(i)
+        return outs[i]
+
+    n_int8 = 0
+    for i, li in enumerate(infos):
+        cur = x.reshape(-1) if i == 0 else out(i - 1)
+        ref = np.zeros(li["outputs"], np.float32)
+        t = li["type"]
+        exact = True
+        if t == common.CONV:
+            b_ = net.layer_biases(i)
+            if li["conv_mode"] == common.CONV_INT8:
+                wq = net.layer_weights_int8(i)
+                im, wm = net.layer_quant_multipliers(i)
+                racc = np.zeros(ref.size, np.int32)
+                fast.oracle_conv_int8_fast(fp(cur), wq.ctypes.data_as(_i8p), fp(b_), fp(ref), racc.ctypes.data_as(_i32p),
+                                           1, li["c"], li["h"], li["w"], li["n"], li["size"], li["stride"], li["pad"],
+                                           li["activation"], im, wm)
+                assert np.array_equal(net.layer_int8_acc(i), racc), "layer %d int8 accumulators" % i
+                n_int8 += 1
+            else:
+                olib.oracle_conv_f32(fp(cur), fp(net.layer_weights(i)), fp(b_), fp(ref), 1, li["c"], li["h"], li["w"],
+                                     li["n"], li["size"], li["stride"], li["pad"], li["activation"])
+                exact = False
+        elif t == common.ROUTE:
+            ref = np.concatenate([out(j) for j in route_inputs[i]])
+        elif t == common.SHORTCUT:
+            olib.oracle_shortcut(fp(cur), fp(out(li["index"])), fp(ref), 1, li["w"], li["h"], li["c"],
+                                 li["out_w"], li["out_h"], li["out_c"], li["activation"])
+        elif t == common.UPSAMPLE:
+            olib.oracle_upsample(fp(cur), fp(ref), 1, li["c"], li["h"], li["w"], li["stride"], 1.0)
+        elif t == common.YOLO:
+            olib.oracle_yolo(fp(cur), fp(ref), 1, li["n"], li["classes"], li["w"] * li["h"])
+            exact = False
+        else:
+            raise AssertionError("unexpected layer type %d" % t)
+        got = out(i)
+        if exact:
+            assert np.array_equal(_bits(got), _bits(ref)), "layer %d %r not bit-exact" % (i, li)
+        else:
+            ok, ratio, worst = fp32_close(got, ref)
+            assert ok, "layer %d %r: err/allowed %.3g" % (i, li, ratio)
+    assert n_int8 == 71
+    net.close()
+
+
+# ---------------------------------------------------------------------------- dog.jpg (config 1)
+DOG = os.path.join(common.GOLDEN_DIR, "dog", "dog_yolov3-tiny_416.npz")
+
+
+def _match_rows(r, g):
+    """fraction of reference rows r that have a row of g with the same box (1e-4 rel)"""
+    if not len(r) or not len(g):
+        return 1.0 if len(r) == len(g) else 0.0, None
+    with np.errstate(invalid="ignore", over="ignore"):
+        dist = (np.abs(r[:, None, :4] - g[None, :, :4]) / (1e-5 + 1e-4 * np.abs(r[:, None, :4]))).max(axis=2)
+    dist = np.nan_to_num(dist, nan=0.0)
+    j = dist.argmin(axis=1)
+    ok = dist[np.arange(len(r)), j] < 1.0
+    return ok.mean(), (ok, j)
+
+
+def test_dog_jpg_fp32_against_the_reference_cpu_fixture():
+    z = np.load(DOG)
+    pixels = z["pixels"]
+    sw, sh = (int(v) for v in z["src_wh"])
+    name, W, H = "yolov3-tiny", 416, 416
+    cfg, wts = common.model_files(name, W, H)
+    assert hashlib.sha256(open(wts, "rb").read()).hexdigest() == str(z["weights_sha256"]), "synthetic weights changed"
+    net = Network.load(cfg, wts, 1, 0, device=0)
+    net.set_input_u8(0, pixels)                               # GPU /255 + resize_image of the decoded photo
+    sized = net.input_download()
+    assert hashlib.sha256(sized.tobytes()).hexdigest() == str(z["sized_sha256"]), "front end differs from the reference's sized.data"
+    net.forward_staged()
+    net.synchronize()
+    sums = z["fp32_layer_sums"]
+    for i in range(net.n):
+        o = net.layer_output(i).astype(np.float64)
+        # sum of N terms each within 1e-4 relative: compare against the abs-sum scale
+        assert abs(o.sum() - sums[i, 0]) <= 1e-4 * sums[i, 1] + 1e-6, "layer %d sum" % i
+        assert abs(np.abs(o).sum() - sums[i, 1]) <= 1e-4 * sums[i, 1] + 1e-6, "layer %d abs-sum" % i
+    for key, thresh in (("fp32_dets", 0.24), ("fp32_dets_low", float(z["low_thresh"]))):
+        r = z[key]
+        g = net.get_boxes(0, sw, sh, thresh, nms=0.4)
+        assert abs(len(r) - len(g)) <= max(2, len(r) // 50), (key, len(r), len(g))
+        frac, m = _match_rows(r, g)
+        assert frac > 0.98, (key, frac)
+        if m is not None:
+            ok, j = m
+            np.testing.assert_allclose(g[j[ok]][:, 4], r[ok][:, 4], rtol=1e-4, atol=1e-5)
+    assert len(z["fp32_dets_low"]) > 100
+    net.close()
+
+
+@pytest.mark.skipif(not os.path.exists(refbind.HIP), reason="oracle/_ref/libyolo2ref_hip.so not built")
+@pytest.mark.parametrize("quantized", [0, 1])
+def test_dog_jpg_reference_host_code_cpu_vs_hip(quantized):
+    """src/main.c:187-229 on the photo: load_image + resize_image (fixture pixels through the pinned
+    oracle front end = the reference's sized.data), then network_predict_cpu / _quantized vs
+    network_predict_hip on the SAME network object, then the reference's own get_network_boxes + do_nms_sort."""
+    z = np.load(DOG)
+    sw, sh = (int(v) for v in z["src_wh"])
+    name, W, H = "yolov3-tiny", 416, 416
+    cfg, wts = common.model_files(name, W, H)
+    sized = common.oracle_load_resized(common.oracle_lib(), z["pixels"], W, H)
+    assert hashlib.sha256(sized.tobytes()).hexdigest() == str(z["sized_sha256"])
+    ref = refbind.RefNetwork(cfg, wts, 1, quantized, hip=True)
+    x = sized[None]
+    ref.predict(x)
+    heads = [i for i in range(ref.n) if ref.layer_info(i)["type"] == common.YOLO]
+    cpu_heads = {i: ref.layer_output(i) for i in heads}
+    thresh = float(z["low_thresh"])
+    cpu_dets = ref.get_detections(0, sw, sh, thresh, nms=0.4)
+    key = "int8_dets_low" if quantized else "fp32_dets_low"
+    assert np.array_equal(_bits(cpu_dets), _bits(z[key])), "the reference no longer reproduces its own fixture"
+    ref.predict_hip(x)
+    for i in heads:
+        got, want = ref.layer_output(i), cpu_heads[i]
+        if quantized:
+            # int8 codes are step functions of the (1e-6-different) FP32 first layer: statistical agreement,
+            # layer exactness is established teacher-forced
+            g = got.astype(np.float64); r = want.astype(np.float64)
+            assert np.sqrt(np.mean((g - r) ** 2)) / np.sqrt(np.mean(r * r)) < 0.05
+        else:
+            ok, ratio, _ = fp32_close(got, want)
+            assert ok, "head %d: err/allowed %.3g" % (i, ratio)
+    hip_dets = ref.get_detections(0, sw, sh, thresh, nms=0.4)
+    if not quantized:
+        assert abs(len(hip_dets) - len(cpu_dets)) <= max(2, len(cpu_dets) // 50)
+        frac, _ = _match_rows(cpu_dets, hip_dets)
+        assert frac > 0.98
+    ref.lib.ref_free_hip()

@@ -52,7 +52,7 @@ def test_frames_through_the_whole_path(olib):
         for a, b_ in zip(heads_staged, heads_ref):
             assert np.array_equal(a.view(np.uint32), b_.view(np.uint32)), rnd
         for b in range(B):
-            host = net.get_boxes(b, sw, sh, 0.1, nms=0.45, relative=0)
+            host = common.oracle_boxes(net, b, sw, sh, 0.1, nms=0.45, relative=0)
             assert counts[b] == len(host)
             assert np.array_equal(rows[b].view(np.uint32), host.view(np.uint32)), (rnd, b)
     net.close()

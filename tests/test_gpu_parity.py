@@ -48,14 +48,14 @@ CONV_SHAPES = [
 ]
 
 
-# (variant, forced tile): variant 0 = v1 burst schedule (tiles 1..8), variant 1 = v2 software-pipelined
-# schedule with tap-major K order where C % 16 == 0 (tiles 11..19); tile 0 = the built-in heuristic
-VARIANT_TILES = [(0, t) for t in range(0, 9)] + [(1, 0)] + [(1, t) for t in range(11, 23)]
+# forced tile of the direct kernel (yl_network_set_conv_tile): 0 = the built-in heuristic, 11..22 = every
+# tile configuration of conv_f32_mfma.hip (tap-major K order where C % 16 == 0)
+TILES = [0] + list(range(11, 23))
 
 
 @pytest.mark.parametrize("shape", CONV_SHAPES)
-@pytest.mark.parametrize("variant,tile", VARIANT_TILES)
-def test_conv_f32_vs_oracle(olib, shape, variant, tile):
+@pytest.mark.parametrize("tile", TILES)
+def test_conv_f32_vs_oracle(olib, shape, tile):
     B, Cc, H, W, M, size, stride, pad, act = shape
     rng = np.random.default_rng(1234 + M + size)
     K = Cc * size * size
@@ -63,24 +63,19 @@ def test_conv_f32_vs_oracle(olib, shape, variant, tile):
     bias = rng.normal(0, 0.5, M).astype(np.float32)
     x = rng.standard_normal((B, Cc, H, W)).astype(np.float32)
     d = D.conv(B, W, H, Cc, M, size, stride, pad, act, wts, bias)
-    lib.yl_debug_set_conv_variant(variant)
-    lib.yl_debug_force_conv_tile(tile)
-    try:
-        net = _net_from([d], B, W, H, Cc)
-        got = net.predict(x)
-    finally:
-        lib.yl_debug_force_conv_tile(0)
-        lib.yl_debug_set_conv_variant(1)
+    net = _net_from([d], B, W, H, Cc)
+    net.set_conv_tile(tile)
+    got = net.predict(x)
     ref = np.zeros(B * d.outputs, dtype=np.float32)
     olib.oracle_conv_f32(fp(x), fp(wts), fp(bias), fp(ref), B, Cc, H, W, M, size, stride, pad, act)
     ok, ratio, worst = fp32_close(got, ref)
-    assert ok, "variant %d tile %d shape %r: err/allowed %.3g at %d: got %r ref %r" % (variant, tile, shape, ratio, worst, got[worst], ref[worst])
+    assert ok, "tile %d shape %r: err/allowed %.3g at %d: got %r ref %r" % (tile, shape, ratio, worst, got[worst], ref[worst])
     # MFMA f32 is an fma chain: expect f32-roundoff-class agreement, far inside the 1e-4 bar
     assert ratio < 0.2
     net.close()
 
 
-# K1w: Winograd F(2x2,3x3) kernel (forced tile 30), 3x3 / stride 1 / pad 1 only
+# K1w: Winograd F(2x2,3x3) kernel (forced tile 31), 3x3 / stride 1 / pad 1 only
 WINO_SHAPES = [
     # B, C, H, W, M, act
     (2, 16, 13, 13, 33, D.LEAKY),          # 2 panels, M tail, odd size, 49 tiles/image: a block spans 2 images
@@ -96,8 +91,7 @@ WINO_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", WINO_SHAPES)
-@pytest.mark.parametrize("wtile", [30, 31])        # 64-filter tiling / 32-filter two-workgroups-per-CU tiling
-def test_conv_winograd_vs_oracle(olib, shape, wtile):
+def test_conv_winograd_vs_oracle(olib, shape):
     B, Cc, H, W, M, act = shape
     rng = np.random.default_rng(99 + M + H)
     K = Cc * 9
@@ -105,25 +99,19 @@ def test_conv_winograd_vs_oracle(olib, shape, wtile):
     bias = rng.normal(0, 0.5, M).astype(np.float32)
     x = (rng.standard_normal((B, Cc, H, W)) + 0.3).astype(np.float32)
     d = D.conv(B, W, H, Cc, M, 3, 1, 1, act, wts, bias)
-    lib.yl_debug_force_conv_tile(wtile)
-    try:
-        net = _net_from([d], B, W, H, Cc)
-        got = net.predict(x)
-        assert "wino" in net.layer_kernel(0)
-    finally:
-        lib.yl_debug_force_conv_tile(0)
+    net = _net_from([d], B, W, H, Cc)
+    net.set_conv_tile(31)
+    got = net.predict(x)
+    assert "wino" in net.layer_kernel(0)
     ref = np.zeros(B * d.outputs, dtype=np.float32)
     olib.oracle_conv_f32(fp(x), fp(wts), fp(bias), fp(ref), B, Cc, H, W, M, 3, 1, 1, act)
     ok, ratio, worst = fp32_close(got, ref)
     assert ok, "shape %r: err/allowed %.3g at %d: got %r ref %r" % (shape, ratio, worst, got[worst], ref[worst])
     assert ratio < 0.2         # measured ~0.03: the transforms add/subtract only
     # the direct kernel on the same layer agrees to roundoff as well
-    lib.yl_debug_force_conv_tile(14)
-    try:
-        direct = net.predict(x)
-        assert "wino" not in net.layer_kernel(0)
-    finally:
-        lib.yl_debug_force_conv_tile(0)
+    net.set_conv_tile(14)
+    direct = net.predict(x)
+    assert "wino" not in net.layer_kernel(0)
     ok2, ratio2, _ = fp32_close(got, direct)
     assert ok2 and ratio2 < 0.2
     net.close()
@@ -135,14 +123,13 @@ def test_winograd_switch_off_keeps_direct_kernel():
     wts = rng.normal(0, 0.05, M * Cc * 9).astype(np.float32)
     d = D.conv(B, W, H, Cc, M, 3, 1, 1, D.LEAKY, wts, np.zeros(M, np.float32))
     x = rng.standard_normal((B, Cc, H, W)).astype(np.float32)
-    lib.yl_debug_set_winograd(0)
-    try:
-        net = _net_from([d], B, W, H, Cc)
-        net.predict(x)
-        assert "wino" not in net.layer_kernel(0)
-        net.close()
-    finally:
-        lib.yl_debug_set_winograd(1)
+    from yolo2_light_amd._lib import check
+    net = Network.from_desc([d], B, W, H, Cc, 0)
+    check(lib.yl_network_set_winograd(net._h, 0), "set_winograd")
+    net.to_device(0)
+    net.predict(x)
+    assert "wino" not in net.layer_kernel(0)
+    net.close()
     net = _net_from([d], B, W, H, Cc)
     net.predict(x)
     assert "wino" in net.layer_kernel(0)
@@ -388,7 +375,7 @@ def test_compact_detections_matches_host_decode():
     net.synchronize()
     rec = rec.cpu().numpy(); cnt = cnt.cpu().numpy()
     for b in range(batch):
-        host = net.get_boxes(b, 1, 1, 0.24, nms=0.0, relative=1)
+        host = common.oracle_boxes(net, b, 1, 1, 0.24, nms=0.0, relative=1)
         assert cnt[b] == len(host)
         dev = rec[b, :cnt[b]]
         # order differs (atomic slots): sort both by (objectness, x, y)

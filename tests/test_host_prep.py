@@ -98,7 +98,7 @@ def test_cfg_errors_are_reported(tmp_path):
         net.load_weights(str(wfile))             # truncated file is refused, not half-loaded
 
 
-@pytest.mark.parametrize("C,M,tiling", [(16, 33, 32), (24, 64, 32), (64, 70, 32), (16, 33, 64), (32, 130, 64)])
+@pytest.mark.parametrize("C,M,tiling", [(16, 33, 32), (24, 64, 32), (64, 70, 32), (32, 130, 32)])
 def test_winograd_weight_packing(C, M, tiling):
     """U = G g G^T (double, rounded once) lands where the K1w kernels read it (conv_f32_wino*.hip);
     filters beyond M are zero."""
@@ -134,3 +134,29 @@ def test_winograd_weight_packing(C, M, tiling):
                 got = p[tm, kb, :, kl & 1, ml, kl >> 1]
                 want = u[m, c].reshape(16) if m < M else np.zeros(16, np.float32)
                 assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (tm, ml, c)
+
+
+@pytest.mark.skipif(not refbind.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name,width,height", [("yolov3", 64, 64), ("yolov3-tiny", 96, 96), ("yolov3-spp", 64, 64),
+                                               ("yolov2-voc", 96, 96), ("tiny-yolo-voc", 96, 96)])
+def test_gpu_quant_rule_selects_the_reference_parsers_l_quantized(name, width, height):
+    """yl_network_set_quant_rule(GPU): the INT8 layer set == `l.quantized` of the reference's own parse
+    (src/additionally.c:3557-3559, 3996-4004); the default CPU rule == yolov2_forward_network_q's
+    `i >= 1 && activation != LINEAR` (src/yolov2_forward_network_quantized.c:1036)."""
+    cfg, wts = common.model_files(name, width, height)
+    ref = refbind.RefNetwork(cfg, wts, 1, 1)
+    gpu = Network.load(cfg, wts, 1, 1, quant_rule=1)
+    cpu = Network.load(cfg, wts, 1, 1)
+    n_gpu = n_cpu = 0
+    for i in range(ref.n):
+        ri = ref.layer_info(i)
+        if ri["type"] != common.CONV:
+            continue
+        assert gpu.layer_info(i)["int8"] == (1 if ri["quantized"] else 0), "layer %d: GPU rule" % i
+        want_cpu = 1 if (i >= 1 and ri["activation"] != 3) else 0
+        assert cpu.layer_info(i)["int8"] == want_cpu, "layer %d: CPU rule" % i
+        n_gpu += gpu.layer_info(i)["int8"]
+        n_cpu += want_cpu
+    assert 0 < n_gpu <= n_cpu        # the GPU rule is the stricter one (no 1x1, nothing near the [yolo] heads)
+    if name.startswith("yolov3"):
+        assert n_gpu < n_cpu

@@ -143,3 +143,36 @@ def test_entropy_calibration_matches_reference(olib, seed, n, scale, shape):
     ref = rl.ref_entropy_calibration(common.fp(x), x.size, 1.0 / 16, 4096)
     got = olib.oracle_entropy_calibration(common.fp(x), x.size, 1.0 / 16, 4096)
     assert np.float32(got).view(np.uint32) == np.float32(ref).view(np.uint32), (got, ref)
+
+
+def test_fast_int8_oracle_equals_oracle(olib):
+    """oracle/fast_oracle.c (tap-outermost integer accumulation, OpenMP) == oracle_conv_int8 bit for bit:
+    accumulators and outputs, incl. stride 2, 1x1, no padding, the int16 wrap corner and the clamp."""
+    import ctypes as C
+    fast = common.oracle_fast_lib()
+    i8p, i32p = C.POINTER(C.c_int8), C.POINTER(C.c_int32)
+    rng = np.random.default_rng(4)
+    for (B, Cc, H, W, M, size, stride, pad) in [(2, 16, 13, 11, 24, 3, 1, 1), (1, 32, 19, 23, 20, 3, 2, 1),
+                                                (2, 64, 9, 7, 33, 1, 1, 0), (1, 8, 10, 10, 6, 3, 1, 0),
+                                                (1, 5, 12, 9, 7, 5, 2, 2), (1, 2048, 4, 4, 3, 3, 1, 1)]:
+        K = Cc * size * size
+        wts = rng.normal(0, 0.7 if Cc < 2048 else 4.0, M * K).astype(np.float32)
+        wq = np.zeros(M * K, np.int8)
+        w_mult = olib.oracle_quantize_weights(common.fp(wts), M * K, wq.ctypes.data_as(i8p))
+        if Cc == 2048:
+            wq[:] = np.where(rng.random(M * K) < 0.5, 127, 120).astype(np.int8)     # drives |acc/32| past 32767
+        bias = rng.normal(0, 0.5, M).astype(np.float32)
+        in_mult = 11.3
+        x = (rng.standard_normal((B, Cc, H, W)) * (3 if Cc < 2048 else 40)).astype(np.float32)
+        x.reshape(-1)[:6] = [1e9, -1e9, 40000.7 / in_mult, -33000.2 / in_mult, 127.9 / in_mult, -128.5 / in_mult]
+        oh, ow = (H + 2 * pad - size) // stride + 1, (W + 2 * pad - size) // stride + 1
+        a = np.zeros(B * M * oh * ow, np.float32); b = np.zeros_like(a)
+        aa = np.zeros(a.size, np.int32); ba = np.zeros(a.size, np.int32)
+        olib.oracle_conv_int8(common.fp(x), wq.ctypes.data_as(i8p), common.fp(bias), common.fp(a), aa.ctypes.data_as(i32p),
+                              B, Cc, H, W, M, size, stride, pad, 7, in_mult, w_mult)
+        fast.oracle_conv_int8_fast(common.fp(x), wq.ctypes.data_as(i8p), common.fp(bias), common.fp(b),
+                                   ba.ctypes.data_as(i32p), B, Cc, H, W, M, size, stride, pad, 7, in_mult, w_mult)
+        assert np.array_equal(aa, ba)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        if Cc == 2048:
+            assert (np.abs(aa) == 32767).any(), "clamp corner not reached"

@@ -30,19 +30,16 @@ SHAPES_608 = [
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--tiles", default="0,12,14,20,22,30",
-                    help="forced tile ids: 1..8 = v1 kernel, 11..19 = v2 pipelined kernel, 0 = heuristic, 30 = Winograd (3x3/1/1 only)")
-    ap.add_argument("--variant", type=int, default=1, help="0 = v1 (c-major weights), 1 = v2 (tap-major where possible)")
+    ap.add_argument("--tiles", default="0,12,14,20,22,31",
+                    help="forced tile ids: 11..22 = direct kernel tiles, 0 = heuristic, 31 = Winograd (3x3/1/1 only)")
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--only", default="", help="comma list of shape indices")
     args = ap.parse_args()
     import torch
     import descs as D
     from yolo2_light_amd import Network
-    from yolo2_light_amd._lib import lib
 
     tiles = [int(t) for t in args.tiles.split(",")]
-    lib.yl_debug_set_conv_variant(args.variant)
     only = [int(i) for i in args.only.split(",")] if args.only else range(len(SHAPES_608))
     rng = np.random.default_rng(0)
     B = args.batch
@@ -55,16 +52,13 @@ def main():
         wts = rng.normal(0, np.sqrt(2.0 / K), M * K).astype(np.float32)
         bias = rng.normal(0, 0.1, M).astype(np.float32)
         d = D.conv(B, H, H, Cc, M, size, stride, pad, D.LEAKY, wts, bias)
-        if 30 in tiles:                    # the 64-filter Winograd tiling is packed only while forced
-            lib.yl_debug_force_conv_tile(30)
         net = Network.from_desc([d], B, H, H, Cc)
         net.to_device(0)
-        lib.yl_debug_force_conv_tile(0)
         x = torch.rand((B, Cc, H, H), device="cuda:0", dtype=torch.float32) - 0.3
         flops = 2.0 * M * K * d.out_h * d.out_w * B
         best = None
         for t in tiles:
-            lib.yl_debug_force_conv_tile(t)
+            net.set_conv_tile(t)
             try:
                 net.profile(x.data_ptr(), 1)          # warm-up
                 ms, _ = net.profile(x.data_ptr(), args.iters)
@@ -72,7 +66,7 @@ def main():
                 print("# shape %d tile %d: %s" % (si, t, e), flush=True)
                 continue
             finally:
-                lib.yl_debug_force_conv_tile(0)
+                net.set_conv_tile(0)
             tf = flops / (ms[0] * 1e-3) / 1e12
             rec = {"shape": si, "M": M, "C": Cc, "size": size, "stride": stride, "H": H, "count": cnt,
                    "tile": t, "kernel": net.layer_kernel(0), "ms": float(ms[0]), "tflops": float(tf)}

@@ -40,7 +40,7 @@ class LayerDesc(C.Structure):
         ("n", C.c_int), ("size", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
         ("out_w", C.c_int), ("out_h", C.c_int), ("out_c", C.c_int),
         ("outputs", C.c_int), ("inputs", C.c_int),
-        ("batch_normalize", C.c_int), ("xnor", C.c_int), ("index", C.c_int),
+        ("batch_normalize", C.c_int), ("xnor", C.c_int), ("quantized", C.c_int), ("index", C.c_int),
         ("input_layers", c_int_p), ("input_sizes", c_int_p),
         ("classes", C.c_int), ("coords", C.c_int), ("total", C.c_int), ("softmax", C.c_int),
         ("mask", c_int_p), ("anchors", c_float_p), ("scale", C.c_float),
@@ -83,6 +83,7 @@ _SIGS = {
     "yl_network_set_stream": (C.c_int, [_vp, _vp]),
     "yl_network_synchronize": (C.c_int, [_vp]),
     "yl_network_layer_output": (C.c_int, [_vp, C.c_int, c_float_p]),
+    "yl_network_layer_output_image": (C.c_int, [_vp, C.c_int, C.c_int, c_float_p]),
     "yl_network_layer_output_dev": (_vp, [_vp, C.c_int]),
     "yl_network_input_dev": (_vp, [_vp]),
     "yl_network_set_debug": (C.c_int, [_vp, C.c_int]),
@@ -95,11 +96,11 @@ _SIGS = {
     "yl_network_get_boxes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_float,
                                        c_float_p, C.c_int, c_int_p]),
     "yl_network_pull_heads": (C.c_int, [_vp]),
-    "yl_debug_force_conv_tile": (C.c_int, [C.c_int]),
-    "yl_debug_last_conv_tile": (C.c_char_p, []),
-    "yl_debug_set_conv_variant": (C.c_int, [C.c_int]),
-    "yl_debug_set_winograd": (C.c_int, [C.c_int]),
-    "yl_debug_set_nms_mode": (C.c_int, [C.c_int]),
+    "yl_network_set_conv_tile": (C.c_int, [_vp, C.c_int]),
+    "yl_network_set_winograd": (C.c_int, [_vp, C.c_int]),
+    "yl_network_set_nms_mode": (C.c_int, [_vp, C.c_int]),
+    "yl_network_set_quant_rule": (C.c_int, [_vp, C.c_int]),
+    "yl_network_layer_head": (C.c_int, [_vp, C.c_int, c_int_p, c_float_p]),
     "yl_debug_wino_pack": (C.c_longlong, [c_float_p, C.c_int, C.c_int, C.c_int, c_float_p, C.c_longlong]),
     "yl_network_compact_detections": (C.c_int, [_vp, C.c_float, C.c_int, _vp, _vp]),
     "yl_network_detect_batch": (C.c_int, [_vp, c_int_p, c_int_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,

@@ -1,9 +1,29 @@
-// conv_f32_wino32.hip -- K1w, second tiling: Winograd F(2x2,3x3) with TWO workgroups per CU.
+// conv_f32_wino32.hip -- K1w: 3x3 / stride 1 / pad 1 FP32 convolution as Winograd F(2x2,3x3) on
+// v_mfma_f32_32x32x2_f32; input transform, 16 plane GEMMs and output transform fused in one kernel.
 //
-// Same mathematics, transforms and rounding points as conv_f32_wino.hip (read its header first).
-// That kernel gives every wave all 16 planes of a 32x32 block (256 accumulator registers): one
-// wave per SIMD and one workgroup per CU, so nothing overlaps a workgroup's prologue, its epilogue
-// or a memory stall (PMC: matrix pipe busy 47 % of the time).  Here a workgroup is 32 filters x 64
+// Same layer as conv_f32_mfma.hip computes (forward_convolutional_layer_cpu FP32 branch,
+// src/yolov2_forward_network.c:204-261): out = act(conv3x3(in, w) + bias).  The reference does
+// im2col + gemm_nn (9 multiplies per output, channel and filter); F(2x2,3x3) needs 16 multiplies
+// per 2x2 output tile = 4 per output -- 2.25x fewer MFMA flops, which matters because K1 already
+// runs at ~92 % of what the FP32 matrix pipe delivers at the clock it sustains.
+// 32 of yolov3's 75 convolutions (77 % of its FLOPs) have this shape.
+//
+//   U[xi]   = G g G^T              per (filter m, channel c): 4x4, packed by the host once
+//   V[xi]   = B^T d B              per (tile t, channel c): d = 4x4 input patch, zero outside
+//   M[xi]   = sum_c U[xi][m][c] * V[xi][c][t]        16 independent GEMMs, xi = 4*i + j
+//   Y       = A^T M A              2x2 outputs of tile t for filter m; + bias, leaky, [shortcut]
+//
+// FP32 error: the transforms only add/subtract and halve (G's halves are folded into U in double),
+// measured max |err| = 4e-6 of the layer RMS against 2.5e-6 for the direct kernel (bar 1e-4,
+// tests/common.py::fp32_close).  im2col AND the V / M tensors never exist in HBM: every thread
+// gathers the 4x4 patches of one channel of one tile (one 16-byte buffer load per patch row; halo
+// rows -> voffset -1 -> 0.0 from the range check, halo columns by lane selects), transforms them in
+// registers and writes them to the LDS stage.
+//
+// Tiling: a first version gave every wave all 16 planes of a 32x32 block (256 accumulator
+// registers): one wave per SIMD and one workgroup per CU, so nothing overlapped a workgroup's
+// prologue, its epilogue or a memory stall (PMC: matrix pipe busy 47 % of the time,
+// profiles/r1_rocprofv3_pmc_wino64_layer_512x256x38.txt).  Here a workgroup is 32 filters x 64
 // tiles, a wave owns HALF of the planes (8 x 16 = 128 AccVGPRs <= 256 registers in total), panels
 // are 4 channels and the LDS stage is 24 KB: two workgroups are resident per CU (2 waves per SIMD)
 // and run out of phase.  Price: the U slice is re-read per 32 instead of 64 filters.
@@ -33,7 +53,9 @@
 namespace yl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4v __attribute__((__vector_size__(16)));   // see conv_f32_wino.hip
+// the return type of __builtin_amdgcn_raw_buffer_load_b128.  NB: __builtin_bit_cast(float, q[i]) on a
+// vector element is miscompiled by this clang (every i reads element 0): use __uint_as_float
+typedef unsigned int u32x4v __attribute__((__vector_size__(16)));
 
 namespace {
 
@@ -376,6 +398,11 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
         }
         if (rnd == 0) __syncthreads();
     }
+}
+
+bool wino_applicable(int C, int M, int size, int stride, int pad)
+{
+    return size == 3 && stride == 1 && pad == 1 && C % 8 == 0 && C >= 16 && M >= 1;      // + H, W >= 4 (launcher)
 }
 
 size_t wino32_packed_floats(int C, int M)

@@ -431,18 +431,16 @@ size_t nms_lds_bytes(int cap, int classes)
     return n;
 }
 
-static int g_nms_mode = 1;      // 1 = (image, class)-parallel suppression, 0 = one workgroup per image
-void nms_set_mode(int m) { g_nms_mode = m; }
 
 int launch_nms(float *rec_scratch, const int *counts, int B, int cap, int classes, float nms, int netw, int neth,
                const ImgDims &dims, int relative, int letter, float *rec_out, int *counts_out, unsigned *meta,
-               void *stream)
+               int mode, void *stream)
 {
     if (cap > NMS_MAX_CAP) return (int)hipErrorInvalidValue;
     const int row_stride = 6 + classes;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = nms_lds_bytes(cap, classes);
-    if (g_nms_mode == 0 || !(nms > 0) || !meta) {
+    if (mode == 0 || !(nms > 0) || !meta) {   // mode 1 = (image, class)-parallel suppression
         hipLaunchKernelGGL(nms_kernel<0>, dim3(B), dim3(NMS_THREADS), lds, s, rec_scratch, counts, cap, classes,
                            row_stride, nms, netw, neth, dims, relative, letter, rec_out, counts_out, meta);
         return (int)hipGetLastError();

@@ -136,6 +136,9 @@ int parse_cfg_file(const char *path, int batch, int quantized, Network &net) {
     if (const std::string *ic = ns.find("input_calibration")) net.input_calibration = parse_float_list(*ic);
 
     int ph = net.h, pw = net.w, pc = net.c, pinputs = net.h * net.w * net.c;
+    // the parser's running `params.quantized` (src/additionally.c:3996-4004): switched off for good by
+    // the first convolution that has a [yolo] section two sections further on
+    int params_quantized = quantized;
     net.layers.clear();
     for (size_t si = 1; si < secs.size(); ++si) {
         const Section &s = secs[si];
@@ -150,6 +153,7 @@ int parse_cfg_file(const char *path, int batch, int quantized, Network &net) {
             l.n = s.geti("filters", 1);
             l.size = s.geti("size", 1);
             l.stride = s.geti("stride", 1);
+            if (l.size <= 0 || l.stride <= 0 || l.n <= 0) { set_error(std::string(where) + "filters, size and stride must be positive"); return YL_ERR_CFG; }
             int pad = s.geti("pad", 0);
             int padding = s.geti("padding", 0);
             if (pad) padding = l.size / 2;
@@ -161,6 +165,11 @@ int parse_cfg_file(const char *path, int batch, int quantized, Network &net) {
             if (!(l.h && l.w && l.c)) { set_error(std::string(where) + "Layer before convolutional layer must output image."); return YL_ERR_CFG; }
             l.batch_normalize = s.geti("batch_normalize", 0);
             l.xnor = s.geti("xnor", 0);
+            // l.quantized of the reference's parser = the layer set its GPU path quantises
+            // (parse_network_cfg src/additionally.c:3996-4004, parse_convolutional :3557-3559)
+            if (si + 2 < secs.size() && secs[si + 2].type == "[yolo]") params_quantized = 0;
+            l.gpu_quantized = params_quantized;
+            if (idx == 0 || l.activation == YL_LINEAR || (idx > 1 && l.stride > 1) || l.size == 1) l.gpu_quantized = 0;
             if (s.geti("binary", 0)) { set_error(std::string(where) + "binary=1 is not on the hot path"); return YL_ERR_UNSUPPORTED; }
             l.out_h = (l.h + 2 * l.pad - l.size) / l.stride + 1;
             l.out_w = (l.w + 2 * l.pad - l.size) / l.stride + 1;
@@ -179,6 +188,7 @@ int parse_cfg_file(const char *path, int batch, int quantized, Network &net) {
             l.type = YL_MAXPOOL;
             l.stride = s.geti("stride", 1);
             l.size = s.geti("size", l.stride);
+            if (l.size <= 0 || l.stride <= 0) { set_error(std::string(where) + "size and stride must be positive"); return YL_ERR_CFG; }
             l.pad = s.geti("padding", l.size - 1);
             l.h = ph; l.w = pw; l.c = pc;
             if (!(l.h && l.w && l.c)) { set_error(std::string(where) + "Layer before maxpool layer must output image."); return YL_ERR_CFG; }
@@ -231,6 +241,7 @@ int parse_cfg_file(const char *path, int batch, int quantized, Network &net) {
             l.type = YL_UPSAMPLE;
             l.stride = s.geti("stride", 2);
             if (l.stride < 0) { set_error(std::string(where) + "reverse upsample is not on the hot path"); return YL_ERR_UNSUPPORTED; }
+            if (l.stride == 0) { set_error(std::string(where) + "stride must be positive"); return YL_ERR_CFG; }
             l.w = pw; l.h = ph; l.c = pc;
             l.out_w = pw * l.stride; l.out_h = ph * l.stride; l.out_c = pc;
             l.outputs = l.out_w * l.out_h * l.out_c;
@@ -239,6 +250,7 @@ int parse_cfg_file(const char *path, int batch, int quantized, Network &net) {
         } else if (s.type == "[reorg]") {
             l.type = YL_REORG;
             l.stride = s.geti("stride", 1);
+            if (l.stride <= 0) { set_error(std::string(where) + "stride must be positive"); return YL_ERR_CFG; }
             if (s.geti("reverse", 0)) { set_error(std::string(where) + "reverse reorg is not on the hot path"); return YL_ERR_UNSUPPORTED; }
             l.w = pw; l.h = ph; l.c = pc;
             l.out_w = pw / l.stride; l.out_h = ph / l.stride; l.out_c = pc * l.stride * l.stride;
@@ -272,7 +284,9 @@ int parse_cfg_file(const char *path, int batch, int quantized, Network &net) {
             l.n = s.geti("num", 1);
             l.total = l.n;
             l.softmax = s.geti("softmax", 0);
-            if (s.find("tree") || s.find("map")) { set_error(std::string(where) + "softmax tree / map (YOLO9000) is not on the hot path"); return YL_ERR_UNSUPPORTED; }
+            // classfix == -1 zeroes scale < .5 in get_region_boxes_cpu (src/additionally.c:3591); no decode here honours it
+            if (s.geti("classfix", 0) != 0) { set_error(std::string(where) + "classfix != 0 is not on the hot path"); return YL_ERR_UNSUPPORTED; }
+            if (s.find("tree") != nullptr || s.find("map") != nullptr) { set_error(std::string(where) + "softmax tree / map (YOLO9000) is not on the hot path"); return YL_ERR_UNSUPPORTED; }
             if (l.coords != 4) { set_error(std::string(where) + "coords != 4 unsupported"); return YL_ERR_UNSUPPORTED; }
             l.w = pw; l.h = ph; l.c = pc;
             l.outputs = l.h * l.w * l.n * (l.classes + l.coords + 1);

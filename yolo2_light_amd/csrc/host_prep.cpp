@@ -143,8 +143,12 @@ void select_conv_modes(Network &net) {
     for (size_t i = 0; i < net.layers.size(); ++i) {
         Layer &l = net.layers[i];
         if (l.type != YL_CONVOLUTIONAL) continue;
-        // yolov2_forward_network_q: `i >= 1 && l.activation != LINEAR` (quantized.c:1036)
-        if (net.quantized && i >= 1 && l.activation != YL_LINEAR) l.conv_mode = CONV_INT8;
+        // CPU rule, yolov2_forward_network_q: `i >= 1 && l.activation != LINEAR` (quantized.c:1036);
+        // GPU rule, forward_network_gpu_cudnn_quantized: the parser's `l.quantized`
+        // (src/additionally.c:3557-3559, 3996-4004) -- yl_network_set_quant_rule
+        const bool q = net.quant_rule == YL_QUANT_RULE_GPU ? (l.gpu_quantized != 0)
+                                                           : (i >= 1 && l.activation != YL_LINEAR);
+        if (net.quantized && q) l.conv_mode = CONV_INT8;
         // forward_convolutional_layer_cpu: `l.xnor && l.align_bit_weights && stride==1 && pad==1`
         // (yolov2_forward_network.c:116)
         else if (l.xnor && l.stride == 1 && l.pad == 1 && l.size == 3) l.conv_mode = CONV_XNOR;

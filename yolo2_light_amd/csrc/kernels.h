@@ -19,27 +19,19 @@ struct ConvF32Args {
     int size, stride, pad;
     int act;              // YL_LINEAR / YL_LEAKY
     int tapmajor;         // K order of `wt`: 0 = (c,ky,kx) like im2col_cpu, 1 = (ky,kx,c) (needs C % 16 == 0)
-    const float *wino_u;  // Winograd-packed weights (wino_pack_weights) or nullptr: 3x3/1/1 layers only
-    const float *wino32_u; // the same for the 32-filter tiling (wino32_pack_weights) or nullptr
+    const float *wino32_u; // Winograd-packed weights (wino32_pack_weights) or nullptr: 3x3/1/1 layers only
 };
-int launch_conv_f32(const ConvF32Args &a, void *stream);
-// force a tile config (0 = heuristic): used by the tile sweep in bench/tests
-void conv_f32_force_tile(int cfg);
-int conv_f32_forced_tile();
-void conv_f32_set_variant(int v);
-int conv_f32_get_variant();
-int launch_conv_f32_v2(const ConvF32Args &a, int cfg, void *stream, char *name, size_t name_len);
-const char *conv_f32_last_tile_name();
-// K1w (conv_f32_wino.hip): Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 layers.
-// mode: 0 = never, 1 = wherever the packed weights exist (default); forced tile 30 = always, any
-// other forced tile = never (tile sweeps of the direct kernel)
-void conv_f32_set_winograd(int mode);
-int conv_f32_get_winograd();
+// per-network kernel-selection knobs (snapshotted in Network: two networks driven from two host
+// threads, one per GPU, share no mutable launch state)
+struct ConvF32Opts {
+    int force_tile = 0;   // 0 = heuristic, 11..22 = direct tile 1..12, 31 = Winograd (tuning / tests)
+    int winograd = 1;     // Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 layers with C >= 64
+};
+// writes the name of the kernel instance it launched into name[name_len]
+int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, char *name, size_t name_len);
+// K1w (conv_f32_wino32.hip): Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 layers,
+// 32 filters x 64 tiles per workgroup, two workgroups per CU
 bool wino_applicable(int C, int M, int size, int stride, int pad);
-size_t wino_packed_floats(int C, int M);
-void wino_pack_weights(const float *w, int C, int M, float *dst);
-int launch_conv_f32_wino(const ConvF32Args &a, const float *u_packed, void *stream, char *name, size_t name_len);
-// second tiling (conv_f32_wino32.hip): 32 filters x 64 tiles, two workgroups per CU; forced tile 31
 size_t wino32_packed_floats(int C, int M);
 void wino32_pack_weights(const float *w, int C, int M, float *dst);
 int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, void *stream, char *name, size_t name_len);
@@ -117,11 +109,10 @@ struct ImgDims {
     uint32_t wh[NMS_MAX_DIMS];
 };
 // meta = unsigned[B][1 + (classes+31)/32] scratch (per image: `total`, class bitmap) for the
-// (image, class)-parallel path; nullptr or nms_set_mode(0) = one workgroup per image
+// (image, class)-parallel path (mode 1); nullptr or mode 0 = one workgroup per image
 int launch_nms(float *rec_scratch, const int *counts, int B, int cap, int classes, float nms, int netw, int neth,
                const ImgDims &dims, int relative, int letter, float *rec_out, int *counts_out, unsigned *meta,
-               void *stream);
-void nms_set_mode(int m);
+               int mode, void *stream);
 
 // K13 (layers.hip): per-image histogram of lround(|x| / bin_width), saturated; hist = unsigned[batch][max_bin]
 int launch_hist_abs(const float *x, size_t per_image, int batch, int max_bin, float bin_width, unsigned *hist, void *stream);

@@ -54,9 +54,8 @@ static void free_device(Network &net)
         if (l.host_registered && l.host_output) (void)hipHostUnregister(l.host_output);
         l.host_registered = false;
         if (l.d_weights_t) (void)hipFree(l.d_weights_t);
-        if (l.d_wino_u) (void)hipFree(l.d_wino_u);
         if (l.d_wino32_u) (void)hipFree(l.d_wino32_u);
-        l.d_wino_u = nullptr; l.d_wino32_u = nullptr;
+        l.d_wino32_u = nullptr;
         if (l.d_biases) (void)hipFree(l.d_biases);
         if (l.d_weights_i8) (void)hipFree(l.d_weights_i8);
         if (l.d_weights_bits) (void)hipFree(l.d_weights_bits);
@@ -76,6 +75,8 @@ static void free_device(Network &net)
     for (void *e : net.u8_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
     net.u8_events.clear();
     net.h_u8 = nullptr; net.d_u8 = nullptr; net.u8_stride = 0;
+    if (net.h_det_rows) (void)hipHostFree(net.h_det_rows);
+    net.h_det_rows = nullptr; net.h_det_bytes = 0; net.det_cache_valid = false;
     if (net.d_det_scratch) (void)hipFree(net.d_det_scratch);
     if (net.d_det_out) (void)hipFree(net.d_det_out);
     if (net.d_det_counts) (void)hipFree(net.d_det_counts);
@@ -117,7 +118,7 @@ static int upload_conv(Network &net, Layer &l)
         // tap-major (ky,kx,c) so that one BK panel shares a single tap (scalar decode once per panel)
         l.Kpad = round_up(K, 32);
         l.Mpad = round_up(M, 256);
-        l.tapmajor = (conv_f32_get_variant() >= 1 && l.size > 1 && l.size <= 5 && (l.c % 16) == 0) ? 1 : 0;
+        l.tapmajor = (l.size > 1 && l.size <= 5 && (l.c % 16) == 0) ? 1 : 0;
         const int taps = l.size * l.size;
         std::vector<float> wt((size_t)l.Kpad * l.Mpad, 0.f);
         for (int m = 0; m < M; ++m)
@@ -135,16 +136,8 @@ static int upload_conv(Network &net, Layer &l)
         // 3x3 / stride 1 / pad 1: also the Winograd F(2x2,3x3) form of the same weights (K1w).
         // Not for the xnor fallback: its +-mean weights would pick up G's halves and the layer is
         // specified by the reference as an exact +-1 GEMM.
-        if (conv_f32_get_winograd() && !xnor_fallback && wino_applicable(l.c, M, l.size, l.stride, l.pad) &&
+        if (net.conv_opts.winograd && !xnor_fallback && wino_applicable(l.c, M, l.size, l.stride, l.pad) &&
             l.out_h == l.h && l.out_w == l.w && l.h >= 4 && l.w >= 4) {
-            // the first (64-filter) tiling is an A/B and test variant: packed only for networks
-            // uploaded while it is forced (yl_debug_force_conv_tile(30))
-            if (conv_f32_forced_tile() == 30) {
-                std::vector<float> u(wino_packed_floats(l.c, M));
-                wino_pack_weights(l.weights.data(), l.c, M, u.data());
-                YL_HIP(hipMalloc((void **)&l.d_wino_u, u.size() * sizeof(float)));
-                YL_HIP(hipMemcpy(l.d_wino_u, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice));
-            }
             std::vector<float> u32(wino32_packed_floats(l.c, M));
             wino32_pack_weights(l.weights.data(), l.c, M, u32.data());
             YL_HIP(hipMalloc((void **)&l.d_wino32_u, u32.size() * sizeof(float)));
@@ -347,10 +340,8 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.K = l.size * l.size * l.c; a.Kpad = l.Kpad; a.Mpad = l.Mpad;
             a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
             a.tapmajor = l.tapmajor;
-            a.wino_u = l.d_wino_u;
             a.wino32_u = l.d_wino32_u;
-            YL_LAUNCH(launch_conv_f32(a, s), "conv_f32");
-            l.kernel_name = conv_f32_last_tile_name();
+            YL_LAUNCH(launch_conv_f32(a, net.conv_opts, s, l.kernel_name, sizeof(l.kernel_name)), "conv_f32");
         } else if (l.conv_mode == CONV_INT8) {
             int8_t *q_in = net.d_qbuf + (i % 3) * net.qbuf_bytes;
             if (!l.q_from_producer)
@@ -378,7 +369,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
             // float ALPHA1 = R_MULT / (l.input_quant_multipler * l.weights_quant_multipler);  (quantized.c:596)
             a.alpha1 = 32 / (l.input_quant_multipler * l.weights_quant_multipler);
             YL_LAUNCH(launch_conv_i8(a, s), "conv_i8");
-            l.kernel_name = "conv_i8_mfma";
+            snprintf(l.kernel_name, sizeof(l.kernel_name), "conv_i8_mfma");
         } else {
             YL_LAUNCH(launch_pack_sign_bits(input, net.d_bitbuf, B, l.c, l.h, l.w, l.Cw, s), "pack_sign_bits");
             ConvXnorArgs a;
@@ -386,7 +377,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.out = l.d_output; a.dbg = l.d_debug;
             a.B = B; a.C = l.c; a.Cw = l.Cw; a.H = l.h; a.W = l.w; a.M = l.n; a.Mpad = l.Mpad; a.act = l.activation;
             YL_LAUNCH(launch_conv_xnor(a, s), "conv_xnor");
-            l.kernel_name = "conv_xnor";
+            snprintf(l.kernel_name, sizeof(l.kernel_name), "conv_xnor");
         }
         break;
     }
@@ -435,6 +426,7 @@ static int forward(Network &net, const float *input_dev, int slot)
     YL_HIP(hipSetDevice(net.device));
     const float *input = input_dev;
     const size_t nl = net.layers.size();
+    ++net.forward_seq;
     void **ev = slot >= 0 ? &net.layer_events[(size_t)slot * (nl + 1)] : nullptr;
     for (size_t i = 0; i < nl; ++i) {
         if (ev) YL_HIP(hipEventRecord((hipEvent_t)ev[i], (hipStream_t)net.stream));
@@ -444,6 +436,13 @@ static int forward(Network &net, const float *input_dev, int slot)
     }
     if (ev) YL_HIP(hipEventRecord((hipEvent_t)ev[nl], (hipStream_t)net.stream));
     return YL_OK;
+}
+
+// false for tensors the fusion plan never writes (a conv folded into its [shortcut], an INT8 conv
+// whose only reader takes the int8 side output)
+static bool layer_materialised(const Layer &l)
+{
+    return !(l.type == YL_CONVOLUTIONAL && (l.fused_shortcut >= 0 || l.skip_f32_out));
 }
 
 static int pull_heads(Network &net, bool also_last)
@@ -514,6 +513,7 @@ int yl_network_create_from_desc(const yl_layer_desc *layers, int n_layers, int b
         l.out_w = d.out_w; l.out_h = d.out_h; l.out_c = d.out_c;
         l.outputs = d.outputs; l.inputs = d.inputs;
         l.batch_normalize = d.batch_normalize; l.xnor = d.xnor; l.index = d.index;
+        l.gpu_quantized = d.quantized;
         l.classes = d.classes; l.coords = d.coords ? d.coords : 4; l.total = d.total; l.softmax = d.softmax;
         l.scale = d.scale;
         l.host_output = d.output;
@@ -772,13 +772,37 @@ int yl_network_layer_output(yl_network *net, int i, float *dst_host)
 {
     YL_LAYER_OR(YL_ERR_ARG)
     if (!dst_host || !net->net.on_device) { set_error("bad argument / not on device"); return YL_ERR_STATE; }
+    if (!layer_materialised(l)) {
+        set_error("this layer's FP32 tensor is not materialised under yl_network_set_fusion (folded into its consumer)");
+        return YL_ERR_STATE;
+    }
     YL_HIP(hipSetDevice(net->net.device));
     YL_HIP(hipStreamSynchronize((hipStream_t)net->net.stream));
     YL_HIP(hipMemcpy(dst_host, l.d_output, sizeof(float) * (size_t)net->net.batch * l.outputs, hipMemcpyDeviceToHost));
     return YL_OK;
 }
 
-const float *yl_network_layer_output_dev(const yl_network *net, int i) { YL_LAYER_OR(nullptr) return l.d_output; }
+int yl_network_layer_output_image(yl_network *net, int i, int image, float *dst_host)
+{
+    YL_LAYER_OR(YL_ERR_ARG)
+    if (!dst_host || !net->net.on_device) { set_error("bad argument / not on device"); return YL_ERR_STATE; }
+    if (image < 0 || image >= net->net.batch) { set_error("image index out of range"); return YL_ERR_ARG; }
+    if (!layer_materialised(l)) {
+        set_error("this layer's FP32 tensor is not materialised under yl_network_set_fusion (folded into its consumer)");
+        return YL_ERR_STATE;
+    }
+    YL_HIP(hipSetDevice(net->net.device));
+    YL_HIP(hipStreamSynchronize((hipStream_t)net->net.stream));
+    YL_HIP(hipMemcpy(dst_host, l.d_output + (size_t)image * l.outputs, sizeof(float) * (size_t)l.outputs, hipMemcpyDeviceToHost));
+    return YL_OK;
+}
+
+const float *yl_network_layer_output_dev(const yl_network *net, int i)
+{
+    YL_LAYER_OR(nullptr)
+    if (!layer_materialised(l)) { set_error("layer output not materialised under fusion"); return nullptr; }
+    return l.d_output;
+}
 
 float *yl_network_input_dev(yl_network *net) { return net ? net->net.d_input : nullptr; }
 
@@ -841,7 +865,7 @@ int yl_network_layer_times(yl_network *net, int slot, float *ms_per_layer, float
 const char *yl_network_layer_kernel(const yl_network *net, int i)
 {
     YL_LAYER_OR(nullptr)
-    return l.kernel_name.c_str();
+    return l.kernel_name;
 }
 
 int yl_network_profile(yl_network *net, const float *input_dev, int iters, float *ms_per_layer, float *total_ms)
@@ -872,25 +896,94 @@ int yl_network_get_boxes(yl_network *net, int image, int w, int h, float thresh,
                          float nms, float *rows, int max_rows, int *classes_out)
 {
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }
-    return get_boxes_host(net->net, image, w, h, thresh, relative, letter, nms, rows, max_rows, classes_out);
+    Network &n = net->net;
+    if (!n.on_device) { set_error("network not on device"); return YL_ERR_STATE; }
+    if (image < 0 || image >= n.batch) { set_error("image index out of range"); return YL_ERR_ARG; }
+    if (w <= 0 || h <= 0) { set_error("image size must be positive"); return YL_ERR_ARG; }
+    const int classes = n.layers.back().classes;
+    if (classes_out) *classes_out = classes;
+    const int cap = NMS_MAX_CAP;
+    const size_t row = (size_t)(6 + classes);
+    // the decode + NMS of the whole batch is one pass on the device: keep it while the caller walks
+    // the images of one forward with the same arguments
+    DetKey key{n.forward_seq, w, h, thresh, relative, letter, nms};
+    if (!n.det_cache_valid || memcmp(&key, &n.det_cache_key, sizeof(key)) != 0) {
+        YL_HIP(hipSetDevice(n.device));
+        const size_t need = sizeof(float) * (size_t)n.batch * cap * row + sizeof(int) * (size_t)n.batch;
+        if (n.h_det_bytes < need) {
+            if (n.h_det_rows) (void)hipHostFree(n.h_det_rows);
+            n.h_det_rows = nullptr; n.h_det_bytes = 0;
+            YL_HIP(hipHostMalloc((void **)&n.h_det_rows, need, hipHostMallocDefault));
+            n.h_det_bytes = need;
+        }
+        std::vector<int> ws((size_t)n.batch, w), hs((size_t)n.batch, h);
+        int *counts = reinterpret_cast<int *>(n.h_det_rows + (size_t)n.batch * cap * row);
+        n.det_cache_valid = false;
+        const int rc = yl_network_get_boxes_batch(net, ws.data(), hs.data(), thresh, relative, letter, nms, cap,
+                                                  n.h_det_rows, counts);
+        if (rc != YL_OK) return rc;
+        n.det_cache_key = key;
+        n.det_cache_valid = true;
+    }
+    const int *counts = reinterpret_cast<const int *>(n.h_det_rows + (size_t)n.batch * cap * row);
+    const int count = counts[image];
+    int nrows = count < cap ? count : cap;
+    if (nrows > max_rows) nrows = max_rows;
+    if (rows && nrows > 0) memcpy(rows, n.h_det_rows + (size_t)image * cap * row, sizeof(float) * row * nrows);
+    return count;
 }
 
-int yl_debug_force_conv_tile(int cfg) { conv_f32_force_tile(cfg); return YL_OK; }
-int yl_debug_set_conv_variant(int v) { conv_f32_set_variant(v); return YL_OK; }
-int yl_debug_set_winograd(int mode) { conv_f32_set_winograd(mode); return YL_OK; }
-int yl_debug_set_nms_mode(int mode) { nms_set_mode(mode); return YL_OK; }
+int yl_network_set_conv_tile(yl_network *net, int cfg)
+{
+    if (!net) { set_error("null argument"); return YL_ERR_ARG; }
+    if (!(cfg == 0 || (cfg >= 11 && cfg <= 22) || cfg == 31)) { set_error("unknown tile id"); return YL_ERR_ARG; }
+    net->net.conv_opts.force_tile = cfg;
+    return YL_OK;
+}
+
+int yl_network_set_winograd(yl_network *net, int on)
+{
+    if (!net) { set_error("null argument"); return YL_ERR_ARG; }
+    if (net->net.on_device) { set_error("set_winograd must precede to_device"); return YL_ERR_STATE; }
+    net->net.conv_opts.winograd = on != 0;
+    return YL_OK;
+}
+
+int yl_network_set_nms_mode(yl_network *net, int mode)
+{
+    if (!net) { set_error("null argument"); return YL_ERR_ARG; }
+    net->net.nms_mode = mode != 0;
+    net->net.det_cache_valid = false;
+    return YL_OK;
+}
+
+int yl_network_set_quant_rule(yl_network *net, int rule)
+{
+    if (!net || (rule != YL_QUANT_RULE_CPU && rule != YL_QUANT_RULE_GPU)) { set_error("bad argument"); return YL_ERR_ARG; }
+    if (net->net.on_device) { set_error("set_quant_rule must precede to_device"); return YL_ERR_STATE; }
+    net->net.quant_rule = rule;
+    select_conv_modes(net->net);
+    return YL_OK;
+}
+
+int yl_network_layer_head(const yl_network *net, int i, int *mask, float *anchors)
+{
+    YL_LAYER_OR(YL_ERR_ARG)
+    if (l.type != YL_YOLO && l.type != YL_REGION) { set_error("not a detection head"); return YL_ERR_ARG; }
+    for (int k = 0; k < l.n && mask; ++k) mask[k] = (l.type == YL_YOLO) ? l.mask[k] : k;
+    for (size_t k = 0; k < l.anchors.size() && anchors; ++k) anchors[k] = l.anchors[k];
+    return l.n;
+}
 
 long long yl_debug_wino_pack(const float *weights, int c, int m, int tiling, float *dst, long long dst_floats)
 {
-    if (!weights || c <= 0 || m <= 0 || c % 8 != 0 || (tiling != 32 && tiling != 64)) { set_error("bad argument"); return YL_ERR_ARG; }
-    const size_t need = tiling == 32 ? wino32_packed_floats(c, m) : wino_packed_floats(c, m);
+    if (!weights || c <= 0 || m <= 0 || c % 8 != 0 || tiling != 32) { set_error("bad argument"); return YL_ERR_ARG; }
+    const size_t need = wino32_packed_floats(c, m);
     if (!dst) return (long long)need;
     if (dst_floats < (long long)need) { set_error("dst too small"); return YL_ERR_ARG; }
-    if (tiling == 32) wino32_pack_weights(weights, c, m, dst);
-    else wino_pack_weights(weights, c, m, dst);
+    wino32_pack_weights(weights, c, m, dst);
     return (long long)need;
 }
-const char *yl_debug_last_conv_tile(void) { return conv_f32_last_tile_name(); }
 
 // ------------------------------------------------------------------ INT8 calibration tool
 float yl_entropy_from_histogram(const uint32_t *counts, int max_bin, float bin_width)
@@ -1136,7 +1229,7 @@ int yl_network_detect_batch(yl_network *net, const int *img_w, const int *img_h,
     YL_LAUNCH(launch_compact(heads, nh, B, n.w, n.h, thresh, cap, 6 + classes, n.d_det_scratch, n.d_det_counts, n.stream),
               "compact");
     YL_LAUNCH(launch_nms(n.d_det_scratch, n.d_det_counts, B, cap, classes, nms, n.w, n.h, dims, relative, letter,
-                         records_dev, counts_dev, n.d_det_meta, n.stream), "nms");
+                         records_dev, counts_dev, n.d_det_meta, n.nms_mode, n.stream), "nms");
     return YL_OK;
 }
 

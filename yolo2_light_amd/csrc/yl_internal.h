@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/yolo2_hip.h"
+#include "kernels.h"
 
 namespace yl {
 
@@ -22,6 +23,7 @@ struct Layer {
     int out_w = 0, out_h = 0, out_c = 0;
     int outputs = 0, inputs = 0;
     int batch_normalize = 0, xnor = 0;
+    int gpu_quantized = 0;               // the reference parser's `l.quantized` (GPU-path quantisation rule)
     int index = 0;                       // shortcut `from`
     std::vector<int> input_layers, input_sizes;   // route
     int classes = 0, coords = 4, total = 0, softmax = 0;
@@ -48,16 +50,15 @@ struct Layer {
     float *d_weights_t = nullptr;        // FP32: k-major packed [Kpad][Mpad]
     float *d_biases = nullptr;
     int   Kpad = 0, Mpad = 0;
-    int   tapmajor = 0;                  // K order of d_weights_t (see conv_f32_mfma_v2.hip)
-    float *d_wino_u = nullptr;           // FP32 3x3/1/1: Winograd-packed U (conv_f32_wino.hip), else nullptr
-    float *d_wino32_u = nullptr;         // the same for conv_f32_wino32.hip
+    int   tapmajor = 0;                  // K order of d_weights_t (see conv_f32_mfma.hip)
+    float *d_wino32_u = nullptr;         // FP32 3x3/1/1: Winograd-packed U (conv_f32_wino32.hip), else nullptr
     int8_t *d_weights_i8 = nullptr;      // INT8: [Mpad][taps][Cpad] (channel-fastest)
     int   Cpad = 0;
     uint64_t *d_weights_bits = nullptr;  // XNOR: [Mpad][taps][Cw] 64-bit words
     float *d_mean = nullptr;
     int   Cw = 0;
     int32_t *d_debug = nullptr;          // xnor counts / int8 acc (debug mode)
-    std::string kernel_name;             // dominant kernel of this layer's last launch
+    char kernel_name[64] = "";           // kernel instance of this layer's last launch
     int   fused_shortcut = -1;           // conv: index of the [shortcut] layer folded into its epilogue
     bool  fused_into_conv = false;       // shortcut: produced by the preceding conv's epilogue
     bool  q_from_producer = false;       // INT8 conv: its quantised input is written by the producing conv
@@ -66,9 +67,19 @@ struct Layer {
     bool  skip_f32_out = false;          // FP32 tensor of this layer has no reader and is not written
 };
 
+// arguments of the cached yl_network_get_boxes pass
+struct DetKey {
+    unsigned long long seq;
+    int w, h;
+    float thresh;
+    int relative, letter;
+    float nms;
+};
+
 struct Network {
     int batch = 1, w = 0, h = 0, c = 0;
     int quantized = 0;
+    int quant_rule = YL_QUANT_RULE_CPU;  // which convolutions `quantized` applies to (yl_network_set_quant_rule)
     std::vector<float> input_calibration;
     std::vector<Layer> layers;
     bool weights_loaded = false;
@@ -78,6 +89,9 @@ struct Network {
     bool on_device = false;
     bool debug = false;
     bool fuse = false;                   // conv+shortcut epilogue fusion (yl_network_set_fusion)
+    ConvF32Opts conv_opts;               // K1 kernel-selection knobs of THIS network (no process-global launch state)
+    int nms_mode = 1;                    // 1 = one workgroup per (image, class), 0 = one per image
+    unsigned long long forward_seq = 0;  // bumped by every forward: detection cache key
     void *stream = nullptr;              // hipStream_t
     bool own_stream = false;
     float *d_input = nullptr;
@@ -94,6 +108,10 @@ struct Network {
     float *d_det_out = nullptr;          // batched detections: device staging of yl_network_get_boxes_batch
     size_t det_out_bytes = 0;
     int *d_det_counts = nullptr;         // [2][batch]: raw compaction counts, staged output counts
+    float *h_det_rows = nullptr;         // pinned: rows [batch][cap][6+classes] + counts [batch] of yl_network_get_boxes
+    size_t h_det_bytes = 0;
+    DetKey det_cache_key{};
+    bool det_cache_valid = false;
     unsigned *d_det_meta = nullptr;      // [batch][1 + class words]: NMS `total` + class bitmap
     size_t det_meta_bytes = 0;
     uint8_t *h_u8 = nullptr;             // pinned staging of u8 source images, one region per batch slot
@@ -116,10 +134,6 @@ void quantize_network(Network &net);
 void select_conv_modes(Network &net);
 // host_calib.cpp
 float entropy_from_counts(const uint32_t *counts, int max_bin, float bin_width);
-// host_detect.cpp
-int get_boxes_host(Network &net, int image, int w, int h, float thresh, int relative,
-                   int letter, float nms, float *rows, int max_rows, int *classes_out);
-
 }  // namespace yl
 
 struct yl_network {

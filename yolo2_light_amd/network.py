@@ -62,9 +62,14 @@ class Network:
 
     @classmethod
     def load(cls, cfg_path: str, weights_path: str, batch: int = 1, quantized: int = 0,
-             device: Optional[int] = None, debug: bool = False, fuse: bool = False) -> "Network":
+             device: Optional[int] = None, debug: bool = False, fuse: bool = False,
+             quant_rule: int = 0, winograd: bool = True) -> "Network":
         """The full prep sequence of test_detector_cpu (src/main.c:160-171)."""
         net = cls.from_cfg(cfg_path, batch, quantized)
+        if quant_rule:
+            net.set_quant_rule(quant_rule)
+        if not winograd:
+            check(lib.yl_network_set_winograd(net._h, 0), "yl_network_set_winograd")
         net.load_weights(weights_path)
         net.fuse_conv_batchnorm()
         net.calculate_binary_weights()
@@ -152,7 +157,27 @@ class Network:
     def flops_per_image(self) -> float:
         return lib.yl_network_flops_per_image(self._h)
 
+    def layer_head(self, i: int):
+        """(mask, anchors) of YOLO/REGION layer i"""
+        li = self.layer_info(i)
+        mask = (C.c_int * max(li["n"], 1))()
+        anchors = (C.c_float * (2 * max(li["total"], li["n"], 1)))()
+        n = lib.yl_network_layer_head(self._h, i, mask, anchors)
+        if n < 0:
+            raise YoloHipError("yl_network_layer_head failed: " + _lib.last_error())
+        return np.array(mask[:n], dtype=np.int32), np.array(anchors[:], dtype=np.float32)
+
     # ------------------------------------------------------------ device
+    def set_quant_rule(self, rule: int) -> None:
+        """0 = the reference CPU path's INT8 layer set, 1 = its GPU path's (`l.quantized`); before to_device"""
+        check(lib.yl_network_set_quant_rule(self._h, rule), "yl_network_set_quant_rule")
+
+    def set_conv_tile(self, cfg: int) -> None:
+        check(lib.yl_network_set_conv_tile(self._h, cfg), "yl_network_set_conv_tile")
+
+    def set_nms_mode(self, mode: int) -> None:
+        check(lib.yl_network_set_nms_mode(self._h, mode), "yl_network_set_nms_mode")
+
     def set_fusion(self, on: bool = True) -> None:
         """Fold same-shape linear [shortcut] layers into the preceding conv's epilogue (before to_device)."""
         check(lib.yl_network_set_fusion(self._h, 1 if on else 0), "yl_network_set_fusion")
@@ -194,6 +219,16 @@ class Network:
         out = np.empty(self.batch * li["outputs"], dtype=np.float32)
         check(lib.yl_network_layer_output(self._h, i, _fp(out)), "yl_network_layer_output")
         return out
+
+    def layer_output_image(self, i: int, image: int) -> np.ndarray:
+        li = self.layer_info(i)
+        out = np.empty(li["outputs"], dtype=np.float32)
+        check(lib.yl_network_layer_output_image(self._h, i, image, _fp(out)), "yl_network_layer_output_image")
+        return out
+
+    def layer_materialised(self, i: int) -> bool:
+        """False for FP32 tensors the fusion plan never writes (folded conv, int8-only consumer)"""
+        return bool(lib.yl_network_layer_output_dev(self._h, i))
 
     def layer_xnor_counts(self, i: int) -> np.ndarray:
         li = self.layer_info(i)
@@ -271,16 +306,13 @@ class Network:
 
     def get_boxes(self, image: int, w: int, h: int, thresh: float, nms: float = 0.0,
                   relative: int = 1, letter: int = 0, max_rows: int = 4096) -> np.ndarray:
-        classes = C.c_int(0)
-        # first call sizes the result
-        n = lib.yl_network_get_boxes(self._h, image, w, h, thresh, relative, letter, nms, None, 0, C.byref(classes))
+        classes = self.layer_info(self.n - 1)["classes"]
+        max_rows = min(max_rows, 2048)          # YL_DETECT_MAX_CAP
+        rows = np.zeros((max_rows, 6 + classes), dtype=np.float32)
+        n = lib.yl_network_get_boxes(self._h, image, w, h, thresh, relative, letter, nms, _fp(rows), max_rows, None)
         if n < 0:
             raise YoloHipError("yl_network_get_boxes failed: " + _lib.last_error())
-        rows = np.zeros((max(n, 1), 6 + classes.value), dtype=np.float32)
-        n2 = lib.yl_network_get_boxes(self._h, image, w, h, thresh, relative, letter, nms, _fp(rows), n, C.byref(classes))
-        if n2 < 0:
-            raise YoloHipError("yl_network_get_boxes failed: " + _lib.last_error())
-        return rows[:n]
+        return rows[:min(n, max_rows)].copy()
 
     @staticmethod
     def _dims(sizes, batch):
