@@ -61,6 +61,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--layers", action="store_true", help="also print a per-layer table to stderr")
     ap.add_argument("--tile", type=int, default=0, help="force K1 tile config (tuning)")
+    ap.add_argument("--i8-tile", type=int, default=0, help="force K2 (INT8) tile config (tuning)")
     ap.add_argument("--no-fuse", action="store_true", help="keep [shortcut] layers as separate kernels")
     return ap.parse_args()
 
@@ -213,6 +214,8 @@ def main():
     net.set_stream(stream.cuda_stream)
     if args.tile:
         net.set_conv_tile(args.tile)
+    if args.i8_tile:
+        net.set_int8_tile(args.i8_tile)
 
     B = args.batch
     gen = torch.Generator(device=dev)

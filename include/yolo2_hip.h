@@ -262,6 +262,9 @@ int yl_network_pull_heads(yl_network *net);
  * yl_network_set_nms_mode: yl_network_detect_batch's suppression stage, 1 = one workgroup per
  *   (image, class) (default), 0 = one workgroup per image; same rows either way. */
 int yl_network_set_conv_tile(yl_network *net, int cfg);
+/* the same for the INT8 convolution (conv_i8_mfma.hip): 0 = heuristic, 1 = 64x128, 2 = 32x256, 3 = 128x128,
+ * 4 = 128x256 (8 waves), 5 = 64x256 */
+int yl_network_set_int8_tile(yl_network *net, int cfg);
 int yl_network_set_winograd(yl_network *net, int on);
 int yl_network_set_nms_mode(yl_network *net, int mode);
 /* Test hook (host only, no GPU needed): the Winograd weight transform U = G g G^T of a 3x3 layer
@@ -296,7 +299,7 @@ int yl_network_compact_detections(yl_network *net, float thresh, int cap,
  * img_w/img_h: host int[batch] with the source image sizes, or both NULL when relative=1 and
  * letter=0 (boxes relative to the network input).  cap <= YL_DETECT_MAX_CAP.
  * Asynchronous on the network's stream; reads the head outputs of the last forward. */
-#define YL_DETECT_MAX_CAP 2048
+#define YL_DETECT_MAX_CAP 4096
 int yl_network_detect_batch(yl_network *net, const int *img_w, const int *img_h, float thresh,
                             int relative, int letter, float nms, int cap,
                             float *records_dev, int *counts_dev);

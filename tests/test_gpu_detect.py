@@ -127,7 +127,7 @@ def test_overflowing_cap_reports_the_true_count():
     assert list(counts) == [n * w * h] * B
     assert all(len(r) == 50 for r in rows)
     with pytest.raises(Exception):
-        net.get_boxes_batch(0.2, 0.45, cap=4096)       # > YL_DETECT_MAX_CAP
+        net.get_boxes_batch(0.2, 0.45, cap=8192)       # > YL_DETECT_MAX_CAP
     with pytest.raises(Exception):
         net.get_boxes_batch(0.2, 0.45, cap=64, relative=0)   # absolute boxes need image sizes
     net.close()

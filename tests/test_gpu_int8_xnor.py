@@ -79,8 +79,16 @@ INT8_SHAPES = [
 ]
 
 
+INT8_SHAPES += [
+    (2, 128, 12, 12, 128, 3, 1, 1),    # M % 128 == 0: the wide tiles without row masks
+    (1, 256, 19, 19, 256, 3, 1, 1),    # odd map (yolov3-608's last scale), two 128-row tiles, 18 panels
+    (3, 64, 8, 8, 64, 1, 1, 0),        # one panel only (nkb = 1)
+]
+
+
 @pytest.mark.parametrize("shape", INT8_SHAPES)
-def test_conv_int8_bit_exact(olib, shape):
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+def test_conv_int8_bit_exact(olib, shape, tile):
     B, Cc, H, W, M, size, stride, pad = shape
     rng = np.random.default_rng(99 + Cc + M)
     K = Cc * size * size
@@ -95,6 +103,7 @@ def test_conv_int8_bit_exact(olib, shape):
     l1 = D.conv(B, W, H, Cc, M, size, stride, pad, D.LEAKY, wts, bias, weights_int8=wq, in_mult=in_mult, w_mult=w_mult)
     net = _net_from([l0, l1], B, W, H, Cc, quantized=1)
     assert net.layer_info(1)["int8"] == 1
+    net.set_int8_tile(tile)
     got = net.predict(x)
     acc = net.layer_int8_acc(1)
     ref = np.zeros_like(got)
@@ -225,15 +234,19 @@ def test_int8_network_vs_reference_library_batch1():
     net.close()
 
 
-def test_int8_fusion_is_bit_identical():
+@pytest.mark.parametrize("width,height,batch,tile", [(96, 96, 2, 0), (96, 96, 2, 1), (96, 96, 2, 3), (96, 96, 2, 4),
+                                                     (96, 96, 2, 5), (160, 96, 3, 0), (160, 96, 3, 3), (224, 160, 1, 4)])
+def test_int8_fusion_is_bit_identical(width, height, batch, tile):
     """-quantized yolov3 with yl_network_set_fusion: conv+[shortcut] folded, the next layer's int8
     input written from the producer's epilogue (no separate quantise pass), unread FP32 tensors
-    skipped.  Every tensor that is still materialised must equal the unfused run bit for bit."""
-    name, width, height, batch = "yolov3", 96, 96, 2
+    skipped.  Every tensor that is still materialised must equal the unfused run bit for bit -- for every
+    tile configuration of the INT8 kernel (odd maps down to 3x3: tiles span several images)."""
+    name = "yolov3"
     cfg, wts = common.model_files(name, width, height)
     x = common.seeded_input(batch, 3, height, width)
     plain = Network.load(cfg, wts, batch, 1, device=0)
     fused = Network.load(cfg, wts, batch, 1, device=0, fuse=True)
+    fused.set_int8_tile(tile)
     plain.predict(x)
     fused.predict(x)
     infos = plain.layers()

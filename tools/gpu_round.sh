@@ -79,6 +79,39 @@ if has pmc; then
   find $OUT -name "*counter_collection.csv" -size +30M -delete
   find $OUT -name "*kernel_trace.csv" -size +20M -delete
 fi
+if has i8tiles; then
+  echo "== INT8 tile sweep (per-layer tables)" | tee -a $OUT/summary.txt
+  for T in ${I8TILES:-0 1 3 4 5}; do
+    timeout 600 python bench.py --mode int8 --i8-tile $T --steps 8 --warmup 2 --layers --no-cpu-baseline --no-e2e > $OUT/bench_int8_t$T.json 2> $OUT/bench_int8_t${T}_layers.txt
+    echo "i8 tile $T exit $? $(python -c "import json,sys; d=json.loads(open('$OUT/bench_int8_t$T.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'])" 2>/dev/null)" | tee -a $OUT/summary.txt
+  done
+fi
+if has blockpmc; then
+  # per-dispatch counters of the residual-block micro network: BLOCK_ARGS="--mode int8 --C 512 --H 38" BLOCK_TAG=i8s4
+  echo "== block micro network + PMC: $BLOCK_ARGS" | tee -a $OUT/summary.txt
+  timeout 300 python tools/block_bench.py $BLOCK_ARGS > $OUT/block_${BLOCK_TAG}.txt 2>&1
+  cat $OUT/block_${BLOCK_TAG}.txt | tail -14
+  for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INSTS_SMEM" "FETCH_SIZE" "WRITE_SIZE"; do
+    N=$(echo $C | tr ' ' '_' | cut -c1-30)
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/blk_${BLOCK_TAG}_$N -o pmc -- python $R/tools/block_bench.py $BLOCK_ARGS --iters 1 > $R/$OUT/blk_${BLOCK_TAG}_$N.log 2>&1 )
+    echo "blockpmc $BLOCK_TAG $N exit $?" | tee -a $OUT/summary.txt
+  done
+  python tools/pmc_dispatch.py $OUT conv > $OUT/block_${BLOCK_TAG}_pmc.txt 2>&1
+  find $OUT -name "*kernel_trace.csv" -size +20M -delete
+fi
+if has pmcx; then
+  # PMC passes for another bench mode: PMCX_ARGS="--mode int8" PMCX_TAG=int8 (own runs, kernel-trace only)
+  echo "== rocprofv3 PMC passes for: $PMCX_ARGS" | tee -a $OUT/summary.txt
+  for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS"; do
+    N=$(echo $C | tr ' ' '_' | cut -c1-40)
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmcx_${PMCX_TAG}_$N -o pmc -- python $R/bench.py $PMCX_ARGS --steps 1 --warmup 0 --no-cpu-baseline --no-e2e --raw-head --nms 0 > $R/$OUT/pmcx_${PMCX_TAG}_$N.log 2>&1 )
+    echo "pmcx $PMCX_TAG $N exit $?" | tee -a $OUT/summary.txt
+  done
+  python tools/pmc_summary.py $OUT > $OUT/pmcx_${PMCX_TAG}_summary.txt 2>&1
+  head -60 $OUT/pmcx_${PMCX_TAG}_summary.txt
+  find $OUT -name "*counter_collection.csv" -size +30M -delete
+  find $OUT -name "*kernel_trace.csv" -size +20M -delete
+fi
 if has dist1; then
   echo "== bench through torch.distributed.run, world 1 (RCCL all-gather path)" | tee -a $OUT/summary.txt
   timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline --no-e2e --raw-head --nms 0 > $OUT/bench_dist1.json 2> $OUT/bench_dist1.err

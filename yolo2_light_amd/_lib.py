@@ -97,6 +97,7 @@ _SIGS = {
                                        c_float_p, C.c_int, c_int_p]),
     "yl_network_pull_heads": (C.c_int, [_vp]),
     "yl_network_set_conv_tile": (C.c_int, [_vp, C.c_int]),
+    "yl_network_set_int8_tile": (C.c_int, [_vp, C.c_int]),
     "yl_network_set_winograd": (C.c_int, [_vp, C.c_int]),
     "yl_network_set_nms_mode": (C.c_int, [_vp, C.c_int]),
     "yl_network_set_quant_rule": (C.c_int, [_vp, C.c_int]),

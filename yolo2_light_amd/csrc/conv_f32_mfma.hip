@@ -59,6 +59,9 @@ struct ConvF32Dev {
     const float *add;
     float *out_add;
     float *out;
+    int8_t *q_out;        // optional int8 side output for a following INT8 convolution (see epilogue.h)
+    float q_mult;
+    int q_G;
     int B, C, H, W, M, OH, OW;
     int K, Kpad, Mpad;
     int size, stride, pad;
@@ -78,6 +81,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
     static_assert(WM * WN == NWAVES, "wave grid");
     static_assert(TM >= 1 && TN >= 1, "tile too small");
     static_assert(NWAVES * 8 * TN * 32 <= 2 * BK * (BM + BN), "epilogue strips fit in the panel buffers");
+    // the quantise-on-store epilogue stages 16 rows per wave
+    constexpr bool Q_OK = NWAVES * 16 * TN * 32 <= 2 * BK * (BM + BN);
     static_assert(BN % 64 == 0 && BN <= NT, "a wave must stay inside one k row of the B panel");
     constexpr int A_F4 = BK * BM / 4;
     constexpr int APT = (A_F4 + NT - 1) / NT;               // float4 per thread per panel
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
     // ---- fused epilogue: +bias, activation (identical arithmetic to v1), then row-wise stores
     //      through a wave-private LDS strip (epilogue.h); the main loop's last barrier has passed,
     //      so the panel buffers are dead and are reused as the strips ----
-    float *strip = smem + wave * (8 * TN * 32);
+    float *strip = smem + wave * ((Q_OK ? 16 : 8) * TN * 32);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         float vals[TN][16];
@@ -328,6 +333,13 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
                 float v = acc[i][j][e] + bv;
                 if (p.act == YL_LEAKY) v = (v > 0.f) ? v : (float)(.1 * (double)v);
                 vals[j][e] = v;
+            }
+        }
+        if constexpr (Q_OK) {
+            if (p.q_out) {
+                store_rows_via_lds_q<TN>(strip, vals, m0 + wm0 + i * 32, p.M, n0 + wn0, p.Ntotal, p.OHW,
+                                         p.out, p.add, p.out_add, p.q_out, p.q_mult, p.q_G, lane);
+                continue;
             }
         }
         store_rows_via_lds<TN>(strip, vals, m0 + wm0 + i * 32, p.M, n0 + wn0, p.Ntotal, p.OHW,
@@ -363,6 +375,12 @@ static int launch_conv_f32_direct(const ConvF32Args &a, int cfg, void *stream, c
 {
     ConvF32Dev d;
     d.in = a.in; d.wt = a.wt; d.bias = a.bias; d.add = a.add; d.out_add = a.out_add; d.out = a.out;
+    d.q_out = a.q_out; d.q_mult = a.q_mult; d.q_G = a.q_G;
+    if (a.q_out) {
+        if (a.M % 16 != 0) return (int)hipErrorInvalidValue;
+        if (cfg == 10) cfg = 7;         // 16-row strips of the quantise-on-store epilogue do not fit these two
+        if (cfg == 11) cfg = 6;
+    }
     d.B = a.B; d.C = a.C; d.H = a.H; d.W = a.W; d.M = a.M; d.OH = a.OH; d.OW = a.OW;
     d.K = a.K; d.Kpad = a.Kpad; d.Mpad = a.Mpad;
     d.size = a.size; d.stride = a.stride; d.pad = a.pad; d.act = a.act;
@@ -403,6 +421,7 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
     // measured on MI355X (tools/sweep_conv.py, yolov3-608 shapes, B=64): with 32 input channels
     // ([64,288,92416]) Winograd wins stand-alone (1.59 vs 2.16 ms) but not in the network, where the
     // layer carries a fused shortcut and is bound by 3 GB of epilogue traffic (2.31 vs 2.2 ms): C >= 64.
+    if (a.q_out && a.wino32_u) return (int)hipErrorInvalidValue;      // the planner gives q_out to direct layers only
     if (a.wino32_u && (o.force_tile == 31 || (o.force_tile == 0 && o.winograd && a.C >= 64)))
         return launch_conv_f32_wino32(a, a.wino32_u, stream, name, name_len);
     if (o.force_tile == 31) return (int)hipErrorInvalidValue;   // forced on a layer without packed U

@@ -8,8 +8,7 @@
 // Data layout in HBM (chosen for 16-byte coalescing, not inherited from the reference):
 //   activations  act_q[B][G][H][W][16]  int8, G = Cpad/16 channel groups ("NC/16HW16"):
 //                for a fixed channel group consecutive pixels are consecutive 16-byte units,
-//                so both the quantise kernel's stores and the conv's im2col gathers are
-//                perfectly coalesced dwordx4 accesses.
+//                so both the quantise stores and the conv's im2col gathers are coalesced dwordx4.
 //   weights      w_q[K16pad][Mpad][16]  int8, K16 index = tap*G + cg (tap = ky*size+kx),
 //                i.e. k-major panels of 16-byte units, zero padded.
 // Math: v_mfma_i32_32x32x32_i8.  Each lane feeds 16 consecutive k-bytes of one filter (A)
@@ -18,7 +17,29 @@
 // scalar arithmetic exactly:
 //   o16 = clamp_abs(acc32 / 32 [C truncating division], 32767)
 //   y   = o16 * ALPHA1 ; y += bias ; leaky: y > 0 ? y : y / 10
-// Roofline: with FP32 activations in/out this path is HBM-bound, not MFMA-bound.
+//
+// What bounds it: activations stay FP32 between layers where a [shortcut]/route/head
+// reads them (reference semantics), so a residual block moves 8 bytes of FP32 residual stream per
+// output next to 1-2 bytes of int8 -- HBM-bound, the MFMA work is 5-30 % of a layer.  Round 1's
+// kernel spent more issue slots in its epilogue than in its K loop (per output ~40 VALU + an LDS
+// transpose + per-element branches) and more LDS cycles staging 64x128 tiles than MFMA cycles.
+// This version:
+//   * the epilogue works in the MFMA C/D register layout -- no LDS, no wave barriers:
+//       - a lane owns pixel column n and rows (e&3)+8*(e>>2)+4*half: FP32 NCHW loads/stores are one
+//         dword per lane, 32 consecutive pixels = one 128-byte line per row and half-wave, addressed
+//         through buffer descriptors (row offset in an SGPR, pixel offset in a VGPR, columns beyond
+//         the tensor dropped by the range check);
+//       - the [shortcut] operand is fetched BEFORE the last K panel and lands under its MFMAs;
+//       - the int8 side output for the next layer packs the lane's 4 consecutive channels into a
+//         dword and one v_permlane32_swap gives each lane 8 contiguous bytes of the 16-byte unit
+//         (lanes 0-31 bytes 0-7, lanes 32-63 bytes 8-15): 512 contiguous bytes per store instruction;
+//   * exact arithmetic in ~16 VALU per output: the int16 clamp is applied first (|acc| < 2^20 is
+//     exact in float), acc/32 = trunc(acc * 2^-5), y/10 by Markstein's fma sequence, leaky as
+//     max(y, y/10); the two data-dependent corners (|y| < 1e-30 where the fma sequence could meet
+//     subnormals, |x*mult| >= 32768 where `int16_t = float` wraps) are detected per 32x32 block with
+//     v_min3/v_max3 and recomputed by the plain formulas on a cold path;
+//   * tile choice per layer: 128x128 (wave tile 64x64: half the LDS operand traffic per MFMA) for
+//     K-heavy layers, 64x128 / 32x256 for narrow-M layers.
 #include <hip/hip_runtime.h>
 #include <climits>
 #include <cstdlib>
@@ -31,6 +52,7 @@ namespace yl {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------ K2a: quantise + repack
 // one lane per (b, cg, pixel): 16 coalesced plane reads, one 16-byte coalesced store
@@ -71,17 +93,10 @@ int launch_quantize_nhwc(const float *in, int8_t *out, int B, int C, int H, int 
 }
 
 // ------------------------------------------------------------------ K2b: INT8 MFMA implicit GEMM
-// With 32-cycle MFMAs and K of only 0.1-9 KB per output the matrix work is ~5 % of this
-// kernel; measured (profiles/r1_int8_pmc.txt) it is bound by instruction issue and by how
-// many waves are in flight, so the design goals are: few instructions per output, small
-// register/LDS footprint (3 waves/SIMD), loads one full iteration ahead.
 //   - one LDS panel = BK16 16-byte k-units (128 bytes of K), double-buffered; registers hold
-//     panel kb+1 and are refilled with panel kb+2 in slices interleaved with the MFMAs (as K1 v2)
+//     panel kb+1 and are refilled with panel kb+2 in slices interleaved with the MFMAs (as K1)
 //   - when G >= BK16 (C >= 128) a panel lies inside one tap: tap decode once per panel
-//   - bias comes from LDS, the epilogue is ~15 VALU per output and exact (see below)
-//   - optional fused [shortcut] (out_add = y + add), bit-identical to the separate kernel
 constexpr int BK16 = 8;          // 16-byte k-units per LDS panel (= 4 MFMA k-steps of 32)
-constexpr int NT = 256;
 
 struct ConvI8Dev {
     const int8_t *in_q;
@@ -104,28 +119,33 @@ struct ConvI8Dev {
 // y / 10 correctly rounded (the reference's leaky on this path is `y / 10`, quantized.c:625):
 // Markstein's sequence q = RN(y*r), e = fma(-10, q, y), q' = fma(e, r, q) with r = RN(1/10) returns
 // RN(y/10) for normal operands; tiny |y| (possible subnormal intermediates) take the IEEE divide.
-__device__ __forceinline__ float div10_exact(float y)
+__device__ __forceinline__ float div10_markstein(float y)
 {
-    if (fabsf(y) < 1e-30f) return __fdiv_rn(y, 10.f);
     const float r = 0.1f;
     const float q = __fmul_rn(y, r);
     const float e = __fmaf_rn(-10.f, q, y);
     return __fmaf_rn(e, r, q);
 }
-
-template <int BM, int BN, int WM, int WN, bool TAPPANEL>
-__global__ __launch_bounds__(NT) void conv_i8_mfma_kernel(ConvI8Dev p)
+__device__ __forceinline__ float div10_exact(float y)
 {
+    if (fabsf(y) < 1e-30f) return __fdiv_rn(y, 10.f);
+    return div10_markstein(y);
+}
+
+template <int BM, int BN, int WM, int WN, bool TAPPANEL, bool MFULL>
+__global__ __launch_bounds__(WM * WN * 64) void conv_i8_mfma_kernel(ConvI8Dev p)
+{
+    constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
     constexpr int KSTEPS = BK16 / 2;
-    static_assert(WM * WN == 4, "4 waves");
-    static_assert(BN % 64 == 0 && BN <= NT, "B panel mapping");
+    static_assert(BN % 64 == 0 && BN <= NT && NT % BN == 0, "B panel mapping");
     constexpr int A_UNITS = BK16 * BM;                 // 16-byte units per A panel
     constexpr int APT = (A_UNITS + NT - 1) / NT;
     constexpr bool A_FULL = (A_UNITS % NT) == 0;
     constexpr int BPT = BK16 * BN / NT;
     constexpr int G_STEP = NT / BN;
+    static_assert(BPT >= 1 && BK16 % G_STEP == 0, "B panel mapping");
 
     __shared__ __attribute__((aligned(16))) uint4 smem[2 * BK16 * BM + 2 * BK16 * BN + BM / 4];
     uint4 *As = smem;
@@ -265,59 +285,89 @@ __global__ __launch_bounds__(NT) void conv_i8_mfma_kernel(ConvI8Dev p)
     }
     __syncthreads();
 
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int buf = kb & 1;
-        const bool do_store = kb + 1 < nkb;
-        const bool do_load = kb + 2 < nkb;
-        if (do_load) { YL_PANEL_SETUP(kb + 2) }
-        const uint4 *Ab = As + buf * BK16 * BM + wm0 + l31;
-        const uint4 *Bb = Bs + buf * BK16 * BN + wn0 + l31;
-        v4i av[2][TM], bv[2][TN];
+    // one k-block; DO_STORE: registers (panel kb+1) -> LDS[buf^1]; DO_LOAD: panel kb+2 -> registers
+#define YL_ITER(KB, DO_STORE, DO_LOAD)                                                             \
+    {                                                                                              \
+        const int buf = (KB) & 1;                                                                  \
+        if (DO_LOAD) { YL_PANEL_SETUP((KB) + 2) }                                                  \
+        const uint4 *Ab = As + buf * BK16 * BM + wm0 + l31;                                        \
+        const uint4 *Bb = Bs + buf * BK16 * BN + wn0 + l31;                                        \
+        v4i av[2][TM], bv[2][TN];                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) av[0][i] = __builtin_bit_cast(v4i, Ab[half * BM + i * 32]); \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[0][j] = __builtin_bit_cast(v4i, Bb[half * BN + j * 32]); \
+        _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                    \
+            const int cur = ks & 1, nxt = cur ^ 1;                                                 \
+            _Pragma("unroll") for (int e = ks * APT / KSTEPS; e < (ks + 1) * APT / KSTEPS; ++e) {  \
+                if (DO_STORE) YL_STORE_A(buf ^ 1, e)                                               \
+                if (DO_LOAD) YL_LOAD_A((KB) + 2, e)                                                \
+            }                                                                                      \
+            _Pragma("unroll") for (int e = ks * BPT / KSTEPS; e < (ks + 1) * BPT / KSTEPS; ++e) {  \
+                if (DO_STORE) YL_STORE_B(buf ^ 1, e)                                               \
+                if (DO_LOAD) YL_LOAD_B((KB) + 2, e)                                                \
+            }                                                                                      \
+            if (ks + 1 < KSTEPS) {                                                                 \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                     \
+                    av[nxt][i] = __builtin_bit_cast(v4i, Ab[(2 * (ks + 1) + half) * BM + i * 32]); \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                     \
+                    bv[nxt][j] = __builtin_bit_cast(v4i, Bb[(2 * (ks + 1) + half) * BN + j * 32]); \
+            }                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                         \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                     \
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
+    }
+
+    int kb = 0;
+    for (; kb + 2 < nkb; ++kb) { YL_ITER(kb, true, true) __syncthreads(); }
+    if (kb + 1 < nkb) { YL_ITER(kb, true, false) __syncthreads(); ++kb; }
+
+    // ---- epilogue addressing (C/D layout): this lane's pixel columns and row offsets ----
+    const int OHW = p.OHW;
+    const int ob_first = (n0 + wn0) / OHW;                       // wave-uniform
+    int voff_o[TN], voff_q[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) av[0][i] = __builtin_bit_cast(v4i, Ab[half * BM + i * 32]);
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + l31;
+        const int ob = n / OHW;
+        const int opix = n - ob * OHW;
+        const bool ok = n < p.Ntotal;
+        voff_o[j] = ok ? (int)(((unsigned)(ob - ob_first) * (unsigned)p.M * (unsigned)OHW + (unsigned)opix +
+                                4u * (unsigned)half * (unsigned)OHW) * 4u) : -1;
+        voff_q[j] = ok ? (int)((((unsigned)(ob - ob_first) * (unsigned)p.q_G * (unsigned)OHW + (unsigned)opix) * 16u) +
+                               8u * (unsigned)half) : -1;
+    }
+    const size_t img_out = (size_t)p.M * OHW;
+    size_t orec = ((size_t)p.B - ob_first) * img_out * 4;
+    if (orec > 0xFFFFFFFEull) orec = 0xFFFFFFFEull;
+    const bool has_add = p.add != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)((has_add ? p.add : p.bias) + (has_add ? (size_t)ob_first * img_out : 0)), 0, has_add ? (int)(unsigned)orec : 0, 0x00020000);
+    const int row_bytes = OHW * 4;
+    // row validity of rows that can lie beyond M (only when the filter count is not a multiple of the tile)
+#define YL_ROW_OFF(I, E) ((m0 + wm0 + (I) * 32 + ((E) & 3) + 8 * ((E) >> 2)) * row_bytes)
+#define YL_ROW_OK(I, E) (MFULL || (m0 + wm0 + (I) * 32 + ((E) & 3) + 8 * ((E) >> 2) + 4 * half) < p.M)
+
+    // [shortcut] operand: fetched now, lands under the MFMAs of the last panel
+    float addv[TM][TN][16];
+    if (has_add) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bv[0][j] = __builtin_bit_cast(v4i, Bb[half * BN + j * 32]);
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            const int cur = ks & 1, nxt = cur ^ 1;
-#pragma unroll
-            for (int e = ks * APT / KSTEPS; e < (ks + 1) * APT / KSTEPS; ++e) {
-                if (do_store) YL_STORE_A(buf ^ 1, e)
-                if (do_load) YL_LOAD_A(kb + 2, e)
-            }
-#pragma unroll
-            for (int e = ks * BPT / KSTEPS; e < (ks + 1) * BPT / KSTEPS; ++e) {
-                if (do_store) YL_STORE_B(buf ^ 1, e)
-                if (do_load) YL_LOAD_B(kb + 2, e)
-            }
-            if (ks + 1 < KSTEPS) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) av[nxt][i] = __builtin_bit_cast(v4i, Ab[(2 * (ks + 1) + half) * BM + i * 32]);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bv[nxt][j] = __builtin_bit_cast(v4i, Bb[(2 * (ks + 1) + half) * BN + j * 32]);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int e = 0; e < 16; ++e)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
+                    addv[i][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                        rs_add, YL_ROW_OK(i, e) ? voff_o[j] : -1, YL_ROW_OFF(i, e), 0));
     }
+    YL_ITER(kb, false, false)
+#undef YL_ITER
 #undef YL_PANEL_SETUP
 #undef YL_LOAD_A
 #undef YL_LOAD_B
 #undef YL_STORE_A
 #undef YL_STORE_B
 
-    // ---- exact reference epilogue, then row-wise stores through wave-private LDS strips ----
-    //   o16 = clamp_abs(acc32 / 32 [C truncation], 32767); y = o16*ALPHA1; y += bias; leaky: y/10
-    float bias_r[TM][16];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) bias_r[i][e] = bias_s[wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half];
     if (p.dbg) {          // parity hook: int16-clamped accumulators, straight from the C/D layout
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -339,30 +389,112 @@ __global__ __launch_bounds__(NT) void conv_i8_mfma_kernel(ConvI8Dev p)
                 }
         }
     }
-    __syncthreads();      // bias_s and the panel buffers are dead from here: reuse as strips
-    float *strip = reinterpret_cast<float *>(smem) + wave * (16 * TN * 32);
+
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.out ? p.out + (size_t)ob_first * img_out : (float *)p.bias), 0, p.out ? (int)(unsigned)orec : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_oadd = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(has_add ? p.out_add + (size_t)ob_first * img_out : (float *)p.bias), 0, has_add ? (int)(unsigned)orec : 0, 0x00020000);
+    const size_t img_q = (size_t)p.q_G * OHW * 16;
+    size_t qrec = ((size_t)p.B - ob_first) * img_q;
+    if (qrec > 0xFFFFFFFEull) qrec = 0xFFFFFFFEull;
+    const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.q_out ? p.q_out + (size_t)ob_first * img_q : (int8_t *)p.bias), 0, p.q_out ? (int)(unsigned)qrec : 0, 0x00020000);
+    const bool leaky = p.act == YL_LEAKY;
+    const float alpha1 = p.alpha1, q_mult = p.q_mult;
+
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        float vals[TN][16];
+        float bias_r[16];
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int e = 0; e < 16; ++e) bias_r[e] = bias_s[wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float y[16];
+            float tmin = 1.f;
+            // ---- o16 -> y (fast forms; the corners are caught by tmin and redone below).  o16 =
+            //      max_abs(acc / 32, 32767): clamping acc to +-(32767*32+31) FIRST gives the same o16 (the
+            //      clamp only acts where |acc/32| >= 32768) and makes acc exact in float, so the C
+            //      truncating division is trunc(acc * 2^-5) ----
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int a = acc[i][j][e];
-                int o = (a + ((a >> 31) & 31)) >> 5;                 // a / 32, C truncation toward zero
-                o = o > 32767 ? 32767 : (o < -32767 ? -32767 : o);   // max_abs(., 256*128-1)
-                float y = __fmul_rn((float)o, p.alpha1);
-                y = __fadd_rn(y, bias_r[i][e]);
-                if (p.act == YL_LEAKY) y = (y > 0.f) ? y : div10_exact(y);
-                vals[j][e] = y;
+                const int c = a < -1048575 ? -1048575 : (a > 1048575 ? 1048575 : a);
+                const float o = truncf(__fmul_rn((float)c, 0.03125f));
+                float v = __fadd_rn(__fmul_rn(o, alpha1), bias_r[e]);
+                if (leaky) {
+                    tmin = fminf(tmin, fabsf(v));
+                    v = fmaxf(v, div10_markstein(v));
+                }
+                y[e] = v;
             }
-        if (p.q_out)
-            store_rows_via_lds_q<TN>(strip, vals, m0 + wm0 + i * 32, p.M, n0 + wn0, p.Ntotal, p.OHW,
-                                     p.out, p.add, p.out_add, p.q_out, p.q_mult, p.q_G, lane);
-        else
-            store_rows_via_lds<TN>(strip, vals, m0 + wm0 + i * 32, p.M, n0 + wn0, p.Ntotal, p.OHW,
-                                   p.out, p.add, p.out_add, lane);
+            if (leaky && __builtin_amdgcn_ballot_w64(tmin < 1e-30f) != 0ull) {      // cold: zeros / near-subnormal outputs
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int a = acc[i][j][e];
+                    int o = (a + ((a >> 31) & 31)) >> 5;
+                    o = o > 32767 ? 32767 : (o < -32767 ? -32767 : o);
+                    float v = __fadd_rn(__fmul_rn((float)o, alpha1), bias_r[e]);
+                    y[e] = (v > 0.f) ? v : div10_exact(v);
+                }
+            }
+            // ---- FP32 outputs in the C/D layout: one 128-byte line per row and half-wave ----
+            if (p.out) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[e]), rs_out,
+                                                          YL_ROW_OK(i, e) ? voff_o[j] : -1, YL_ROW_OFF(i, e), 0);
+            }
+            if (has_add) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    y[e] = __fadd_rn(y[e], addv[i][j][e]);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y[e]), rs_oadd,
+                                                          YL_ROW_OK(i, e) ? voff_o[j] : -1, YL_ROW_OFF(i, e), 0);
+                }
+            }
+            // ---- int8 side output for the next INT8 convolution (its input multiplier) ----
+            if (p.q_out) {
+                unsigned pk[4];
+                float tmax = 0.f;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    int c[4];
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const float t = __fmul_rn(y[g4 * 4 + r4], q_mult);
+                        tmax = fmaxf(tmax, fabsf(t));
+                        const int ci = (int)t;                          // v_cvt_i32_f32: truncation
+                        c[r4] = ci < -127 ? -127 : (ci > 127 ? 127 : ci);
+                    }
+                    pk[g4] = __builtin_amdgcn_perm((unsigned)c[1], (unsigned)c[0], 0x0C0C0400u) |
+                             __builtin_amdgcn_perm((unsigned)c[3], (unsigned)c[2], 0x04000C0Cu);
+                }
+                if (__builtin_amdgcn_ballot_w64(!(tmax < 32768.f)) != 0ull) {    // cold: the int16 wrap-around corner / NaN
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        unsigned w = 0;
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4)
+                            w |= ((unsigned)(quantize_input_i8(y[g4 * 4 + r4], q_mult) & 0xFF)) << (8 * r4);
+                        pk[g4] = w;
+                    }
+                }
+                // rows 0-3 | 8-11 (lanes 0-31) and 4-7 | 12-15 (lanes 32-63) of each 16-channel unit:
+                // after the half exchange lanes 0-31 hold bytes 0-7, lanes 32-63 bytes 8-15
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(pk[2 * u], pk[2 * u + 1], false, false);
+                    v2u d;
+                    d[0] = sw[0]; d[1] = sw[1];
+                    const int cg = (m0 + wm0 + i * 32 + 16 * u) >> 4;
+                    const bool unit_ok = MFULL || (m0 + wm0 + i * 32 + 16 * u) < p.M;
+                    __builtin_amdgcn_raw_buffer_store_b64(d, rs_q, unit_ok ? voff_q[j] : -1, cg * OHW * 16, 0);
+                }
+            }
+        }
     }
+#undef YL_ROW_OFF
+#undef YL_ROW_OK
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -371,15 +503,21 @@ static int launch_i8_tile(ConvI8Dev p, hipStream_t s)
     p.tiles_m = (p.M + BM - 1) / BM;
     const long long blocks = (long long)p.tiles_m * ((p.Ntotal + BN - 1) / BN);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    constexpr int NT = WM * WN * 64;
+    const bool mfull = (p.M % BM) == 0;
     // a panel of BK16 units lies inside one tap when G is a multiple of BK16 (C >= 128)
-    if (p.G >= BK16)
-        hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, true>), dim3((unsigned)blocks), dim3(NT), 0, s, p);
-    else
-        hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, false>), dim3((unsigned)blocks), dim3(NT), 0, s, p);
+    const bool tap = p.G >= BK16;
+    dim3 grid((unsigned)blocks), block(NT);
+    if (tap && mfull) hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, p);
+    else if (tap) hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, p);
+    else if (mfull) hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, p);
     return (int)hipGetLastError();
 }
 
-int launch_conv_i8(const ConvI8Args &a, void *stream)
+// tile: 0 = heuristic, 1 = 64x128 (4 waves, wave tile 32x64), 2 = 32x256, 3 = 128x128 (wave tile 64x64),
+//       4 = 128x256 (8 waves, wave tile 64x64), 5 = 64x256 (wave tile 64x64)
+int launch_conv_i8(const ConvI8Args &a, int tile, void *stream, char *name, size_t name_len)
 {
     ConvI8Dev d;
     d.in_q = a.in_q; d.w_q = a.w_q; d.bias = a.bias; d.out = a.out; d.dbg = a.dbg;
@@ -388,6 +526,7 @@ int launch_conv_i8(const ConvI8Args &a, void *stream)
     d.B = a.B; d.G = a.Cpad / 16; d.H = a.H; d.W = a.W; d.M = a.M; d.Mpad = a.Mpad; d.OH = a.OH; d.OW = a.OW;
     d.size = a.size; d.stride = a.stride; d.pad = a.pad; d.act = a.act; d.alpha1 = a.alpha1;
     if (d.G <= 0 || (d.G & (d.G - 1)) != 0 || a.size > 5) return (int)hipErrorInvalidValue;
+    if (a.q_out && (a.M % 16) != 0) return (int)hipErrorInvalidValue;
     d.Gshift = 0;
     while ((1 << d.Gshift) < d.G) ++d.Gshift;
     d.K16 = a.size * a.size * d.G;
@@ -398,13 +537,27 @@ int launch_conv_i8(const ConvI8Args &a, void *stream)
     d.Ntotal = (int)nt;
     d.tiles_m = 0;
     hipStream_t s = (hipStream_t)stream;
-    // measured (gpurun r1i): this kernel is bound by waves in flight, not by operand reuse, so the
-    // 64x128 tile (49 KB LDS -> 3 workgroups/CU) beats 128x128 (66 KB -> 2): 2498 vs 2344 img/s on
-    // yolov3-608.  YL_I8_TILE=128 forces the larger tile for A/B runs.
-    static const int force = [] { const char *e = getenv("YL_I8_TILE"); return e ? atoi(e) : 0; }();
-    if (a.M <= 32) return launch_i8_tile<32, 256, 1, 4>(d, s);
-    if (force == 128 && a.M > 64) return launch_i8_tile<128, 128, 4, 1>(d, s);
-    return launch_i8_tile<64, 128, 2, 2>(d, s);
+    if (tile == 0) {
+        auto nblocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((nt + bn - 1) / bn); };
+        if (a.M <= 32) tile = 2;
+        else if (a.M <= 64) tile = 1;
+        // the wide wave tile pays where the K loop is long (3x3 with C >= 128) and there are enough tiles
+        else if (d.K16 >= 72 && nblocks(128, 128) >= 512) tile = 3;
+        else tile = 1;
+    }
+    if ((tile == 3 || tile == 4) && a.Mpad % 128 != 0) tile = 1;
+    const char *t = "?";
+    int rc;
+    switch (tile) {
+    case 1: t = "64x128"; rc = launch_i8_tile<64, 128, 2, 2>(d, s); break;
+    case 2: t = "32x256"; rc = launch_i8_tile<32, 256, 1, 4>(d, s); break;
+    case 3: t = "128x128"; rc = launch_i8_tile<128, 128, 2, 2>(d, s); break;
+    case 4: t = "128x256w8"; rc = launch_i8_tile<128, 256, 2, 4>(d, s); break;
+    case 5: t = "64x256"; rc = launch_i8_tile<64, 256, 1, 4>(d, s); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+    if (name) snprintf(name, name_len, "conv_i8_mfma<%s>", t);
+    return rc;
 }
 
 }  // namespace yl

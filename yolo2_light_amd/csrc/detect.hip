@@ -440,6 +440,15 @@ int launch_nms(float *rec_scratch, const int *counts, int B, int cap, int classe
     const int row_stride = 6 + classes;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = nms_lds_bytes(cap, classes);
+    const size_t lds_c = nms_class_lds_bytes(cap);
+    if (lds > 64 * 1024 || lds_c > 64 * 1024) {
+        // beyond the default 64 KB of dynamic LDS per workgroup (gfx950 has 160 KB per CU); per device, cheap
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&nms_class_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c);
+        if (e != hipSuccess) return (int)e;
+    }
     if (mode == 0 || !(nms > 0) || !meta) {   // mode 1 = (image, class)-parallel suppression
         hipLaunchKernelGGL(nms_kernel<0>, dim3(B), dim3(NMS_THREADS), lds, s, rec_scratch, counts, cap, classes,
                            row_stride, nms, netw, neth, dims, relative, letter, rec_out, counts_out, meta);
@@ -447,7 +456,7 @@ int launch_nms(float *rec_scratch, const int *counts, int B, int cap, int classe
     }
     hipLaunchKernelGGL(nms_kernel<2>, dim3(B), dim3(NMS_THREADS), lds, s, rec_scratch, counts, cap, classes,
                        row_stride, nms, netw, neth, dims, relative, letter, rec_out, counts_out, meta);
-    hipLaunchKernelGGL(nms_class_kernel, dim3(classes, B), dim3(NMS_THREADS), nms_class_lds_bytes(cap), s,
+    hipLaunchKernelGGL(nms_class_kernel, dim3(classes, B), dim3(NMS_THREADS), lds_c, s,
                        rec_scratch, counts, cap, classes, row_stride, nms, meta);
     hipLaunchKernelGGL(nms_kernel<1>, dim3(B), dim3(NMS_THREADS), lds, s, rec_scratch, counts, cap, classes,
                        row_stride, nms, netw, neth, dims, relative, letter, rec_out, counts_out, meta);

@@ -13,7 +13,10 @@ struct ConvF32Args {
     const float *bias;    // [M]
     const float *add;     // optional fused [shortcut]: out_add = act(conv) + add (nullptr = none)
     float *out_add;       // destination of the fused shortcut (the SHORTCUT layer's output)
-    float *out;           // [B][M][OH][OW]; may be nullptr when only out_add is wanted
+    float *out;           // [B][M][OH][OW]; may be nullptr when only out_add / q_out is wanted
+    int8_t *q_out = nullptr;   // optional quantised side output for the next INT8 conv: act_q[B][q_G][OH][OW][16]
+    float q_mult = 0.f;   // that layer's input_quant_multipler
+    int q_G = 0;          // its channel groups (Cpad/16); direct kernel only, needs M % 16 == 0
     int B, C, H, W, M, OH, OW;
     int K, Kpad, Mpad;
     int size, stride, pad;
@@ -56,7 +59,8 @@ struct ConvI8Args {
     int act;
     float alpha1;         // R_MULT / (in_mult * w_mult)   (quantized.c:596)
 };
-int launch_conv_i8(const ConvI8Args &a, void *stream);
+// tile: 0 = heuristic, 1..5 see conv_i8_mfma.hip (tuning / tests); writes the kernel instance name
+int launch_conv_i8(const ConvI8Args &a, int tile, void *stream, char *name, size_t name_len);
 
 // ---- K3: XNOR path ----
 // K3a: sign bits of FP32 NCHW packed along channels -> [B][H][W][Cw] 64-bit words, bit = (x > 0)
@@ -102,7 +106,7 @@ int launch_compact(const HeadDesc *heads, int n_heads, int B, int netw, int neth
 // rec_scratch[B][cap][6+classes] is consumed (its prob columns are zeroed in place); rows come out
 // in rec_out in the reference's final order.  Source image sizes travel as a kernel argument
 // (w | h << 16): mode 0 = network size, 1 = wh[0] for every image, 2 = wh[b].
-constexpr int NMS_MAX_CAP = 2048;
+constexpr int NMS_MAX_CAP = 4096;      // 30 bytes of LDS per record: 123 KB of the CU's 160 KB
 constexpr int NMS_MAX_DIMS = 256;
 struct ImgDims {
     int mode;

@@ -293,7 +293,12 @@ static int to_device(Network &net, int device)
             const Layer &in_l = net.layers[j - 1];
             if (in_l.type == YL_SHORTCUT && in_l.fused_into_conv) prod = j - 2;
             Layer &pl = net.layers[prod];
-            if (pl.type != YL_CONVOLUTIONAL || pl.conv_mode != CONV_INT8) continue;
+            if (pl.type != YL_CONVOLUTIONAL) continue;
+            // producer kernels with a quantise-on-store epilogue: K2, and K1's direct kernel (never a layer
+            // Winograd could take, never the xnor FP32 fallback): yolov3's layer 0 stops writing 3 GB of FP32
+            const bool f32_direct = pl.conv_mode == CONV_F32 && !pl.xnor &&
+                                    !wino_applicable(pl.c, pl.n, pl.size, pl.stride, pl.pad);
+            if (pl.conv_mode != CONV_INT8 && !f32_direct) continue;
             if (prod == j - 1 && pl.fused_shortcut >= 0) continue;
             if (pl.q_out_layer >= 0) continue;
             if ((pl.n % 16) != 0 || cons.Cpad != pl.n) continue;          // no padded channel groups
@@ -326,7 +331,13 @@ static int forward_layer(Network &net, size_t i, const float *input)
                 conv_in = net.d_binbuf;
             }
             a.in = conv_in; a.wt = l.d_weights_t; a.bias = l.d_biases; a.add = nullptr; a.out_add = nullptr;
-            a.out = l.d_output;
+            a.out = l.skip_f32_out ? nullptr : l.d_output;
+            if (l.q_out_layer >= 0) {
+                const Layer &nx = net.layers[l.q_out_layer];
+                a.q_out = net.d_qbuf + (l.q_out_layer % 3) * net.qbuf_bytes;
+                a.q_mult = nx.input_quant_multipler;
+                a.q_G = nx.Cpad / 16;
+            }
             if (l.fused_shortcut >= 0) {
                 // conv + [shortcut] in one pass (the reference GPU path fuses the same pair for XNOR
                 // convs, src/additionally.c:326-339): shortcut.out = act(conv) + layers[index].out;
@@ -368,8 +379,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
             // float ALPHA1 = R_MULT / (l.input_quant_multipler * l.weights_quant_multipler);  (quantized.c:596)
             a.alpha1 = 32 / (l.input_quant_multipler * l.weights_quant_multipler);
-            YL_LAUNCH(launch_conv_i8(a, s), "conv_i8");
-            snprintf(l.kernel_name, sizeof(l.kernel_name), "conv_i8_mfma");
+            YL_LAUNCH(launch_conv_i8(a, net.i8_tile, s, l.kernel_name, sizeof(l.kernel_name)), "conv_i8");
         } else {
             YL_LAUNCH(launch_pack_sign_bits(input, net.d_bitbuf, B, l.c, l.h, l.w, l.Cw, s), "pack_sign_bits");
             ConvXnorArgs a;
@@ -938,6 +948,14 @@ int yl_network_set_conv_tile(yl_network *net, int cfg)
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }
     if (!(cfg == 0 || (cfg >= 11 && cfg <= 22) || cfg == 31)) { set_error("unknown tile id"); return YL_ERR_ARG; }
     net->net.conv_opts.force_tile = cfg;
+    return YL_OK;
+}
+
+int yl_network_set_int8_tile(yl_network *net, int cfg)
+{
+    if (!net) { set_error("null argument"); return YL_ERR_ARG; }
+    if (cfg < 0 || cfg > 5) { set_error("unknown tile id"); return YL_ERR_ARG; }
+    net->net.i8_tile = cfg;
     return YL_OK;
 }
 

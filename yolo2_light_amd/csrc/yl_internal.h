@@ -90,6 +90,7 @@ struct Network {
     bool debug = false;
     bool fuse = false;                   // conv+shortcut epilogue fusion (yl_network_set_fusion)
     ConvF32Opts conv_opts;               // K1 kernel-selection knobs of THIS network (no process-global launch state)
+    int i8_tile = 0;                     // K2 tile (0 = heuristic; yl_network_set_int8_tile)
     int nms_mode = 1;                    // 1 = one workgroup per (image, class), 0 = one per image
     unsigned long long forward_seq = 0;  // bumped by every forward: detection cache key
     void *stream = nullptr;              // hipStream_t

@@ -175,6 +175,9 @@ class Network:
     def set_conv_tile(self, cfg: int) -> None:
         check(lib.yl_network_set_conv_tile(self._h, cfg), "yl_network_set_conv_tile")
 
+    def set_int8_tile(self, cfg: int) -> None:
+        check(lib.yl_network_set_int8_tile(self._h, cfg), "yl_network_set_int8_tile")
+
     def set_nms_mode(self, mode: int) -> None:
         check(lib.yl_network_set_nms_mode(self._h, mode), "yl_network_set_nms_mode")
 
@@ -307,7 +310,7 @@ class Network:
     def get_boxes(self, image: int, w: int, h: int, thresh: float, nms: float = 0.0,
                   relative: int = 1, letter: int = 0, max_rows: int = 4096) -> np.ndarray:
         classes = self.layer_info(self.n - 1)["classes"]
-        max_rows = min(max_rows, 2048)          # YL_DETECT_MAX_CAP
+        max_rows = min(max_rows, 4096)          # YL_DETECT_MAX_CAP
         rows = np.zeros((max_rows, 6 + classes), dtype=np.float32)
         n = lib.yl_network_get_boxes(self._h, image, w, h, thresh, relative, letter, nms, _fp(rows), max_rows, None)
         if n < 0:
