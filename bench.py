@@ -3,26 +3,33 @@
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N > 1 is launched with torch.distributed.run, one rank per GPU (RCCL).
-A "step" = one pass of the hot path over one batch of synthetic images that
-are already resident in HBM: forward of every layer (FP32 MFMA conv + small
-layers) -> on-device detection decode + compaction + per-class NMS for every image
-(yl_network_detect_batch) -> (N>1) RCCL all-gather of the fixed-capacity
-detection records to every rank.
-Default workload = BASELINE.json's metric config: yolov3.cfg 608x608,
-batch 64 per GPU, FP32, synthetic weights/images (no datasets or checkpoints
-exist offline).  Scaling is weak: the path shards by independent images, each
-rank owns `--batch` images and the replicated weights.
+A "step" = one pass of the hot path over one batch of synthetic images that are already resident in
+HBM: forward of every layer -> on-device detection decode + compaction + per-class NMS for every image
+(yl_network_detect_batch) -> (N>1) RCCL all-gather of the fixed-capacity detection records.
+
+Default workload = BASELINE.json's metric config: yolov3.cfg 608x608, GLOBAL batch 64, synthetic
+weights/images (no datasets or checkpoints exist offline).  The metric is "FP32 & INT8": `value` is the FP32
+leg, the `-quantized` INT8 leg of the same workload is timed in the same run and reported under "int8".
+Scaling is STRONG by default (config 3: the batch of 64 independent images is sharded over the N GPUs with
+yl_shard_range, 64/N images per GPU); `--scaling weak` keeps `--batch` images per GPU.
 
 Rank 0 prints ONE JSON line with the driver's fields plus
-  "roofline"     -- dominant kernel (the FP32 MFMA implicit-GEMM conv instance that
-                    carries most FLOPs): algorithmic FLOPs of its launches / their
-                    HIP-event-measured duration inside the timed region, vs the
-                    157.3 TFLOP/s FP32-matrix peak (MI355X_MICROARCH.md)
-  "cpu_baseline" -- the reference's own CPU path (oracle/_ref, its fastest documented
-                    build AVX+OpenMP) timed on this host, N=1 / rank 0 only.
-  "pcie_inclusive" -- the same workload host-to-host (u8 frames in, detection rows out; and
-                    yl_network_predict on float host images), N=1 only; reported beside
-                    `value`, never as `value`.
+  "roofline"     -- dominant kernel of the FP32 leg: EXECUTED matrix FLOPs of its launches (for the Winograd
+                    kernel the 16-multiply form incl. odd-size tile padding, i.e. what the MFMA pipe issued)
+                    / their HIP-event-measured duration inside the timed region, vs the 157.3 TFLOP/s FP32
+                    matrix peak: `frac` <= 1.  The algorithmic rate (2*M*K*N) and the Winograd
+                    speed-up are separate fields.  `traffic` is read from the committed PMC passes
+                    (profiles/pmc_traffic.json; counters need their own serialising rocprofv3 runs).
+  "int8"         -- value / ms_per_step of the INT8 leg, its roofline against HBM (algorithmic bytes of the
+                    dominant INT8 kernel's launches / their measured duration vs 8 TB/s) with the INT8-MFMA
+                    rate beside it, and the INT8-vs-FP32 detection agreement on the same images.
+  "cpu_baseline" -- the reference's own CPU path (oracle/_ref, its fastest documented build AVX+OpenMP)
+                    timed on this host, N=1 / rank 0 only.
+  "batch_sweep"  -- FP32 images/sec of ONE GPU at 8/16/32 images per step: what a rank of a strong-scaled
+                    8/4/2-GPU run has to do (N=1 only).
+  "group_n1"     -- the same step through the single-process multi-GPU C-ABI (yl_group_*, RCCL send/recv
+                    gather) on the GPU of this process (N=1 only).
+  "pcie_inclusive" -- the same workload host-to-host; reported beside `value`, never as `value`.
 """
 from __future__ import annotations
 
@@ -38,8 +45,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)"
-HBM_PEAK_GBS = 8000.0
+# /opt/skills/guides/MI355X_MICROARCH.md
+FP32_MATRIX_PEAK_TFLOPS = 157.3     # "Peak FP32 (matrix)": v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+INT8_MFMA_PEAK_TOPS = 5000.0        # i8 MFMA = 2x the bf16 rate (~2.5 PF dense): 2048 op/clk/SIMD; ubench 4404
+HBM_PEAK_GBS = 8000.0               # HBM3E spec; 6.29 TB/s measured for a float4 copy
+VALU_POPC_PEAK_TBITMAC = 629.0      # XNOR: one v_xnor + one v_bcnt per 32 bit-MACs, 32 lanes/clk/SIMD, 2.4 GHz
 
 
 def parse_args():
@@ -49,12 +59,15 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--model", default="yolov3", choices=["yolov3", "yolov3-tiny", "tiny-yolo-xnor"])
     ap.add_argument("--size", type=int, default=608)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
-    ap.add_argument("--mode", default="fp32", choices=["fp32", "int8"])
+    ap.add_argument("--batch", type=int, default=64, help="GLOBAL batch (strong scaling) / images per GPU (weak)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
+    ap.add_argument("--mode", default="both", choices=["both", "fp32", "int8"],
+                    help="both = FP32 leg as `value` + INT8 leg under \"int8\"; fp32 / int8 = that leg only as `value`")
     ap.add_argument("--thresh", type=float, default=0.24)
     ap.add_argument("--cap", type=int, default=1024, help="detection records per image")
     ap.add_argument("--nms", type=float, default=0.4, help="do_nms_sort threshold (src/main.c:173); 0 = compaction only")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive leg after the timed region")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip batch sweep / group leg / agreement / recalibration")
     ap.add_argument("--raw-head", action="store_true",
                     help="keep the uncalibrated random detection head (thousands of boxes per image)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,16 +108,16 @@ def cpu_baseline(cfg: str, wts: str, width: int, height: int, quantized: int, bu
     }
 
 
-def calibrate_head(Network, cfg: str, wts: str, size: int, device: int, thresh: float, quantized: int):
+def calibrate_head(Network, cfg: str, wts: str, size: int, device: int, thresh: float):
     """Bias shifts that give the random-weight YOLO heads a detector-like output density.
     With i.i.d. weights whole anchor channels saturate (every cell of an anchor passes the
     objectness threshold with ~40 of 80 classes each: ~3800 boxes/image at 608), which no trained
     detector produces and which would turn the post-processing stage into the benchmark.  A
-    2-image probe measures each head channel's logit distribution; the objectness channels are
+    2-image FP32 probe measures each head channel's logit distribution; the objectness channels are
     shifted so that 0.3 % of the cells pass `thresh` (~70 boxes per 608x608 image, COCO-like) and
     the class channels so that ~1.5 % of (box, class) pairs exceed 0.5.  Convolution work is
-    unchanged (same shapes, same FLOPs); only head biases move."""
-    probe = Network.load(cfg, wts, 2, quantized, device=device)
+    unchanged (same shapes, same FLOPs); only head biases move.  The same weights serve both legs."""
+    probe = Network.load(cfg, wts, 2, 0, device=device)
     x = np.random.default_rng(11).random((2, 3, size, size), dtype=np.float32)
     probe.predict(x)
     deltas = []
@@ -125,7 +138,294 @@ def calibrate_head(Network, cfg: str, wts: str, size: int, device: int, thresh: 
     return deltas
 
 
-def pcie_inclusive(net, torch, stream, args, rec, cnt, steps: int = 3):
+def recalibrate_int8(Network, cfg: str, wts: str, size: int, device: int) -> str:
+    """`darknet detector calibrate` on synthetic images (yl_network_calibrate): the cfg's shipped
+    input_calibration= list belongs to the trained weights; the -quantized leg gets the multipliers the
+    reference's own tool derives for THESE weights.  Returns the path of a cfg with that list."""
+    probe = Network.load(cfg, wts, 2, 0, device=device)
+    imgs = np.random.default_rng(12).random((4, 3, size, size), dtype=np.float32)
+    mult = probe.calibrate(imgs)
+    probe.close()
+    text = open(cfg).read()
+    vals = ", ".join("%.6g" % float(v) for v in mult) + ", 16"
+    lines = []
+    done = False
+    for line in text.splitlines():
+        if line.strip().startswith("input_calibration"):
+            line = "input_calibration = " + vals
+            done = True
+        lines.append(line)
+    if not done:
+        k = next(i for i, ln in enumerate(lines) if ln.strip().startswith("["))
+        lines.insert(k + 1, "input_calibration = " + vals)
+    out = cfg[:-4] + "-recal.cfg"
+    with open(out, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return out
+
+
+def wino_executed_flops(li: dict, B: int) -> float:
+    """MFMA FLOPs conv_f32_wino32 issues: 16 multiplies per (filter, channel, 2x2 tile), filters padded to the
+    32-row tile, tiles = ceil(h/2)*ceil(w/2) per image padded to the 64-tile workgroup."""
+    tiles = B * ((li["h"] + 1) // 2) * ((li["w"] + 1) // 2)
+    tiles = (tiles + 63) // 64 * 64
+    m = (li["n"] + 31) // 32 * 32
+    return 2.0 * m * li["c"] * 16.0 * tiles
+
+
+def iou(a, b):
+    def ov(x1, w1, x2, w2):
+        return min(x1 + w1 / 2, x2 + w2 / 2) - max(x1 - w1 / 2, x2 - w2 / 2)
+    w = ov(a[0], a[2], b[0], b[2]); h = ov(a[1], a[3], b[1], b[3])
+    if w <= 0 or h <= 0:
+        return 0.0
+    inter = w * h
+    return inter / (a[2] * a[3] + b[2] * b[3] - inter)
+
+
+def detection_agreement(ref_rows, got_rows):
+    """`got` (INT8) against `ref` (FP32) per image: a reference detection (a row with a surviving class) is
+    matched by the INT8 detection of the same best class with the highest IoU >= .5; greedy, one-to-one."""
+    tp = n_ref = n_got = 0
+    ious = []
+    dobj = []
+    for r, g in zip(ref_rows, got_rows):
+        r = r[(r[:, 6:] > 0).any(axis=1)] if len(r) else r
+        g = g[(g[:, 6:] > 0).any(axis=1)] if len(g) else g
+        n_ref += len(r); n_got += len(g)
+        used = np.zeros(len(g), bool)
+        gc = g[:, 6:].argmax(axis=1) if len(g) else np.zeros(0, int)
+        for row in r:
+            c = int(row[6:].argmax())
+            best, bj = 0.0, -1
+            for j in np.flatnonzero((gc == c) & ~used):
+                v = iou(row[:4], g[j, :4])
+                if v > best:
+                    best, bj = v, j
+            if bj >= 0 and best >= 0.5:
+                used[bj] = True
+                tp += 1
+                ious.append(best)
+                dobj.append(abs(float(row[4]) - float(g[bj, 4])))
+    return {
+        "fp32_detections": int(n_ref), "int8_detections": int(n_got), "matched": int(tp),
+        "recall_vs_fp32": tp / n_ref if n_ref else None, "precision_vs_fp32": tp / n_got if n_got else None,
+        "mean_iou_of_matched": float(np.mean(ious)) if ious else None,
+        "mean_abs_objectness_diff": float(np.mean(dobj)) if dobj else None,
+        "rule": "same best class, IoU >= 0.5, one-to-one; thresh and nms as the timed step",
+    }
+
+
+class Leg:
+    """One timed leg (FP32 or INT8) of the workload on this rank."""
+
+    def __init__(self, args, torch, dist, dev, stream, Network, cfg, wts, quantized, b_local, world, use_dist):
+        self.args, self.torch, self.dist = args, torch, dist
+        self.quantized, self.B, self.world, self.use_dist = quantized, b_local, world, use_dist
+        self.stream = stream
+        self.net = Network.load(cfg, wts, b_local, quantized, device=dev.index, fuse=not args.no_fuse)
+        self.net.set_stream(stream.cuda_stream)
+        if args.tile:
+            self.net.set_conv_tile(args.tile)
+        if args.i8_tile:
+            self.net.set_int8_tile(args.i8_tile)
+        last = self.net.layer_info(self.net.n - 1)
+        self.classes = last["classes"]
+        self.rec = torch.zeros((b_local, args.cap, 6 + self.classes), device=dev, dtype=torch.float32)
+        self.cnt = torch.zeros((b_local,), device=dev, dtype=torch.int32)
+        if use_dist:
+            # strong scaling shards may be uneven: every rank contributes max-shard rows, the tail is padding
+            self.bmax = -(-args.global_batch // world)
+            self.rec_pad = torch.zeros((self.bmax, args.cap, 6 + self.classes), device=dev, dtype=torch.float32)
+            self.cnt_pad = torch.zeros((self.bmax,), device=dev, dtype=torch.int32)
+            self.rec_all = torch.zeros((world * self.bmax, args.cap, 6 + self.classes), device=dev, dtype=torch.float32)
+            self.cnt_all = torch.zeros((world * self.bmax,), device=dev, dtype=torch.int32)
+
+    def step(self, x, slot):
+        args, torch, net = self.args, self.torch, self.net
+        with torch.cuda.stream(self.stream):
+            net.forward_timed(x.data_ptr(), slot)   # HIP events around every layer, no host sync
+            if args.nms > 0:    # get_network_boxes + do_nms_sort for every image, on the GPU
+                net.detect_batch(args.thresh, args.nms, args.cap, self.rec.data_ptr(), self.cnt.data_ptr())
+            else:
+                net.compact_detections(args.thresh, args.cap, self.rec.data_ptr(), self.cnt.data_ptr())
+            if self.use_dist:
+                self.rec_pad[:self.B].copy_(self.rec, non_blocking=True)
+                self.cnt_pad[:self.B].copy_(self.cnt, non_blocking=True)
+                self.dist.all_gather_into_tensor(self.rec_all, self.rec_pad)
+                self.dist.all_gather_into_tensor(self.cnt_all, self.cnt_pad)
+
+    def run(self, x, steps, warmup):
+        torch, dist = self.torch, self.dist
+        MAX_SLOTS = 64      # HIP-event timing slots: one per timed step (wraps beyond 64 steps)
+        for _ in range(warmup):
+            self.step(x, 0)
+        if self.use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            self.step(x, k % MAX_SLOTS)
+        torch.cuda.synchronize()
+        if self.use_dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        n_slots = min(steps, MAX_SLOTS)
+        layer_ms = np.zeros(self.net.n, dtype=np.float64)
+        for sl in range(n_slots):
+            ms, _ = self.net.layer_times(sl)
+            layer_ms[:] += ms
+        self.layer_ms = layer_ms / n_slots           # per step
+        if self.use_dist:
+            t = torch.tensor([elapsed], device=x.device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
+    def kernels(self):
+        """per kernel instance: launches, ms per step, algorithmic + executed flops, algorithmic bytes"""
+        net, B = self.net, self.B
+        kern = {}
+        for i, li in enumerate(net.layers()):
+            if li["type"] != 0:
+                continue
+            name = net.layer_kernel(i)
+            flops = 2.0 * li["n"] * li["size"] ** 2 * li["c"] * li["out_h"] * li["out_w"] * B
+            rd, wr = net.layer_traffic(i)
+            k = kern.setdefault(name, {"flops": 0.0, "exec_flops": 0.0, "bytes": 0.0, "ms": 0.0, "launches": 0})
+            k["flops"] += flops
+            k["exec_flops"] += wino_executed_flops(li, B) if "wino" in name else flops
+            k["bytes"] += rd + wr
+            k["ms"] += float(self.layer_ms[i])
+            k["launches"] += 1
+        return kern
+
+    def post_ms(self, reps=5):
+        torch = self.torch
+        args = self.args
+        with torch.cuda.stream(self.stream):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(self.stream)
+            for _ in range(reps):
+                if args.nms > 0:
+                    self.net.detect_batch(args.thresh, args.nms, args.cap, self.rec.data_ptr(), self.cnt.data_ptr())
+                else:
+                    self.net.compact_detections(args.thresh, args.cap, self.rec.data_ptr(), self.cnt.data_ptr())
+            e1.record(self.stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    def rows(self):
+        """detections of this rank's images on the host (after a step)"""
+        self.torch.cuda.synchronize()
+        rows, _ = self.net.get_boxes_batch(self.args.thresh, self.args.nms if self.args.nms > 0 else 0.4, cap=self.args.cap)
+        return rows
+
+    def close(self):
+        self.net.close()
+        self.rec = self.cnt = None
+        if self.use_dist:
+            self.rec_pad = self.cnt_pad = self.rec_all = self.cnt_all = None
+        self.torch.cuda.empty_cache()
+
+
+def fp32_roofline(leg, args):
+    kern = leg.kernels()
+    dom_name = max(kern, key=lambda n: kern[n]["flops"])
+    dom = kern[dom_name]
+    sec = dom["ms"] * 1e-3
+    executed = dom["exec_flops"] / sec / 1e12 if sec > 0 else 0.0
+    algorithmic = dom["flops"] / sec / 1e12 if sec > 0 else 0.0
+    conv_ms = sum(k["ms"] for k in kern.values())
+    conv_flops = sum(k["flops"] for k in kern.values())
+    conv_exec = sum(k["exec_flops"] for k in kern.values())
+    traffic = None
+    try:
+        if args.model == "yolov3" and args.size == 608 and leg.B == 64:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pt = json.load(f).get(dom_name)
+            if pt:
+                traffic = (2.0 * pt["fetch_kib"] + pt["write_kib"]) * 1024.0
+    except (OSError, ValueError):
+        traffic = None
+    n = max(dom["launches"], 1)
+    return {
+        "bound": "mfma", "kernel": dom_name,
+        "achieved": executed, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": executed / FP32_MATRIX_PEAK_TFLOPS,
+        "achieved_is": "executed MFMA FLOPs (Winograd: 16 multiplies per 2x2 tile incl. tile padding) / measured launch time",
+        "algorithmic_tflops": algorithmic,                      # 2*M*K*N per launch / the same time (SURVEY 8d)
+        "algorithmic_speedup": dom["flops"] / dom["exec_flops"] if dom["exec_flops"] else None,
+        "traffic": traffic,
+        "traffic_source": "committed rocprofv3 PMC passes (profiles/pmc_traffic.json), not collected in this run",
+        "algorithmic_bytes_per_launch": dom["bytes"] / n,
+        "algorithmic_flops_per_launch": dom["flops"] / n, "executed_flops_per_launch": dom["exec_flops"] / n,
+        "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / n,
+        "all_conv_algorithmic_tflops": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
+        "all_conv_executed_tflops": conv_exec / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
+        "all_conv_executed_frac": (conv_exec / (conv_ms * 1e-3) / 1e12) / FP32_MATRIX_PEAK_TFLOPS if conv_ms > 0 else 0.0,
+        "conv_ms_per_step": conv_ms, "other_layers_ms_per_step": float(leg.layer_ms.sum() - conv_ms),
+        "by_kernel": {nm: {"executed_tflops": (k["exec_flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0),
+                           "algorithmic_tflops": (k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0),
+                           "algorithmic_gbs": (k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0),
+                           "ms_per_step": k["ms"], "launches": k["launches"]} for nm, k in kern.items()},
+    }
+
+
+def int8_roofline(leg):
+    kern = leg.kernels()
+    i8 = {n: k for n, k in kern.items() if n.startswith("conv_i8")}
+    if not i8:
+        return None
+    dom_name = max(i8, key=lambda n: i8[n]["ms"])
+    dom = i8[dom_name]
+    sec = dom["ms"] * 1e-3
+    n = max(dom["launches"], 1)
+    gbs = dom["bytes"] / sec / 1e9 if sec > 0 else 0.0
+    tops = dom["flops"] / sec / 1e12 if sec > 0 else 0.0
+    tot_ms = sum(k["ms"] for k in i8.values())
+    tot_bytes = sum(k["bytes"] for k in i8.values())
+    tot_ops = sum(k["flops"] for k in i8.values())
+    return {
+        "bound": "hbm", "kernel": dom_name,
+        "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+        "achieved_is": "algorithmic bytes (int8 in, weights, FP32 [shortcut] operand in / sum out, int8 side output; "
+                       "yl_network_layer_traffic) of the kernel's launches / their measured duration",
+        "traffic": None, "traffic_source": "see profiles/r2_pmc_int8_*.txt (own rocprofv3 passes)",
+        "mfma_tops": tops, "mfma_peak_tops": INT8_MFMA_PEAK_TOPS, "mfma_frac": tops / INT8_MFMA_PEAK_TOPS,
+        "algorithmic_bytes_per_launch": dom["bytes"] / n, "launches_per_step": dom["launches"],
+        "avg_launch_ms": dom["ms"] / n,
+        "all_int8_conv_gbs": tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0,
+        "all_int8_conv_tops": tot_ops / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0,
+        "int8_conv_ms_per_step": tot_ms, "other_ms_per_step": float(leg.layer_ms.sum() - tot_ms),
+        "by_kernel": {nm: {"algorithmic_gbs": (k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0),
+                           "tops": (k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0),
+                           "ms_per_step": k["ms"], "launches": k["launches"]} for nm, k in kern.items()},
+    }
+
+
+def xnor_roofline(leg):
+    kern = leg.kernels()
+    xn = {n: k for n, k in kern.items() if n.startswith("conv_xnor")}
+    if not xn:
+        return None
+    dom_name = max(xn, key=lambda n: xn[n]["ms"])
+    dom = xn[dom_name]
+    sec = dom["ms"] * 1e-3
+    gbs = dom["bytes"] / sec / 1e9 if sec > 0 else 0.0
+    tbm = dom["flops"] / 2 / sec / 1e12 if sec > 0 else 0.0
+    return {
+        "bound": "hbm", "kernel": dom_name, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": gbs / HBM_PEAK_GBS,
+        "achieved_is": "algorithmic bytes (FP32 in, sign words written + read, FP32 out) / measured duration of the "
+                       "sign-pack + bit-conv launches",
+        "valu_tbitmac_per_s": tbm, "valu_peak_tbitmac_per_s": VALU_POPC_PEAK_TBITMAC, "valu_frac": tbm / VALU_POPC_PEAK_TBITMAC,
+        "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
+        "traffic": None,
+    }
+
+
+def pcie_inclusive(net, torch, stream, args, B, rec, cnt, steps: int = 3):
     """Host-to-host rate of the same workload (reported next to `value`, never as `value`):
     (a) decoder-style input: B u8 768x576x3 frames in pageable host memory per step ->
         yl_network_set_input_u8 (pinned staging, H2D, GPU /255 + resize_image) -> forward ->
@@ -133,7 +433,6 @@ def pcie_inclusive(net, torch, stream, args, rec, cnt, steps: int = 3):
         pipelined on one stream, one sync at the end;
     (b) the reference's own boundary: yl_network_predict(float CHW host images), which also
         brings the head tensors back (what network_predict_cpu leaves in l.output)."""
-    B = args.batch
     rng = np.random.default_rng(7)
     frames = [rng.integers(0, 256, size=(576, 768, 3), dtype=np.uint8) for _ in range(8)]
     rec_h = torch.empty(rec.shape, dtype=rec.dtype).pin_memory()
@@ -172,6 +471,63 @@ def pcie_inclusive(net, torch, stream, args, rec, cnt, steps: int = 3):
     }
 
 
+def batch_sweep(args, torch, dev, stream, Network, cfg, wts, x, batches=(8, 16, 32), steps=4):
+    """FP32 step rate of one GPU at the per-rank batch of a strong-scaled 8/4/2-GPU run"""
+    out = {}
+    for b in batches:
+        if b >= x.shape[0]:
+            continue
+        net = Network.load(cfg, wts, b, 0, device=dev.index, fuse=not args.no_fuse)
+        net.set_stream(stream.cuda_stream)
+        classes = net.layer_info(net.n - 1)["classes"]
+        rec = torch.zeros((b, args.cap, 6 + classes), device=dev, dtype=torch.float32)
+        cnt = torch.zeros((b,), device=dev, dtype=torch.int32)
+        xb = x[:b].contiguous()
+
+        def one():
+            with torch.cuda.stream(stream):
+                net.forward_device(xb.data_ptr())
+                net.detect_batch(args.thresh, args.nms if args.nms > 0 else 0.4, args.cap, rec.data_ptr(), cnt.data_ptr())
+        one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / steps
+        out[str(b)] = {"images_per_sec": b / t, "ms_per_step": t * 1e3,
+                       "predicted_node_images_per_sec_at_%d_gpus" % (x.shape[0] // b): (x.shape[0] // b) * b / t}
+        net.close()
+    return out
+
+
+def group_leg(args, torch, dev, Network, cfg, wts, x, steps=4):
+    """the step through yl_group_* (single process, RCCL send/recv gather) on this process's GPU"""
+    from yolo2_light_amd import parallel
+    B = x.shape[0]
+    model = Network.load(cfg, wts, B, 0, fuse=not args.no_fuse)
+    grp = parallel.Group(model, [dev.index])
+    model.close()
+    rec = torch.zeros((B, args.cap, 6 + grp.classes), device=dev, dtype=torch.float32)
+    cnt = torch.zeros((B,), device=dev, dtype=torch.int32)
+
+    def one():
+        grp.forward([x.data_ptr()])
+        grp.detect_batch(args.thresh, args.nms if args.nms > 0 else 0.4, args.cap, rec.data_ptr(), cnt.data_ptr())
+    torch.cuda.synchronize()
+    one()
+    grp.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    grp.synchronize()
+    t = (time.perf_counter() - t0) / steps
+    dets = int(cnt.sum().item())
+    grp.close()
+    return {"value": B / t, "unit": "images/sec", "ms_per_step": t * 1e3, "devices": 1, "detections": dets,
+            "what": "yl_group_forward + yl_group_detect_batch (ncclSend/ncclRecv gather to the root) on 1 device"}
+
+
 def main():
     args = parse_args()
     import torch
@@ -192,192 +548,148 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from yolo2_light_amd import Network, weights, zoo
-    from yolo2_light_amd._lib import lib
+    from yolo2_light_amd import Network, parallel, weights, zoo
 
-    quantized = 1 if args.mode == "int8" else 0
+    if args.scaling == "strong":
+        args.global_batch = args.batch
+        lo, hi = parallel.shard_range(args.global_batch, rank, world)
+        b_local = hi - lo
+        if b_local < 1:
+            raise SystemExit("global batch %d is smaller than the number of GPUs" % args.batch)
+    else:
+        args.global_batch = args.batch * world
+        lo, b_local = rank * args.batch, args.batch
+
     work = tempfile.mkdtemp(prefix="yl_bench_r%d_" % rank)
     cfg = zoo.write_cfg(args.model, work, args.size, args.size)
     wts = os.path.join(work, "synthetic.weights")
     with open(cfg) as f:
-        weights.write_synthetic_weights(f.read(), wts, seed=1)
+        cfg_text = f.read()
+    weights.write_synthetic_weights(cfg_text, wts, seed=1)
     if not args.raw_head:
-        with open(cfg) as f:
-            cfg_text = f.read()
-        deltas = calibrate_head(Network, cfg, wts, args.size, local_rank, args.thresh, quantized)
+        deltas = calibrate_head(Network, cfg, wts, args.size, local_rank, args.thresh)
         if deltas:
             weights.write_synthetic_weights(cfg_text, wts, seed=1, head_bias_delta=deltas)
-    net = Network.load(cfg, wts, args.batch, quantized, device=local_rank, fuse=not args.no_fuse)
+    xnor_model = args.model == "tiny-yolo-xnor"
+    do_fp32 = args.mode in ("both", "fp32")
+    do_int8 = args.mode in ("both", "int8") and not xnor_model
+    cfg_q = cfg
+    if do_int8 and not args.no_extras:
+        try:
+            cfg_q = recalibrate_int8(Network, cfg, wts, args.size, local_rank)
+        except Exception as ex:          # the shipped list still runs
+            print("recalibration failed: %r" % (ex,), file=sys.stderr)
+
     # one explicit (non-default) HIP stream shared by our kernels and torch/RCCL so the
     # compaction -> all-gather dependency is ordinary stream order
     stream = torch.cuda.Stream(device=dev)
-    net.set_stream(stream.cuda_stream)
-    if args.tile:
-        net.set_conv_tile(args.tile)
-    if args.i8_tile:
-        net.set_int8_tile(args.i8_tile)
-
-    B = args.batch
     gen = torch.Generator(device=dev)
-    gen.manual_seed(2222222 + rank)
-    x = torch.rand((B, 3, args.size, args.size), generator=gen, device=dev, dtype=torch.float32)
-    last = net.layer_info(net.n - 1)
-    classes = last["classes"]
-    rec = torch.zeros((B, args.cap, 6 + classes), device=dev, dtype=torch.float32)
-    cnt = torch.zeros((B,), device=dev, dtype=torch.int32)
-    if use_dist:
-        rec_all = torch.zeros((world * B, args.cap, 6 + classes), device=dev, dtype=torch.float32)
-        cnt_all = torch.zeros((world * B,), device=dev, dtype=torch.int32)
+    if args.scaling == "strong":
+        gen.manual_seed(2222222)         # the same global image set for every world size
+        x_all = torch.rand((args.global_batch, 3, args.size, args.size), generator=gen, device=dev, dtype=torch.float32)
+        x = x_all[lo:lo + b_local].contiguous() if world > 1 else x_all
+        del x_all
+    else:
+        gen.manual_seed(2222222 + rank)
+        x = torch.rand((b_local, 3, args.size, args.size), generator=gen, device=dev, dtype=torch.float32)
+    torch.cuda.empty_cache()
 
-    n_layers = net.n
-    layer_ms = np.zeros(n_layers, dtype=np.float64)
-
-    MAX_SLOTS = 64      # HIP-event timing slots: one per timed step (wraps beyond 64 steps)
-
-    def step(slot: int):
-        with torch.cuda.stream(stream):
-            net.forward_timed(x.data_ptr(), slot)   # HIP events around every layer, no host sync
-            if args.nms > 0:    # get_network_boxes + do_nms_sort for every image, on the GPU
-                net.detect_batch(args.thresh, args.nms, args.cap, rec.data_ptr(), cnt.data_ptr())
+    result = {}
+    rows_fp32 = None
+    for quantized in ([0] if do_fp32 else []) + ([1] if do_int8 else []):
+        leg = Leg(args, torch, dist, dev, stream, Network, cfg_q if quantized else cfg, wts, quantized, b_local,
+                  world, use_dist)
+        elapsed = leg.run(x, args.steps, args.warmup)
+        info = {"value": args.global_batch * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3}
+        if rank == 0:
+            det_counts = leg.cnt.cpu().numpy()
+            info["detections_per_image"] = {"mean": float(det_counts.mean()), "max": int(det_counts.max())}
+            info["detect_ms_per_step"] = leg.post_ms()
+            if xnor_model:
+                info["roofline"] = xnor_roofline(leg)
+            elif quantized:
+                info["roofline"] = int8_roofline(leg)
             else:
-                net.compact_detections(args.thresh, args.cap, rec.data_ptr(), cnt.data_ptr())
-            if use_dist:
-                dist.all_gather_into_tensor(rec_all, rec)
-                dist.all_gather_into_tensor(cnt_all, cnt)
-
-    for _ in range(args.warmup):
-        step(0)
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k % MAX_SLOTS)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    # per-kernel durations measured inside the timed region (read after it ended)
-    n_slots = min(args.steps, MAX_SLOTS)
-    for sl in range(n_slots):
-        ms, _ = net.layer_times(sl)
-        layer_ms[:] += ms
-    layer_ms *= args.steps / n_slots        # layer_ms holds the sum over all timed steps
-    if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---------------- roofline of the dominant kernel (rank-local measurement) -------------
-    infos = net.layers()
-    kern = {}
-    for i, li in enumerate(infos):
-        if li["type"] != 0:
-            continue
-        name = net.layer_kernel(i)
-        flops = 2.0 * li["n"] * li["size"] ** 2 * li["c"] * li["out_h"] * li["out_w"] * B
-        k = kern.setdefault(name, {"flops": 0.0, "ms": 0.0, "launches": 0})
-        k["flops"] += flops
-        k["ms"] += layer_ms[i] / args.steps
-        k["launches"] += 1
-    dom_name = max(kern, key=lambda n: kern[n]["flops"])
-    dom = kern[dom_name]
-    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-    conv_ms = sum(k["ms"] for k in kern.values())
-    conv_flops = sum(k["flops"] for k in kern.values())
-    other_ms = float(layer_ms.sum() / args.steps - conv_ms)
-    # HBM traffic of the dominant kernel: PMC counters need their own rocprofv3 passes (they
-    # serialise kernels), so the per-launch figure comes from the committed summary of those
-    # passes for this exact workload (profiles/pmc_traffic.json), null for any other workload
-    traffic = None
-    algo_bytes = None
-    try:
-        if args.model == "yolov3" and args.size == 608 and B == 64 and args.mode == "fp32":
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pt = json.load(f).get(dom_name)
-            if pt:
-                traffic = (2.0 * pt["fetch_kib"] + pt["write_kib"]) * 1024.0
-    except (OSError, ValueError):
-        traffic = None
-    # algorithmic bytes per launch of the dominant kernel: input + weights read once, output written once
-    ab = 0.0
-    for i, li in enumerate(infos):
-        if li["type"] == 0 and net.layer_kernel(i) == dom_name:
-            ab += 4.0 * (B * li["c"] * li["h"] * li["w"] + li["n"] * li["c"] * li["size"] ** 2
-                         + B * li["n"] * li["out_h"] * li["out_w"])
-    algo_bytes = ab / max(dom["launches"], 1)
-    # post-processing stage on its own (after the timed region): HIP events on the same stream
-    det_counts = cnt.cpu().numpy()
-    with torch.cuda.stream(stream):
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(5):
-            if args.nms > 0:
-                net.detect_batch(args.thresh, args.nms, args.cap, rec.data_ptr(), cnt.data_ptr())
-            else:
-                net.compact_detections(args.thresh, args.cap, rec.data_ptr(), cnt.data_ptr())
-        e1.record(stream)
-    torch.cuda.synchronize()
-    detect_ms = e0.elapsed_time(e1) / 5
-    roofline = {
-        "bound": "mfma", "kernel": dom_name,
-        "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
-        "traffic": traffic, "traffic_unit": "bytes/launch (PMC, separate passes)",
-        "algorithmic_bytes_per_launch": algo_bytes,
-        "algorithmic_flops_per_launch": dom["flops"] / max(dom["launches"], 1),
-        "launches_per_step": dom["launches"],
-        "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
-        "all_conv_tflops": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
-        "conv_ms_per_step": conv_ms, "other_layers_ms_per_step": other_ms,
-        # Winograd F(2x2,3x3) issues 16 multiplies per 2x2 output tile instead of 36: `achieved`
-        # stays the ALGORITHMIC rate (2*M*K*N per launch / duration) and can exceed the
-        # matrix peak; `issued_mfma_tflops` is what the MFMA pipe actually executed
-        "issued_mfma_tflops": (achieved / 2.25 if "wino" in dom_name else achieved),
-        "detect_ms_per_step": detect_ms,
-        "detections_per_image": {"mean": float(det_counts.mean()), "max": int(det_counts.max())},
-        "by_kernel": {n: {"tflops": (k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0),
-                          "ms_per_step": k["ms"], "launches": k["launches"]} for n, k in kern.items()},
-    }
+                info["roofline"] = fp32_roofline(leg, args)
+            info["gflop_per_image"] = leg.net.flops_per_image / 1e9
+            if args.layers:
+                for i, li in enumerate(leg.net.layers()):
+                    print("%3d type=%2d %-28s %8.3f ms" % (i, li["type"], leg.net.layer_kernel(i), leg.layer_ms[i]),
+                          file=sys.stderr)
+            if world == 1 and not args.no_extras:
+                try:
+                    rows = leg.rows()
+                    if quantized and rows_fp32 is not None:
+                        info["agreement_vs_fp32"] = detection_agreement(rows_fp32, rows)
+                        info["agreement_vs_fp32"]["input_calibration"] = (
+                            "recomputed for the synthetic weights with yl_network_calibrate (4 synthetic images)"
+                            if cfg_q != cfg else "the cfg's shipped list")
+                    elif not quantized:
+                        rows_fp32 = rows
+                except Exception as ex:
+                    info["agreement_vs_fp32"] = {"error": repr(ex)}
+            if not quantized and world == 1 and not args.no_e2e:
+                try:
+                    info["pcie_inclusive"] = pcie_inclusive(leg.net, torch, stream, args, b_local, leg.rec, leg.cnt)
+                except Exception as ex:      # the headline number must not depend on this leg
+                    info["pcie_inclusive"] = {"error": repr(ex)}
+        result["int8" if quantized else "fp32"] = info
+        leg.close()
 
     if rank == 0:
-        if args.layers:
-            for i, li in enumerate(infos):
-                print("%3d type=%2d %-28s %8.3f ms" % (i, li["type"], net.layer_kernel(i), layer_ms[i] / args.steps),
-                      file=sys.stderr)
-        cpu = None
-        e2e = None
-        if world == 1 and not args.no_e2e:
+        extras = {}
+        if world == 1 and not args.no_extras and do_fp32 and not xnor_model:
             try:
-                e2e = pcie_inclusive(net, torch, stream, args, rec, cnt)
-            except Exception as ex:      # the headline number must not depend on this leg
-                e2e = {"error": repr(ex)}
+                extras["batch_sweep"] = batch_sweep(args, torch, dev, stream, Network, cfg, wts, x)
+            except Exception as ex:
+                extras["batch_sweep"] = {"error": repr(ex)}
+            try:
+                extras["group_n1"] = group_leg(args, torch, dev, Network, cfg, wts, x)
+            except Exception as ex:
+                extras["group_n1"] = {"error": repr(ex)}
+        cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
-                cpu = cpu_baseline(cfg, wts, args.size, args.size, quantized, args.cpu_seconds)
+                cpu = cpu_baseline(cfg, wts, args.size, args.size, 0 if do_fp32 else 1, args.cpu_seconds)
+                if cpu and do_fp32 and do_int8:
+                    q = cpu_baseline(cfg_q, wts, args.size, args.size, 1, args.cpu_seconds / 2)
+                    if q:
+                        cpu["int8"] = {k: q[k] for k in ("value", "sample")}
             except Exception as e:      # the baseline is reported, never required
                 cpu = {"error": repr(e)}
-        total_images = world * B * args.steps
+        head = result["fp32"] if do_fp32 else result["int8"]
+        dtype = "f32" if do_fp32 else "i8"
+        modes = ("FP32" if do_fp32 else "") + (" & INT8" if do_fp32 and do_int8 else ("INT8" if do_int8 else ""))
         out = {
-            "metric": "images/sec (whole node) %s %dx%d batch %d %s" % (args.model, args.size, args.size, B,
-                                                                       args.mode.upper()),
-            "value": total_images / elapsed,
+            "metric": "images/sec (whole node) %s %dx%d batch %d %s" % (args.model, args.size, args.size,
+                                                                       args.global_batch, modes),
+            "value": head["value"],
             "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.mode == "fp32" else "i8", "data": "synthetic",
-            "config": {"workload": "%s.cfg %dx%d batch=%d/GPU %s, synthetic weights+images resident in HBM, "
-                                   "forward + on-device detection decode/compaction + NMS%s" % (
-                                       args.model, args.size, args.size, B, args.mode.upper(),
-                                       " + RCCL all-gather of detections" if use_dist else ""),
-                       "global_batch": world * B, "parallelism": "image-batch sharding x%d" % world,
-                       "gflop_per_image": net.flops_per_image / 1e9},
-            "roofline": roofline,
+            "ms_per_step": head["ms_per_step"],
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": dtype, "data": "synthetic",
+            "config": {"workload": "%s.cfg %dx%d global batch=%d (%d/GPU) %s, synthetic weights+images resident in "
+                                   "HBM, forward + on-device detection decode/compaction + NMS%s; `value` = the %s leg" % (
+                                       args.model, args.size, args.size, args.global_batch, b_local, modes,
+                                       " + RCCL all-gather of detections" if use_dist else "",
+                                       "FP32" if do_fp32 else "INT8"),
+                       "global_batch": args.global_batch,
+                       "parallelism": "image-batch sharding x%d (%s scaling)" % (world, args.scaling),
+                       "gflop_per_image": head.get("gflop_per_image")},
+            "roofline": head.get("roofline"),
+            "detect_ms_per_step": head.get("detect_ms_per_step"),
+            "detections_per_image": head.get("detections_per_image"),
             "cpu_baseline": cpu,
-            "pcie_inclusive": e2e,
+            "pcie_inclusive": head.get("pcie_inclusive"),
         }
+        if do_fp32 and do_int8:
+            i8 = result["int8"]
+            out["int8"] = {k: i8.get(k) for k in ("value", "ms_per_step", "roofline", "agreement_vs_fp32",
+                                                  "detections_per_image", "detect_ms_per_step")}
+            out["int8"]["unit"] = "images/sec"
+            out["int8"]["speedup_vs_fp32"] = i8["value"] / head["value"]
+        out.update(extras)
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

@@ -149,6 +149,10 @@ const int8_t *yl_network_layer_weights_int8(const yl_network *net, int i);
 const float  *yl_network_layer_mean_arr(const yl_network *net, int i);
 /* mult[2] = {input_quant_multipler, weights_quant_multipler} */
 int yl_network_layer_quant_multipliers(const yl_network *net, int i, float *mult);
+/* ALGORITHMIC HBM bytes layer i's kernels move per forward of the whole batch under the current fusion plan
+ * (after yl_network_to_device): bytes[0] read, bytes[1] written -- every operand once, in the form it is stored
+ * (FP32 NCHW, int8 NC/16HW16, sign words); what bench.py's roofline divides by the measured launch time */
+int yl_network_layer_traffic(const yl_network *net, int i, double *bytes);
 /* per-image FLOPs of the conv layers: sum 2*n*size^2*c*out_h*out_w (src/additionally.c:2903) */
 double yl_network_flops_per_image(const yl_network *net);
 
@@ -349,6 +353,47 @@ int yl_network_calibrate(yl_network *net, const float *images_host, int n_images
                          float *multipliers, int max_out);
 /* the KL scan alone, from an exact histogram counts[max_bin] of lround(|x| / bin_width) (host only) */
 float yl_entropy_from_histogram(const uint32_t *counts, int max_bin, float bin_width);
+
+/* ------------------------------------------------------------------ *
+ *  Several GPUs of one node, ONE host process (new).  The reference selects a single
+ *  device (`-i <n>` -> cuda_set_device, src/main.c:653-661) and hands network_predict the whole batch;
+ *  a group splits that batch of independent images over the listed devices (weights replicated, one
+ *  host thread + HIP stream per device, no data-path collective in the forward pass) and gathers the
+ *  fixed-capacity detection records on devices[0] with RCCL (ncclSend/ncclRecv over xGMI).
+ * ------------------------------------------------------------------ */
+typedef struct yl_group yl_group;
+
+/* image range [first, first+count) of `rank` when global_batch images are split over n ranks: the first
+ * global_batch % n ranks take one image more (host only) */
+int yl_shard_range(int global_batch, int n, int rank, int *first, int *count);
+
+/* `model`: a prepared HOST network (after load/fuse/quantise and any yl_network_set_* knob, NOT on a device)
+ * whose batch is the GLOBAL batch; one replica per device is built and uploaded (in parallel).  The model may
+ * be destroyed afterwards; host `output` pointers given through yl_layer_desc must stay valid (the replicas
+ * write their slices of the heads into them).  devices[0] is the root of the gather. */
+int yl_group_create(const yl_network *model, const int *devices, int n_devices, yl_group **out);
+void yl_group_destroy(yl_group *g);
+int yl_group_size(const yl_group *g);
+int yl_group_shard(const yl_group *g, int rank, int *first, int *count);
+/* borrowed replica of `rank` (introspection, yl_network_set_input_u8, per-layer readback, timing) */
+yl_network *yl_group_member(yl_group *g, int rank);
+
+/* network_predict contract on the global batch (see yl_network_predict): `input` = host
+ * float[global_batch*c*h*w]; every rank stages, runs and pulls its shard concurrently; returns the host
+ * pointer of the last layer's output for the global batch, NULL on failure. */
+float *yl_group_predict(yl_group *g, const float *input);
+/* asynchronous forward of every shard; inputs_dev[rank] = device pointer ON that rank's device, or NULL
+ * (array or entry) for the replica's own input buffer (yl_network_input_dev / yl_network_set_input_u8) */
+int yl_group_forward(yl_group *g, const float *const *inputs_dev);
+int yl_group_synchronize(yl_group *g);
+/* yl_network_detect_batch on every shard + RCCL gather: records_dev_root[global_batch][cap][6+classes] and
+ * counts_dev_root[global_batch] live on devices[0]; img_w/img_h: host int[global_batch] or NULL.  Asynchronous;
+ * the root replica's stream orders the result (yl_network_synchronize(yl_group_member(g, 0))). */
+int yl_group_detect_batch(yl_group *g, const int *img_w, const int *img_h, float thresh, int relative, int letter,
+                          float nms, int cap, float *records_dev_root, int *counts_dev_root);
+/* the same, delivered to host buffers (synchronous; only the filled rows are copied) */
+int yl_group_get_boxes_batch(yl_group *g, const int *img_w, const int *img_h, float thresh, int relative, int letter,
+                             float nms, int cap, float *rows_host, int *counts_host);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,12 @@
  *   - `-quantized` follows net.quantized, XNOR follows l.xnor, using the weights the host
  *     prepared in main.c:160-171 (fused BN, weights_int8 + multipliers, mean_arr).
  * Errors follow the reference convention: error() = perror + exit (src/additionally.c:1595).
+ *
+ * Several GPUs: the reference's CLI selects one device with `-i <n>` (gpu_index, src/main.c:653-661).
+ * With the environment variable YL_GPUS set ("all", or a comma list such as "0,1,2,3") the SAME call
+ * splits net.batch over those devices of the node (yl_group_*: one host thread + stream per device,
+ * weights replicated) -- l.output of every YOLO/REGION layer and the returned pointer cover the whole
+ * batch exactly as on one device, so get_network_boxes / do_nms_sort still run unchanged.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -31,7 +37,8 @@ extern int gpu_index;            /* src/additionally.c:22; -i <n> selects the de
 void error(const char *s);       /* src/additionally.c:1595 */
 
 static yl_network *g_hip_net = NULL;
-static layer *g_hip_owner = NULL;       /* the network whose device image g_hip_net holds */
+static yl_group *g_hip_group = NULL;    /* set instead of a device image of g_hip_net when YL_GPUS is given */
+static layer *g_hip_owner = NULL;       /* the network whose device image g_hip_net / g_hip_group holds */
 
 static void hip_fail(const char *what)
 {
@@ -79,19 +86,34 @@ static yl_network *hip_build(network *net)
     free(d);
     /* conv+[shortcut] epilogue fusion and quantise-on-store: bit-identical head tensors, fewer kernels */
     if (yl_network_set_fusion(h, 1) != YL_OK) hip_fail("yl_network_set_fusion");
+    {
+        const char *gpus = getenv("YL_GPUS");
+        int devs[64], n = 0;
+        if (gpus && *gpus) {
+            if (!strcmp(gpus, "all")) { for (n = 0; n < yl_device_count() && n < 64; ++n) devs[n] = n; }
+            else { const char *p = gpus; while (*p && n < 64) { devs[n++] = atoi(p); p = strchr(p, ','); if (!p) break; ++p; } }
+            if (n > net->batch) n = net->batch;          /* at least one image per device */
+        }
+        if (n > 1) {
+            if (yl_group_create(h, devs, n, &g_hip_group) != YL_OK) hip_fail("yl_group_create");
+            return h;                                    /* kept as the host model; the replicas own the devices */
+        }
+    }
     if (yl_network_to_device(h, gpu_index >= 0 ? gpu_index : 0) != YL_OK) hip_fail("yl_network_to_device");
     return h;
 }
+
+void free_network_hip(void);
 
 float *network_predict_hip(network net, float *input)
 {
     float *out;
     if (!g_hip_net || g_hip_owner != net.layers) {
-        if (g_hip_net) yl_network_destroy(g_hip_net);
+        free_network_hip();
         g_hip_net = hip_build(&net);
         g_hip_owner = net.layers;
     }
-    out = yl_network_predict(g_hip_net, input);
+    out = g_hip_group ? yl_group_predict(g_hip_group, input) : yl_network_predict(g_hip_net, input);
     if (!out) hip_fail("yl_network_predict");
     return out;
 }
@@ -99,6 +121,8 @@ float *network_predict_hip(network net, float *input)
 /* call before free_network(net) (src/additionally.c:2054) */
 void free_network_hip(void)
 {
+    if (g_hip_group) yl_group_destroy(g_hip_group);
+    g_hip_group = NULL;
     if (g_hip_net) yl_network_destroy(g_hip_net);
     g_hip_net = NULL;
     g_hip_owner = NULL;

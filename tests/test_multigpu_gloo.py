@@ -1,5 +1,5 @@
 """The N>1 path (image-batch sharding + gather of fixed-capacity detection
-records) on CPU with world_size 2 over gloo."""
+records) on CPU with world_size 2 over gloo; the group API's argument checks without a GPU."""
 import os
 import socket
 
@@ -74,3 +74,20 @@ def test_gather_detections_world2_gloo():
                 got = merged[owner * b + i]
                 assert got.shape[0] == n
                 assert np.array_equal(got, rec[i, :n])
+
+
+def test_group_without_gpu_fails_loudly():
+    """yl_group_create has no CPU fallback either; argument errors are reported before any device work"""
+    import ctypes as C
+    from yolo2_light_amd import Network, YoloHipError
+    from yolo2_light_amd._lib import lib
+    cfg, wts = common.model_files("yolov3-tiny", 96, 96)
+    model = Network.load(cfg, wts, 4, 0)
+    if lib.yl_device_count() == 0:
+        with pytest.raises(YoloHipError):
+            parallel.Group(model, [0])
+    with pytest.raises(YoloHipError):
+        parallel.Group(model, [])                       # no devices
+    f, c = C.c_int(), C.c_int()
+    assert lib.yl_shard_range(64, 8, 8, C.byref(f), C.byref(c)) != 0
+    assert lib.yl_shard_range(10, 4, 1, C.byref(f), C.byref(c)) == 0 and (f.value, c.value) == (3, 3)

@@ -33,7 +33,7 @@ if has smoke; then
 fi
 if has bench; then
   echo "== bench yolov3 608 b64 fp32" | tee -a $OUT/summary.txt
-  timeout 900 python bench.py --steps 10 --warmup 2 --layers > $OUT/bench.json 2> $OUT/bench_layers.txt
+  timeout 1200 python bench.py --steps 10 --warmup 2 --layers > $OUT/bench.json 2> $OUT/bench_layers.txt
   echo "bench exit $?" | tee -a $OUT/summary.txt
   cat $OUT/bench.json
 fi

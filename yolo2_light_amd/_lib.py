@@ -76,6 +76,7 @@ _SIGS = {
     "yl_network_layer_mean_arr": (c_float_p, [_vp, C.c_int]),
     "yl_network_layer_quant_multipliers": (C.c_int, [_vp, C.c_int, c_float_p]),
     "yl_network_flops_per_image": (C.c_double, [_vp]),
+    "yl_network_layer_traffic": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double)]),
     "yl_network_to_device": (C.c_int, [_vp, C.c_int]),
     "yl_network_set_fusion": (C.c_int, [_vp, C.c_int]),
     "yl_network_predict": (c_float_p, [_vp, c_float_p]),
@@ -113,6 +114,18 @@ _SIGS = {
     "yl_entropy_from_histogram": (C.c_float, [C.POINTER(C.c_uint32), C.c_int, C.c_float]),
     "yl_network_get_boxes_batch": (C.c_int, [_vp, c_int_p, c_int_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,
                                              c_float_p, c_int_p]),
+    "yl_shard_range": (C.c_int, [C.c_int, C.c_int, C.c_int, c_int_p, c_int_p]),
+    "yl_group_create": (C.c_int, [_vp, c_int_p, C.c_int, C.POINTER(_vp)]),
+    "yl_group_destroy": (None, [_vp]),
+    "yl_group_size": (C.c_int, [_vp]),
+    "yl_group_shard": (C.c_int, [_vp, C.c_int, c_int_p, c_int_p]),
+    "yl_group_member": (_vp, [_vp, C.c_int]),
+    "yl_group_predict": (c_float_p, [_vp, c_float_p]),
+    "yl_group_forward": (C.c_int, [_vp, C.POINTER(_vp)]),
+    "yl_group_synchronize": (C.c_int, [_vp]),
+    "yl_group_detect_batch": (C.c_int, [_vp, c_int_p, c_int_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, _vp, _vp]),
+    "yl_group_get_boxes_batch": (C.c_int, [_vp, c_int_p, c_int_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,
+                                           c_float_p, c_int_p]),
 }
 
 # every symbol include/yolo2_hip.h declares (tests/test_abi.py cross-checks against the header)

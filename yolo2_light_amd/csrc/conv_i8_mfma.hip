@@ -539,10 +539,12 @@ int launch_conv_i8(const ConvI8Args &a, int tile, void *stream, char *name, size
     hipStream_t s = (hipStream_t)stream;
     if (tile == 0) {
         auto nblocks = [&](int bm, int bn) { return (long long)((a.M + bm - 1) / bm) * ((nt + bn - 1) / bn); };
+        // measured per layer on yolov3-608 b64 (profiles/r2_i8_tile_sweep.txt): 32x256 for M = 32; 64x128 up
+        // to 64 filters; from 128 filters the 64x64 wave tile (half the LDS operand traffic per MFMA) wins on
+        // every layer, 1x1 included, while there are enough tiles to fill the chip twice
         if (a.M <= 32) tile = 2;
         else if (a.M <= 64) tile = 1;
-        // the wide wave tile pays where the K loop is long (3x3 with C >= 128) and there are enough tiles
-        else if (d.K16 >= 72 && nblocks(128, 128) >= 512) tile = 3;
+        else if (nblocks(128, 128) >= 512) tile = 3;
         else tile = 1;
     }
     if ((tile == 3 || tile == 4) && a.Mpad % 128 != 0) tile = 1;

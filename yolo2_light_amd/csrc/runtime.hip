@@ -666,6 +666,49 @@ double yl_network_flops_per_image(const yl_network *net)
     return f;
 }
 
+int yl_network_layer_traffic(const yl_network *net, int i, double *bytes)
+{
+    YL_LAYER_OR(YL_ERR_ARG)
+    if (!bytes) { set_error("null argument"); return YL_ERR_ARG; }
+    const Network &n = net->net;
+    const double B = n.batch;
+    const double in_el = B * l.inputs, out_el = B * l.outputs;
+    double rd = 0, wr = 0;
+    switch (l.type) {
+    case YL_CONVOLUTIONAL: {
+        const double wel = (double)l.n * l.c * l.size * l.size;
+        const bool fused = l.fused_shortcut >= 0;
+        if (l.conv_mode == CONV_INT8) {
+            const double q_in = B * (double)l.h * l.w * (l.Cpad ? l.Cpad : l.c);
+            if (!l.q_from_producer) { rd += 4 * in_el; wr += q_in; }      // stand-alone quantise pass
+            rd += q_in + wel;
+        } else if (l.conv_mode == CONV_XNOR) {
+            const double bits = B * (double)l.h * l.w * 8.0 * ((l.c + 63) / 64);
+            rd += 4 * in_el + bits + wel / 8;                             // sign-pack pass + bit conv
+            wr += bits;
+        } else {
+            rd += 4 * in_el + 4 * wel;
+            if (l.binarize_input) { rd += 4 * in_el; wr += 4 * in_el; }
+        }
+        if (fused) { rd += 4 * out_el; wr += 4 * out_el; }                // [shortcut] operand in, sum out
+        else if (!l.skip_f32_out) wr += 4 * out_el;
+        if (l.q_out_layer >= 0) wr += out_el;                             // int8 side output (one byte per element)
+        break;
+    }
+    case YL_SHORTCUT:
+        if (!l.fused_into_conv) { rd += 8 * out_el; wr += 4 * out_el; }
+        break;
+    case YL_ROUTE:
+        if (!l.d_output_alias && !(l.n == 1)) { rd += 4 * out_el; wr += 4 * out_el; }
+        break;
+    default:
+        rd += 4 * in_el; wr += 4 * out_el;
+        break;
+    }
+    bytes[0] = rd; bytes[1] = wr;
+    return YL_OK;
+}
+
 int yl_network_set_debug(yl_network *net, int on)
 {
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }

@@ -153,6 +153,12 @@ class Network:
         check(lib.yl_network_layer_quant_multipliers(self._h, i, m), "yl_network_layer_quant_multipliers")
         return float(m[0]), float(m[1])
 
+    def layer_traffic(self, i: int):
+        """(read, written) algorithmic HBM bytes of layer i per forward under the fusion plan"""
+        b = (C.c_double * 2)()
+        check(lib.yl_network_layer_traffic(self._h, i, b), "yl_network_layer_traffic")
+        return float(b[0]), float(b[1])
+
     @property
     def flops_per_image(self) -> float:
         return lib.yl_network_flops_per_image(self._h)
