@@ -348,3 +348,30 @@ def test_xnor_fallback_layers_teacher_forced(olib):
     common._MODEL_CACHE[("xnor-mixed", width, height, 1)] = (cfg, wts)
     stats = _teacher_forced(olib, "xnor-mixed", width, height, batch, 0)
     assert stats["exact"] >= 2
+
+
+@pytest.mark.parametrize("name,width,height,batch", [("tiny-yolo-xnor", 416, 416, 2), ("tiny-yolo-xnor", 96, 96, 3),
+                                                     ("tiny-yolo-xnor", 160, 224, 1)])
+def test_xnor_sign_domain_fusion_is_bit_identical(name, width, height, batch):
+    """yl_network_set_fusion on an XNOR network: conv(xnor) -> [maxpool] -> conv(xnor) chains hand over sign
+    words (the producer's epilogue packs (y > 0), max-pooling is the OR of the window), FP32 tensors nobody else
+    reads are not written.  Every tensor that is still materialised -- the head above all -- equals the unfused
+    run bit for bit."""
+    cfg, wts = common.model_files(name, width, height)
+    x = common.seeded_input(batch, 3, height, width)
+    plain = Network.load(cfg, wts, batch, 0, device=0)
+    fused = Network.load(cfg, wts, batch, 0, device=0, fuse=True)
+    plain.predict(x)
+    fused.predict(x)
+    skipped = checked = 0
+    for i in range(plain.n):
+        if not fused.layer_materialised(i):
+            skipped += 1
+            continue
+        a, b = plain.layer_output(i), fused.layer_output(i)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "layer %d %r" % (i, plain.layer_info(i))
+        checked += 1
+    assert skipped >= 10 and checked >= 3          # 6 xnor convs + 6 max-pools stop writing FP32
+    for b in range(batch):
+        assert np.array_equal(plain.get_boxes(b, width, height, 0.05, nms=0.4), fused.get_boxes(b, width, height, 0.05, nms=0.4))
+    plain.close(); fused.close()

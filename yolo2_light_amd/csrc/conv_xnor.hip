@@ -58,19 +58,111 @@ int launch_pack_sign_bits(const float *in, uint64_t *out, int B, int C, int H, i
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------ K3c: pooling on sign words
+// maxpool followed by an XNOR convolution only needs sign(max) = OR of the window's sign bits (the
+// reference pads max-pool windows with -FLT_MAX, src/yolov2_forward_network.c:268-300: out-of-image taps
+// never set a bit): bits_out[b][cw][oy][ox] = OR over the in-image taps of bits_in[b][cw][.][.]
+__global__ __launch_bounds__(256) void bit_maxpool_kernel(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                          size_t total, int H, int W, int OH, int OW,
+                                                          int size, int stride, int off)
+{
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % OW);
+        size_t t = idx / OW;
+        const int i = (int)(t % OH);
+        t /= OH;                                   // t = cw + Cw*b
+        const uint64_t *src = in + t * (size_t)H * W;
+        uint64_t acc = 0;
+        for (int n = 0; n < size; ++n) {
+            const int cur_h = off + i * stride + n;
+            for (int m = 0; m < size; ++m) {
+                const int cur_w = off + j * stride + m;
+                if (cur_h >= 0 && cur_h < H && cur_w >= 0 && cur_w < W) acc |= src[(size_t)cur_h * W + cur_w];
+            }
+        }
+        out[idx] = acc;
+    }
+}
+
+int launch_bit_maxpool(const uint64_t *in, uint64_t *out, int B, int Cw, int H, int W, int OH, int OW,
+                       int size, int stride, int pad, void *stream)
+{
+    const size_t total = (size_t)B * Cw * OH * OW;
+    size_t g = (total + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g == 0) g = 1;
+    hipLaunchKernelGGL(bit_maxpool_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                       in, out, total, H, W, OH, OW, size, stride, -pad / 2);
+    return (int)hipGetLastError();
+}
+
+// FP32 producer -> maxpool -> XNOR convolution: the pooled FP32 tensor is never needed, one lane takes one
+// (image, 64-channel word, output pixel) and ORs (x > 0) over its window for up to 64 channels
+__global__ __launch_bounds__(256) void maxpool_sign_pack_kernel(const float *__restrict__ in, uint64_t *__restrict__ out,
+                                                                size_t total, int C, int Cw, int H, int W, int OH, int OW,
+                                                                int size, int stride, int off)
+{
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % OW);
+        size_t t = idx / OW;
+        const int i = (int)(t % OH);
+        t /= OH;
+        const int cw = (int)(t % Cw);
+        const size_t b = t / Cw;
+        const int nc = (C - cw * 64) < 64 ? (C - cw * 64) : 64;
+        const float *src = in + (b * C + (size_t)cw * 64) * (size_t)H * W;
+        unsigned lo = 0, hi = 0;
+        for (int c = 0; c < nc; ++c) {
+            bool any = false;
+            for (int n = 0; n < size; ++n) {
+                const int cur_h = off + i * stride + n;
+                if (cur_h < 0 || cur_h >= H) continue;
+                for (int m = 0; m < size; ++m) {
+                    const int cur_w = off + j * stride + m;
+                    if (cur_w >= 0 && cur_w < W) any = any || (src[(size_t)c * H * W + (size_t)cur_h * W + cur_w] > 0.f);
+                }
+            }
+            if (c < 32) lo |= (any ? 1u : 0u) << c;
+            else hi |= (any ? 1u : 0u) << (c - 32);
+        }
+        out[idx] = ((uint64_t)hi << 32) | lo;
+    }
+}
+
+int launch_maxpool_sign_pack(const float *in, uint64_t *out, int B, int C, int Cw, int H, int W, int OH, int OW,
+                             int size, int stride, int pad, void *stream)
+{
+    const size_t total = (size_t)B * Cw * OH * OW;
+    size_t g = (total + 255) / 256;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g == 0) g = 1;
+    hipLaunchKernelGGL(maxpool_sign_pack_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                       in, out, total, C, Cw, H, W, OH, OW, size, stride, -pad / 2);
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------ K3b: XNOR + popcount conv (3x3, stride 1, pad 1)
 struct ConvXnorDev {
     const uint64_t *in_bits;
     const uint64_t *w_bits;
     const float *mean;
     const float *bias;
-    float *out;
+    float *out;               // FP32 output, or nullptr when only the sign words are wanted
+    uint64_t *out_bits;       // sign words of the activation for a following XNOR layer, or nullptr
     int32_t *dbg;
     int B, C, Cw, H, W, M, act;
+    int out_Cw;               // words per pixel of out_bits
     int Ntotal, HW;
 };
 
-template <int CWC, int FT>
+// One lane = one output pixel; the filter loop is wave-uniform, so weight words arrive by scalar loads and
+// enter v_xnor / v_bcnt as SGPR operands.  FT filters per lane (64 where the layer has them: the 9*CWC input
+// words of a channel chunk are fetched once per 64 filters, and the 64 sign bits of the result are exactly one
+// word of the next layer's input).  W32: C <= 32 -- the upper halves of the single word are padding (activation
+// bits 0, weight bits 1: never a match), so only the lower 32 bits are counted.
+template <int CWC, int FT, bool W32>
 __global__ __launch_bounds__(256) void conv_xnor_kernel(ConvXnorDev p)
 {
     const int tid = threadIdx.x;
@@ -119,10 +211,15 @@ __global__ __launch_bounds__(256) void conv_xnor_kernel(ConvXnorDev p)
 #pragma unroll
             for (int w = 0; w < CWC; ++w) {
                 const int soff = ((cw0 + w) * p.HW + ky * p.W + kx) * 8;
-                typedef unsigned v2u __attribute__((ext_vector_type(2)));
-                const v2u v = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff | tinv, soff, 0));
-                in_lo[t][w] = v[0];
-                in_hi[t][w] = v[1];
+                if (W32) {
+                    in_lo[t][w] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff | tinv, soff, 0);
+                    in_hi[t][w] = 0;
+                } else {
+                    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                    const v2u v = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff | tinv, soff, 0));
+                    in_lo[t][w] = v[0];
+                    in_hi[t][w] = v[1];
+                }
             }
         }
 #pragma unroll
@@ -136,7 +233,7 @@ __global__ __launch_bounds__(256) void conv_xnor_kernel(ConvXnorDev p)
                 for (int w = 0; w < CWC; ++w) {
                     const uint64_t ww = wf[(size_t)t * p.Cw + w];
                     c += __popc(~(in_lo[t][w] ^ (unsigned)ww));
-                    c += __popc(~(in_hi[t][w] ^ (unsigned)(ww >> 32)));
+                    if (!W32) c += __popc(~(in_hi[t][w] ^ (unsigned)(ww >> 32)));
                 }
             }
             cnt[f] = c;
@@ -146,6 +243,7 @@ __global__ __launch_bounds__(256) void conv_xnor_kernel(ConvXnorDev p)
     if (!n_ok) return;
     const int K = 9 * p.C;
     const size_t obase = (size_t)bimg * p.M * p.HW + pix;
+    unsigned sign_lo = 0, sign_hi = 0;
 #pragma unroll
     for (int f = 0; f < FT; ++f) {
         const int m = f0 + f;
@@ -155,16 +253,24 @@ __global__ __launch_bounds__(256) void conv_xnor_kernel(ConvXnorDev p)
             float v = __fmul_rn((float)(2 * cnt[f] - K), p.mean[m]);
             v = __fadd_rn(v, p.bias[m]);
             if (p.act == YL_LEAKY) v = (v > 0.f) ? v : (float)(.1 * (double)v);
-            p.out[oi] = v;
+            if (p.out) p.out[oi] = v;
+            // bit = (x > 0) of the value the next layer would read (src/additionally.c:132,1544)
+            if (f < 32) sign_lo |= (v > 0.f ? 1u : 0u) << f;
+            else sign_hi |= (v > 0.f ? 1u : 0u) << (f - 32);
         }
+    }
+    if (p.out_bits) {
+        uint64_t *dst = p.out_bits + ((size_t)bimg * p.out_Cw + (f0 >> 6)) * p.HW + pix;
+        if (FT == 64) *dst = ((uint64_t)sign_hi << 32) | sign_lo;
+        else reinterpret_cast<unsigned *>(dst)[(f0 >> 5) & 1] = sign_lo;      // 32 filters per lane: half a word
     }
 }
 
-template <int CWC, int FT>
+template <int CWC, int FT, bool W32>
 static int launch_xnor(const ConvXnorDev &d, hipStream_t s)
 {
     dim3 grid((unsigned)((d.Ntotal + 255) / 256), (unsigned)((d.M + FT - 1) / FT));
-    hipLaunchKernelGGL((conv_xnor_kernel<CWC, FT>), grid, dim3(256), 0, s, d);
+    hipLaunchKernelGGL((conv_xnor_kernel<CWC, FT, W32>), grid, dim3(256), 0, s, d);
     return (int)hipGetLastError();
 }
 
@@ -172,6 +278,7 @@ int launch_conv_xnor(const ConvXnorArgs &a, void *stream)
 {
     ConvXnorDev d;
     d.in_bits = a.in_bits; d.w_bits = a.w_bits; d.mean = a.mean; d.bias = a.bias; d.out = a.out; d.dbg = a.dbg;
+    d.out_bits = a.out_bits; d.out_Cw = (a.M + 63) / 64;
     d.B = a.B; d.C = a.C; d.Cw = a.Cw; d.H = a.H; d.W = a.W; d.M = a.M; d.act = a.act;
     d.HW = a.H * a.W;
     const long long nt = (long long)a.B * d.HW;
@@ -179,9 +286,14 @@ int launch_conv_xnor(const ConvXnorArgs &a, void *stream)
     d.Ntotal = (int)nt;
     hipStream_t s = (hipStream_t)stream;
     // weights are padded to a multiple of 64 filters (runtime.hip), FT must divide that
-    if (a.Cw % 4 == 0) return launch_xnor<4, 16>(d, s);
-    if (a.Cw % 2 == 0) return launch_xnor<2, 32>(d, s);
-    return launch_xnor<1, 32>(d, s);
+    if (a.C <= 32) return (a.M >= 64) ? launch_xnor<1, 64, true>(d, s) : launch_xnor<1, 32, true>(d, s);
+    if (a.M >= 64) {
+        if (a.Cw % 4 == 0) return launch_xnor<4, 64, false>(d, s);
+        if (a.Cw % 2 == 0) return launch_xnor<2, 64, false>(d, s);
+        return launch_xnor<1, 64, false>(d, s);
+    }
+    if (a.Cw % 2 == 0) return launch_xnor<2, 32, false>(d, s);
+    return launch_xnor<1, 32, false>(d, s);
 }
 
 }  // namespace yl

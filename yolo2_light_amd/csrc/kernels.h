@@ -70,12 +70,18 @@ struct ConvXnorArgs {
     const uint64_t *w_bits;   // [Mpad][9][Cw], channel-pad bits = 1
     const float *mean;        // [M]
     const float *bias;        // [M]
-    float *out;               // [B][M][H][W]
+    float *out;               // [B][M][H][W], or nullptr when only out_bits is wanted
+    uint64_t *out_bits = nullptr;   // optional sign words of the result for a following XNOR layer: [B][ceil(M/64)][H][W]
     int32_t *dbg;             // optional match counts
     int B, C, Cw, H, W, M, Mpad;
     int act;
 };
 int launch_conv_xnor(const ConvXnorArgs &a, void *stream);
+// K3c: max-pooling in the sign domain (OR of the window's sign words), and FP32 -> pooled sign words in one pass
+int launch_bit_maxpool(const uint64_t *in, uint64_t *out, int B, int Cw, int H, int W, int OH, int OW,
+                       int size, int stride, int pad, void *stream);
+int launch_maxpool_sign_pack(const float *in, uint64_t *out, int B, int C, int Cw, int H, int W, int OH, int OW,
+                             int size, int stride, int pad, void *stream);
 
 // ---- K4..K9: small coalesced layers ----
 int launch_maxpool(const float *in, float *out, int B, int C, int H, int W, int OH, int OW,

@@ -188,7 +188,9 @@ static int upload_conv(Network &net, Layer &l)
         YL_HIP(hipMemcpy(l.d_weights_bits, wb.data(), wb.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
         YL_HIP(hipMalloc((void **)&l.d_mean, sizeof(float) * M));
         YL_HIP(hipMemcpy(l.d_mean, l.mean_arr.data(), sizeof(float) * M, hipMemcpyHostToDevice));
-        const size_t bb = (size_t)net.batch * l.h * l.w * l.Cw * sizeof(uint64_t);
+        size_t bb = (size_t)net.batch * l.h * l.w * l.Cw * sizeof(uint64_t);
+        const size_t ob = (size_t)net.batch * l.h * l.w * ((M + 63) / 64) * sizeof(uint64_t);      // sign words of its result
+        if (ob > bb) bb = ob;
         if (bb > net.bitbuf_bytes) net.bitbuf_bytes = bb;
     }
     if (net.debug && l.conv_mode != CONV_F32) {
@@ -243,7 +245,11 @@ static int to_device(Network &net, int device)
     // three quantised-activation buffers used round-robin (layer j reads ring[j % 3]): a producer
     // one or two layers earlier can write layer j's input while reading its own
     if (net.qbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_qbuf, 3 * net.qbuf_bytes));
-    if (net.bitbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_bitbuf, net.bitbuf_bytes));
+    if (net.bitbuf_bytes) {
+        net.bitbuf_bytes = (net.bitbuf_bytes + 255) & ~(size_t)255;
+        YL_HIP(hipMalloc((void **)&net.d_bitbuf, 3 * net.bitbuf_bytes));
+        YL_HIP(hipMemset(net.d_bitbuf, 0, 3 * net.bitbuf_bytes));       // half-word writers (32 filters) rely on zeroed upper halves
+    }
     if (net.binbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_binbuf, net.binbuf_bytes));
     // ---- optional conv+shortcut fusion plan ----
     for (Layer &l : net.layers) { l.fused_shortcut = -1; l.fused_into_conv = false; }
@@ -270,7 +276,10 @@ static int to_device(Network &net, int device)
     }
     // ---- optional quantise-on-store plan (INT8): the producer of an INT8 conv's input emits the
     //      int8 NC/16HW16 tensor from its own epilogue; its FP32 tensor is skipped if nobody reads it
-    for (Layer &l : net.layers) { l.q_from_producer = false; l.q_out_layer = -1; l.skip_f32_out = false; }
+    for (Layer &l : net.layers) {
+        l.q_from_producer = false; l.q_out_layer = -1; l.skip_f32_out = false;
+        l.bits_from_producer = false; l.bits_out_slot = -1; l.pool_bits_mode = 0;
+    }
     if (net.fuse && !net.debug) {
         const int nl = (int)net.layers.size();
         auto referenced_elsewhere = [&](int t, int consumer) {
@@ -305,6 +314,34 @@ static int to_device(Network &net, int device)
             pl.q_out_layer = j;
             cons.q_from_producer = true;
             if (prod == j - 1) pl.skip_f32_out = !referenced_elsewhere(prod, j);
+        }
+        // ---- sign-domain plan (XNOR): an XNOR convolution reads only (x > 0); sign(maxpool(x)) is the OR of
+        //      the window's signs.  conv(xnor) [-> maxpool] -> conv(xnor) chains hand sign words over, the FP32
+        //      tensors in between are written only where something else reads them.
+        for (int j = 1; j < nl; ++j) {
+            Layer &cons = net.layers[j];
+            if (cons.type != YL_CONVOLUTIONAL || cons.conv_mode != CONV_XNOR) continue;
+            Layer &prev = net.layers[j - 1];
+            if (prev.type == YL_CONVOLUTIONAL && prev.conv_mode == CONV_XNOR && prev.fused_shortcut < 0) {
+                prev.bits_out_slot = j;                              // straight into this layer's input slot
+                cons.bits_from_producer = true;
+                prev.skip_f32_out = !referenced_elsewhere(j - 1, j);
+            } else if (prev.type == YL_MAXPOOL && j >= 2) {
+                Layer &pp = net.layers[j - 2];
+                const bool pool_private = !referenced_elsewhere(j - 1, j);
+                if (pp.type == YL_CONVOLUTIONAL && pp.conv_mode == CONV_XNOR && pp.fused_shortcut < 0 && pool_private &&
+                    !referenced_elsewhere(j - 2, j - 1)) {
+                    pp.bits_out_slot = j - 1;                        // pre-pool sign words in the pool layer's slot
+                    pp.skip_f32_out = true;
+                    prev.pool_bits_mode = 1;
+                    prev.skip_f32_out = true;
+                    cons.bits_from_producer = true;
+                } else if (pool_private) {
+                    prev.pool_bits_mode = 2;                         // FP32 in, pooled sign words out
+                    prev.skip_f32_out = true;
+                    cons.bits_from_producer = true;
+                }
+            }
         }
     }
     hipEvent_t e0, e1;
@@ -381,19 +418,32 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.alpha1 = 32 / (l.input_quant_multipler * l.weights_quant_multipler);
             YL_LAUNCH(launch_conv_i8(a, net.i8_tile, s, l.kernel_name, sizeof(l.kernel_name)), "conv_i8");
         } else {
-            YL_LAUNCH(launch_pack_sign_bits(input, net.d_bitbuf, B, l.c, l.h, l.w, l.Cw, s), "pack_sign_bits");
+            auto ring = [&](int slot) { return net.d_bitbuf + (size_t)(slot % 3) * (net.bitbuf_bytes / sizeof(uint64_t)); };
+            uint64_t *in_bits = ring((int)i);
+            if (!l.bits_from_producer)
+                YL_LAUNCH(launch_pack_sign_bits(input, in_bits, B, l.c, l.h, l.w, l.Cw, s), "pack_sign_bits");
             ConvXnorArgs a;
-            a.in_bits = net.d_bitbuf; a.w_bits = l.d_weights_bits; a.mean = l.d_mean; a.bias = l.d_biases;
-            a.out = l.d_output; a.dbg = l.d_debug;
+            a.in_bits = in_bits; a.w_bits = l.d_weights_bits; a.mean = l.d_mean; a.bias = l.d_biases;
+            a.out = l.skip_f32_out ? nullptr : l.d_output; a.dbg = l.d_debug;
+            a.out_bits = l.bits_out_slot >= 0 ? ring(l.bits_out_slot) : nullptr;
             a.B = B; a.C = l.c; a.Cw = l.Cw; a.H = l.h; a.W = l.w; a.M = l.n; a.Mpad = l.Mpad; a.act = l.activation;
             YL_LAUNCH(launch_conv_xnor(a, s), "conv_xnor");
             snprintf(l.kernel_name, sizeof(l.kernel_name), "conv_xnor");
         }
         break;
     }
-    case YL_MAXPOOL:
-        YL_LAUNCH(launch_maxpool(input, l.d_output, B, l.c, l.h, l.w, l.out_h, l.out_w, l.size, l.stride, l.pad, s), "maxpool");
+    case YL_MAXPOOL: {
+        auto ring = [&](int slot) { return net.d_bitbuf + (size_t)(slot % 3) * (net.bitbuf_bytes / sizeof(uint64_t)); };
+        if (l.pool_bits_mode == 1)
+            YL_LAUNCH(launch_bit_maxpool(ring((int)i), ring((int)i + 1), B, (l.c + 63) / 64, l.h, l.w, l.out_h, l.out_w,
+                                         l.size, l.stride, l.pad, s), "bit_maxpool");
+        else if (l.pool_bits_mode == 2)
+            YL_LAUNCH(launch_maxpool_sign_pack(input, ring((int)i + 1), B, l.c, (l.c + 63) / 64, l.h, l.w, l.out_h, l.out_w,
+                                               l.size, l.stride, l.pad, s), "maxpool_sign_pack");
+        if (!l.skip_f32_out)
+            YL_LAUNCH(launch_maxpool(input, l.d_output, B, l.c, l.h, l.w, l.out_h, l.out_w, l.size, l.stride, l.pad, s), "maxpool");
         break;
+    }
     case YL_ROUTE: {
         if (l.d_output_alias) break;
         size_t offset = 0;
@@ -452,6 +502,7 @@ static int forward(Network &net, const float *input_dev, int slot)
 // whose only reader takes the int8 side output)
 static bool layer_materialised(const Layer &l)
 {
+    if (l.type == YL_MAXPOOL) return !l.skip_f32_out;
     return !(l.type == YL_CONVOLUTIONAL && (l.fused_shortcut >= 0 || l.skip_f32_out));
 }
 
@@ -684,8 +735,9 @@ int yl_network_layer_traffic(const yl_network *net, int i, double *bytes)
             rd += q_in + wel;
         } else if (l.conv_mode == CONV_XNOR) {
             const double bits = B * (double)l.h * l.w * 8.0 * ((l.c + 63) / 64);
-            rd += 4 * in_el + bits + wel / 8;                             // sign-pack pass + bit conv
-            wr += bits;
+            if (!l.bits_from_producer) { rd += 4 * in_el; wr += bits; }   // stand-alone sign-pack pass
+            rd += bits + wel / 8;
+            if (l.bits_out_slot >= 0) wr += B * (double)l.out_h * l.out_w * 8.0 * ((l.n + 63) / 64);
         } else {
             rd += 4 * in_el + 4 * wel;
             if (l.binarize_input) { rd += 4 * in_el; wr += 4 * in_el; }
@@ -698,6 +750,13 @@ int yl_network_layer_traffic(const yl_network *net, int i, double *bytes)
     case YL_SHORTCUT:
         if (!l.fused_into_conv) { rd += 8 * out_el; wr += 4 * out_el; }
         break;
+    case YL_MAXPOOL: {
+        const double wi = B * (double)l.h * l.w * 8.0 * ((l.c + 63) / 64), wo = B * (double)l.out_h * l.out_w * 8.0 * ((l.c + 63) / 64);
+        if (l.pool_bits_mode == 1) { rd += wi; wr += wo; }
+        else if (l.pool_bits_mode == 2) { rd += 4 * in_el; wr += wo; }
+        if (!l.skip_f32_out) { rd += 4 * in_el; wr += 4 * out_el; }
+        break;
+    }
     case YL_ROUTE:
         if (!l.d_output_alias && !(l.n == 1)) { rd += 4 * out_el; wr += 4 * out_el; }
         break;

@@ -65,6 +65,10 @@ struct Layer {
     int   q_out_layer = -1;              // INT8 conv: also emits the quantised input of this later layer
     bool  binarize_input = false;        // xnor FP32 fallback: input -> +-1 before the conv
     bool  skip_f32_out = false;          // FP32 tensor of this layer has no reader and is not written
+    // XNOR sign-domain fusion (yl_network_set_fusion): sign words travel between XNOR layers instead of FP32
+    bool  bits_from_producer = false;    // XNOR conv: its packed input is written by the layer(s) before it
+    int   bits_out_slot = -1;            // XNOR conv: also emits the sign words of its result into bit-ring slot (index % 3)
+    int   pool_bits_mode = 0;            // maxpool: 1 = OR-pool sign words (slot i -> slot i+1), 2 = FP32 in -> pooled sign words
 };
 
 // arguments of the cached yl_network_get_boxes pass
@@ -98,7 +102,7 @@ struct Network {
     float *d_input = nullptr;
     int8_t *d_qbuf = nullptr;            // INT8: quantised NHWC activations scratch
     size_t qbuf_bytes = 0;
-    uint64_t *d_bitbuf = nullptr;        // XNOR: channel-packed sign bits scratch
+    uint64_t *d_bitbuf = nullptr;        // XNOR: channel-packed sign words, a ring of 3 slots (layer i reads slot i % 3)
     size_t bitbuf_bytes = 0;
     float *d_binbuf = nullptr;           // XNOR FP32 fallback: +-1 image scratch
     size_t binbuf_bytes = 0;
