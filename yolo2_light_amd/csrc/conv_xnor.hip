@@ -12,7 +12,8 @@
 //   activations  bits[B][Cw][H][W] uint64, bit (c & 63) of word plane (c >> 6) = (x[b][c][y][x] > 0)
 //                (src/additionally.c:132,1544); pad channels = 0.  Consecutive pixels are
 //                consecutive 8-byte words -> coalesced pack stores and tap loads.
-//   weights      wbits[Mpad][9][Cw] uint64, bit = (w_fused > 0); pad channels = 1, so a pad bit
+//   weights      wbits[Mpad/2][Cw][2][9] uint64 (filter pairs interleaved per channel word: one kernel step =
+//                18 contiguous words), bit = (w_fused > 0); pad channels = 1, so a pad bit
 //                never matches (activation 0 vs weight 1) and out-of-image taps -- loaded as 0
 //                through the buffer descriptor's range check -- count as -1 on every REAL
 //                channel exactly like the reference's zero-padded bit im2col.
@@ -162,9 +163,51 @@ struct ConvXnorDev {
 // words of a channel chunk are fetched once per 64 filters, and the 64 sign bits of the result are exactly one
 // word of the next layer's input).  W32: C <= 32 -- the upper halves of the single word are padding (activation
 // bits 0, weight bits 1: never a match), so only the lower 32 bits are counted.
+//
+// Weight stream.  SMEM returns out of order, so the only wait is lgkmcnt(0): a prefetch can be one STEP ahead
+// and no more.  PMC on the first version (profiles/r2_pmc_xnor_first_version.txt): 69 % of the wave cycles in
+// s_waitcnt -- hipcc's scheduler sank each scalar load to ~4 instructions before its wait.  Here a step is 18
+// weight words = 36 SGPRs (two filters x one channel word: a two-word chunk needed more scalar state than 102
+// SGPRs hold and was spilled to VGPR lanes, one v_readlane per two useful instructions); the next step's three
+// loads (x16 + x16 + x4) are issued, a sched_barrier pins them there, and the ~90 VALU instructions (~180 cycles)
+// of the current step run before hipcc's own wait in front of the first use.  (An inline-asm form of the same
+// loads was WRONG on some instances: hipcc copied the destination SGPRs before the data had landed.)
+typedef int s16 __attribute__((ext_vector_type(16)));
+typedef int s4 __attribute__((ext_vector_type(4)));
+struct WSet { s16 a, b; s4 c; };          // 36 dwords = 18 sign words
+
+__device__ __forceinline__ void wset_load(WSet &w, const uint64_t *ptr)
+{
+    const int *q = reinterpret_cast<const int *>(ptr);      // wave-uniform address -> s_load_dwordx16 / x4
+    w.a = *reinterpret_cast<const s16 *>(q);
+    w.b = *reinterpret_cast<const s16 *>(q + 16);
+    w.c = *reinterpret_cast<const s4 *>(q + 32);
+}
+template <int K> __device__ __forceinline__ unsigned wset_dword(const WSet &w)
+{
+    if constexpr (K < 16) return (unsigned)w.a[K];
+    else if constexpr (K < 32) return (unsigned)w.b[K - 16];
+    else return (unsigned)w.c[K - 32];
+}
+
+// accumulate taps [T, T1) of one filter whose 9 words start at word W0 of the set
+template <int CWC, bool W32, int W0, int T, int T1>
+__device__ __forceinline__ int xnor_acc(const WSet &w, const unsigned (&lo)[9][CWC], const unsigned (&hi)[9][CWC], int c)
+{
+    if constexpr (T < T1) {
+        c += __popc(~(lo[T][0] ^ wset_dword<2 * (W0 + T)>(w)));
+        if (!W32) c += __popc(~(hi[T][0] ^ wset_dword<2 * (W0 + T) + 1>(w)));
+        return xnor_acc<CWC, W32, W0, T + 1, T1>(w, lo, hi, c);
+    } else {
+        return c;
+    }
+}
+
 template <int CWC, int FT, bool W32>
 __global__ __launch_bounds__(256) void conv_xnor_kernel(ConvXnorDev p)
 {
+    static_assert(CWC == 1, "a step is two filters x one channel word");
+    constexpr int FS = 2;                       // filters per step
     const int tid = threadIdx.x;
     const int n = blockIdx.x * 256 + tid;
     const int f0 = blockIdx.y * FT;
@@ -202,7 +245,12 @@ __global__ __launch_bounds__(256) void conv_xnor_kernel(ConvXnorDev p)
 #pragma unroll
     for (int f = 0; f < FT; ++f) cnt[f] = 0;
 
-    for (int cw0 = 0; cw0 < p.Cw; cw0 += CWC) {
+    const int nchunk = p.Cw;
+    // weights of step (filter pair q, word cw): wbits[q][cw][2][9]
+    WSet ws[2];
+    wset_load(ws[0], p.w_bits + (size_t)(f0 / 2) * nchunk * 18);
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int cw0 = ch * CWC;
         unsigned in_lo[9][CWC], in_hi[9][CWC];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -223,20 +271,26 @@ __global__ __launch_bounds__(256) void conv_xnor_kernel(ConvXnorDev p)
             }
         }
 #pragma unroll
-        for (int f = 0; f < FT; ++f) {
-            // wave-uniform address -> scalar loads
-            const uint64_t *wf = p.w_bits + ((size_t)(f0 + f) * 9) * p.Cw + cw0;
-            int c = cnt[f];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-#pragma unroll
-                for (int w = 0; w < CWC; ++w) {
-                    const uint64_t ww = wf[(size_t)t * p.Cw + w];
-                    c += __popc(~(in_lo[t][w] ^ (unsigned)ww));
-                    if (!W32) c += __popc(~(in_hi[t][w] ^ (unsigned)(ww >> 32)));
-                }
+        for (int st = 0; st < FT / FS; ++st) {
+            WSet &cur = ws[st & 1];
+            WSet &nxt = ws[(st + 1) & 1];
+            // SMEM has one counter and returns out of order: hipcc waits lgkmcnt(0) at the first use of `cur`.  Use
+            // `cur` HERE (the first tap of the first filter), before the prefetch is issued, so that wait covers only
+            // loads issued a step ago.  (An asm statement as the "use" makes hipcc treat memory as clobbered and fall
+            // back to vector loads for the weights.)
+            cnt[2 * st] = xnor_acc<CWC, W32, 0, 0, 1>(cur, in_lo, in_hi, cnt[2 * st]);
+            __builtin_amdgcn_sched_barrier(0);
+            // next step: the following filter(s) of this chunk, or the first of the next chunk (the set loaded
+            // past the last step of the last chunk is never used: the weights are padded by one step)
+            {
+                const int qn = f0 / 2 + ((st + 1 < FT / FS) ? st + 1 : 0);
+                const int chn = (st + 1 < FT / FS) ? ch : ch + 1;
+                wset_load(nxt, p.w_bits + ((size_t)qn * nchunk + chn) * 18);
             }
-            cnt[f] = c;
+            __builtin_amdgcn_sched_barrier(0);          // the prefetch stays above this step's arithmetic
+            cnt[2 * st] = xnor_acc<CWC, W32, 0, 1, 9>(cur, in_lo, in_hi, cnt[2 * st]);
+            cnt[2 * st + 1] = xnor_acc<CWC, W32, 9, 0, 9>(cur, in_lo, in_hi, cnt[2 * st + 1]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -287,13 +341,7 @@ int launch_conv_xnor(const ConvXnorArgs &a, void *stream)
     hipStream_t s = (hipStream_t)stream;
     // weights are padded to a multiple of 64 filters (runtime.hip), FT must divide that
     if (a.C <= 32) return (a.M >= 64) ? launch_xnor<1, 64, true>(d, s) : launch_xnor<1, 32, true>(d, s);
-    if (a.M >= 64) {
-        if (a.Cw % 4 == 0) return launch_xnor<4, 64, false>(d, s);
-        if (a.Cw % 2 == 0) return launch_xnor<2, 64, false>(d, s);
-        return launch_xnor<1, 64, false>(d, s);
-    }
-    if (a.Cw % 2 == 0) return launch_xnor<2, 32, false>(d, s);
-    return launch_xnor<1, 32, false>(d, s);
+    return (a.M >= 64) ? launch_xnor<1, 64, false>(d, s) : launch_xnor<1, 32, false>(d, s);
 }
 
 }  // namespace yl

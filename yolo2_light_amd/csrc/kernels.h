@@ -67,7 +67,7 @@ int launch_conv_i8(const ConvI8Args &a, int tile, void *stream, char *name, size
 int launch_pack_sign_bits(const float *in, uint64_t *out, int B, int C, int H, int W, int Cw, void *stream);
 struct ConvXnorArgs {
     const uint64_t *in_bits;  // [B][H][W][Cw]
-    const uint64_t *w_bits;   // [Mpad][9][Cw], channel-pad bits = 1
+    const uint64_t *w_bits;   // [Mpad/2][Cw][2][9] (filter pairs interleaved per channel word); channel-pad bits = 1
     const float *mean;        // [M]
     const float *bias;        // [M]
     float *out;               // [B][M][H][W], or nullptr when only out_bits is wanted

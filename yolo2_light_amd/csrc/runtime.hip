@@ -168,11 +168,11 @@ static int upload_conv(Network &net, Layer &l)
         if (qb > net.qbuf_bytes) net.qbuf_bytes = qb;
     } else {   // CONV_XNOR
         if (!l.xnor_ready) { set_error("XNOR layer without yl_network_calculate_binary_weights()"); return YL_ERR_STATE; }
-        // 64-bit sign words along channels: [Mpad][9][Cw]; bit = (w > 0) (src/additionally.c:123,1544);
+        // 64-bit sign words along channels, filter pairs interleaved: [Mpad/2][Cw][2][9]; bit = (w > 0) (src/additionally.c:123,1544);
         // channel-pad bits are 1 in the weights and 0 in the activations so they never match.
         l.Cw = (l.c + 63) / 64;
         l.Mpad = round_up(M, 64);
-        std::vector<uint64_t> wb((size_t)l.Mpad * 9 * l.Cw, 0ull);
+        std::vector<uint64_t> wb((size_t)l.Mpad * l.Cw * 9 + 18, ~0ull);       // + one step: the kernel's last prefetch
         for (int m = 0; m < M; ++m)
             for (int t = 0; t < 9; ++t)
                 for (int cw = 0; cw < l.Cw; ++cw) {
@@ -182,7 +182,7 @@ static int upload_conv(Network &net, Layer &l)
                         const bool bit = (c < l.c) ? (l.weights[((size_t)m * l.c + c) * 9 + t] > 0.f) : true;
                         if (bit) word |= (1ull << b);
                     }
-                    wb[((size_t)m * 9 + t) * l.Cw + cw] = word;
+                    wb[((size_t)(m / 2) * l.Cw + cw) * 18 + (m % 2) * 9 + t] = word;
                 }
         YL_HIP(hipMalloc((void **)&l.d_weights_bits, wb.size() * sizeof(uint64_t)));
         YL_HIP(hipMemcpy(l.d_weights_bits, wb.data(), wb.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
