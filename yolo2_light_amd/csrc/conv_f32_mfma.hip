@@ -335,6 +335,10 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
                 vals[j][e] = v;
             }
         }
+        if (p.q_out && !p.out && !p.add) {          // only the int8 tensor is wanted (yolov3 layer 0 under -quantized)
+            store_q_from_cd<TN>(vals, m0 + wm0 + i * 32, p.M, n0 + wn0, p.Ntotal, p.OHW, p.q_out, p.q_mult, p.q_G, lane);
+            continue;
+        }
         if constexpr (Q_OK) {
             if (p.q_out) {
                 store_rows_via_lds_q<TN>(strip, vals, m0 + wm0 + i * 32, p.M, n0 + wn0, p.Ntotal, p.OHW,
@@ -378,8 +382,10 @@ static int launch_conv_f32_direct(const ConvF32Args &a, int cfg, void *stream, c
     d.q_out = a.q_out; d.q_mult = a.q_mult; d.q_G = a.q_G;
     if (a.q_out) {
         if (a.M % 16 != 0) return (int)hipErrorInvalidValue;
-        if (cfg == 10) cfg = 7;         // 16-row strips of the quantise-on-store epilogue do not fit these two
-        if (cfg == 11) cfg = 6;
+        if (a.out || a.add) {           // 16-row strips of the LDS quantise-on-store epilogue do not fit these two
+            if (cfg == 10) cfg = 7;
+            if (cfg == 11) cfg = 6;
+        }
     }
     d.B = a.B; d.C = a.C; d.H = a.H; d.W = a.W; d.M = a.M; d.OH = a.OH; d.OW = a.OW;
     d.K = a.K; d.Kpad = a.Kpad; d.Mpad = a.Mpad;

@@ -56,8 +56,10 @@ typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 
 // ------------------------------------------------------------------ K2a: quantise + repack
 // one lane per (b, cg, pixel): 16 coalesced plane reads, one 16-byte coalesced store
+// G = channel groups of THIS source, written at groups [g_off, g_off + G) of a tensor with G_total groups (a
+// multi-input [route] is quantised source by source into one int8 tensor: the FP32 concatenation is never built)
 __global__ __launch_bounds__(256) void quantize_nc16_kernel(const float *__restrict__ in, int8_t *__restrict__ out,
-                                                            size_t total, int C, int HW, int G, float mult)
+                                                            size_t total, int C, int HW, int G, int G_total, int g_off, float mult)
 {
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
@@ -76,19 +78,21 @@ __global__ __launch_bounds__(256) void quantize_nc16_kernel(const float *__restr
             w[j >> 2] |= ((unsigned)(q & 0xFF)) << ((j & 3) * 8);
         }
         uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
-        *reinterpret_cast<uint4 *>(out + idx * 16) = v;
+        *reinterpret_cast<uint4 *>(out + (((size_t)b * G_total + g_off + cg) * HW + pix) * 16) = v;
     }
 }
 
-int launch_quantize_nhwc(const float *in, int8_t *out, int B, int C, int H, int W, int Cpad, float mult, void *stream)
+int launch_quantize_nhwc(const float *in, int8_t *out, int B, int C, int H, int W, int Cpad, float mult, void *stream,
+                         int g_off, int G_total)
 {
     const int G = Cpad / 16;
+    if (G_total <= 0) G_total = G;
     const size_t total = (size_t)B * G * H * W;
     size_t g = (total + 255) / 256;
     if (g > 256 * 16) g = 256 * 16;
     if (g == 0) g = 1;
     hipLaunchKernelGGL(quantize_nc16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
-                       in, out, total, C, H * W, G, mult);
+                       in, out, total, C, H * W, G, G_total, g_off, mult);
     return (int)hipGetLastError();
 }
 

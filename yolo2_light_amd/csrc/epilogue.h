@@ -94,6 +94,59 @@ __device__ __forceinline__ int quantize_input_i8(float x, float mult)
     return (abs(s) > 127) ? ((s > 0) ? 127 : -127) : s;
 }
 
+// The int8 side output alone, straight from the MFMA C/D layout (no LDS): a lane owns pixel column n and rows
+// (e&3) + 8*(e>>2) + 4*half; its 4 consecutive channels of each row group pack into one dword, and one
+// v_permlane32_swap per 16-channel unit hands every lane 8 contiguous bytes of the unit (lanes 0-31 bytes 0-7,
+// lanes 32-63 bytes 8-15): 512 contiguous bytes per store instruction.  Fast quantisation = trunc + clamp; the
+// `int16_t = float` wrap corner (|x*mult| >= 32768, see quantize_input_i8) is detected per block and redone.
+// Requires m_base % 32 == 0 and M % 16 == 0.
+template <int TN>
+__device__ __forceinline__ void store_q_from_cd(const float (&vals)[TN][16], int m_base, int M, int n_base, int Ntotal,
+                                                int OHW, int8_t *q_out, float q_mult, int q_G, int lane)
+{
+    const int l31 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n_base + j * 32 + l31;
+        unsigned pk[4];
+        float tmax = 0.f;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            int c[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float t = __fmul_rn(vals[j][g4 * 4 + r4], q_mult);
+                tmax = fmaxf(tmax, fabsf(t));
+                const int ci = (int)t;
+                c[r4] = ci < -127 ? -127 : (ci > 127 ? 127 : ci);
+            }
+            pk[g4] = __builtin_amdgcn_perm((unsigned)c[1], (unsigned)c[0], 0x0C0C0400u) |
+                     __builtin_amdgcn_perm((unsigned)c[3], (unsigned)c[2], 0x04000C0Cu);
+        }
+        if (__builtin_amdgcn_ballot_w64(!(tmax < 32768.f)) != 0ull) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                unsigned w = 0;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+                    w |= ((unsigned)(quantize_input_i8(vals[j][g4 * 4 + r4], q_mult) & 0xFF)) << (8 * r4);
+                pk[g4] = w;
+            }
+        }
+        const int ob = n / OHW;
+        const size_t unit0 = (size_t)ob * q_G * OHW + (n - ob * OHW);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(pk[2 * u], pk[2 * u + 1], false, false);
+            const int cg = (m_base + 16 * u) >> 4;
+            if (n < Ntotal && m_base + 16 * u < M) {
+                uint2 d = make_uint2(sw[0], sw[1]);
+                *reinterpret_cast<uint2 *>(q_out + (unit0 + (size_t)cg * OHW) * 16 + 8 * half) = d;
+            }
+        }
+    }
+}
+
 // As store_rows_via_lds, plus a quantised side output for the NEXT INT8 convolution: the tensor
 // the next layer consumes (out, or out_add when a [shortcut] is fused) is also written as
 // act_q[B][q_G][OH][OW][16] int8 with the next layer's input multiplier, so that layer needs no

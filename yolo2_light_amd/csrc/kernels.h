@@ -41,8 +41,10 @@ int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, void *st
 
 // ---- K2: INT8 path ----
 // K2a: x_q = clamp_abs((int16)(x*mult), 127), FP32 NCHW -> int8 NHWC(Cpad)   (quantized.c:554-560)
+// (g_off, G_total): write this source's Cpad/16 groups at group offset g_off of a tensor with G_total groups
+// (0, 0 = the source is the whole tensor)
 int launch_quantize_nhwc(const float *in, int8_t *out, int B, int C, int H, int W, int Cpad,
-                         float mult, void *stream);
+                         float mult, void *stream, int g_off = 0, int G_total = 0);
 struct ConvI8Args {
     const int8_t *in_q;   // [B][H][W][Cpad]
     const int8_t *w_q;    // [Mpad][size*size][Cpad]

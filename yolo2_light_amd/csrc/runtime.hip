@@ -277,7 +277,7 @@ static int to_device(Network &net, int device)
     // ---- optional quantise-on-store plan (INT8): the producer of an INT8 conv's input emits the
     //      int8 NC/16HW16 tensor from its own epilogue; its FP32 tensor is skipped if nobody reads it
     for (Layer &l : net.layers) {
-        l.q_from_producer = false; l.q_out_layer = -1; l.skip_f32_out = false;
+        l.q_from_producer = false; l.q_out_layer = -1; l.skip_f32_out = false; l.q_from_route = false;
         l.bits_from_producer = false; l.bits_out_slot = -1; l.pool_bits_mode = 0;
     }
     if (net.fuse && !net.debug) {
@@ -314,6 +314,23 @@ static int to_device(Network &net, int device)
             pl.q_out_layer = j;
             cons.q_from_producer = true;
             if (prod == j - 1) pl.skip_f32_out = !referenced_elsewhere(prod, j);
+        }
+        // ---- an INT8 conv behind a multi-input [route] nobody else reads: quantise the route's sources straight
+        //      into the int8 tensor (channel groups at their offsets), the FP32 concatenation is not built
+        for (int j = 1; j < nl; ++j) {
+            Layer &cons = net.layers[j];
+            Layer &rt = net.layers[j - 1];
+            if (cons.type != YL_CONVOLUTIONAL || cons.conv_mode != CONV_INT8 || cons.q_from_producer) continue;
+            if (rt.type != YL_ROUTE || rt.d_output_alias || rt.n < 2 || referenced_elsewhere(j - 1, j)) continue;
+            bool ok = (cons.c % 16) == 0;
+            for (int k = 0; k < rt.n && ok; ++k) {
+                const Layer &src = net.layers[rt.input_layers[k]];
+                ok = (src.out_c % 16) == 0 && src.out_w == cons.w && src.out_h == cons.h &&
+                     !(src.type == YL_CONVOLUTIONAL && (src.fused_shortcut >= 0 || src.skip_f32_out));
+            }
+            if (!ok) continue;
+            cons.q_from_route = true;
+            rt.skip_f32_out = true;
         }
         // ---- sign-domain plan (XNOR): an XNOR convolution reads only (x > 0); sign(maxpool(x)) is the OR of
         //      the window's signs.  conv(xnor) [-> maxpool] -> conv(xnor) chains hand sign words over, the FP32
@@ -392,7 +409,16 @@ static int forward_layer(Network &net, size_t i, const float *input)
             YL_LAUNCH(launch_conv_f32(a, net.conv_opts, s, l.kernel_name, sizeof(l.kernel_name)), "conv_f32");
         } else if (l.conv_mode == CONV_INT8) {
             int8_t *q_in = net.d_qbuf + (i % 3) * net.qbuf_bytes;
-            if (!l.q_from_producer)
+            if (l.q_from_route) {
+                const Layer &rt = net.layers[i - 1];
+                int g_off = 0;
+                for (int k = 0; k < rt.n; ++k) {
+                    const Layer &src = net.layers[rt.input_layers[k]];
+                    YL_LAUNCH(launch_quantize_nhwc(src.d_output, q_in, B, src.out_c, l.h, l.w, src.out_c, l.input_quant_multipler,
+                                                   s, g_off, l.Cpad / 16), "quantize_route");
+                    g_off += src.out_c / 16;
+                }
+            } else if (!l.q_from_producer)
                 YL_LAUNCH(launch_quantize_nhwc(input, q_in, B, l.c, l.h, l.w, l.Cpad, l.input_quant_multipler, s),
                           "quantize_nhwc");
             ConvI8Args a;
@@ -445,7 +471,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
         break;
     }
     case YL_ROUTE: {
-        if (l.d_output_alias) break;
+        if (l.d_output_alias || l.skip_f32_out) break;          // alias, or quantised straight from its sources
         size_t offset = 0;
         for (int k = 0; k < l.n; ++k) {
             const Layer &src = net.layers[l.input_layers[k]];
@@ -502,7 +528,7 @@ static int forward(Network &net, const float *input_dev, int slot)
 // whose only reader takes the int8 side output)
 static bool layer_materialised(const Layer &l)
 {
-    if (l.type == YL_MAXPOOL) return !l.skip_f32_out;
+    if (l.type == YL_MAXPOOL || l.type == YL_ROUTE) return !l.skip_f32_out;
     return !(l.type == YL_CONVOLUTIONAL && (l.fused_shortcut >= 0 || l.skip_f32_out));
 }
 
@@ -758,7 +784,7 @@ int yl_network_layer_traffic(const yl_network *net, int i, double *bytes)
         break;
     }
     case YL_ROUTE:
-        if (!l.d_output_alias && !(l.n == 1)) { rd += 4 * out_el; wr += 4 * out_el; }
+        if (!l.d_output_alias && !(l.n == 1) && !l.skip_f32_out) { rd += 4 * out_el; wr += 4 * out_el; }
         break;
     default:
         rd += 4 * in_el; wr += 4 * out_el;

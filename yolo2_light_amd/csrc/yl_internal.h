@@ -62,6 +62,7 @@ struct Layer {
     int   fused_shortcut = -1;           // conv: index of the [shortcut] layer folded into its epilogue
     bool  fused_into_conv = false;       // shortcut: produced by the preceding conv's epilogue
     bool  q_from_producer = false;       // INT8 conv: its quantised input is written by the producing conv
+    bool  q_from_route = false;          // INT8 conv: its input is a multi-input [route], quantised source by source
     int   q_out_layer = -1;              // INT8 conv: also emits the quantised input of this later layer
     bool  binarize_input = false;        // xnor FP32 fallback: input -> +-1 before the conv
     bool  skip_f32_out = false;          // FP32 tensor of this layer has no reader and is not written
