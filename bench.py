@@ -74,6 +74,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--layers", action="store_true", help="also print a per-layer table to stderr")
     ap.add_argument("--tile", type=int, default=0, help="force K1 tile config (tuning)")
+    ap.add_argument("--variant", type=int, default=-1, help="FP32 schedule variant bits (yl_network_set_variant; A/B runs)")
     ap.add_argument("--i8-tile", type=int, default=0, help="force K2 (INT8) tile config (tuning)")
     ap.add_argument("--no-fuse", action="store_true", help="keep [shortcut] layers as separate kernels")
     return ap.parse_args()
@@ -227,6 +228,8 @@ class Leg:
         self.net.set_stream(stream.cuda_stream)
         if args.tile:
             self.net.set_conv_tile(args.tile)
+        if args.variant >= 0:
+            self.net.set_variant(args.variant)
         if args.i8_tile:
             self.net.set_int8_tile(args.i8_tile)
         last = self.net.layer_info(self.net.n - 1)

@@ -260,12 +260,17 @@ int yl_network_pull_heads(yl_network *net);
 /* Tuning/test hooks, PER NETWORK (two networks driven from two host threads share no launch state).
  * yl_network_set_conv_tile: force the K1 kernel of every FP32 convolution of this network, any time:
  *   0 = built-in heuristic (default), 11..22 = direct implicit-GEMM tile 1..12 (conv_f32_mfma.hip),
- *   31 = Winograd F(2x2,3x3) (conv_f32_wino32.hip; a launch fails on layers it does not apply to).
+ *   31 = Winograd F(2x2,3x3) (conv_f32_wino32.hip; a launch fails on layers it does not apply to),
+ *   41 = LDS-free first-layer kernel (conv_f32_smallk.hip; C*size^2 <= 32 and filters <= 32 only).
  * yl_network_set_winograd: 0 = never pick Winograd heuristically and do not pack its weights, 1 = default;
  *   BEFORE yl_network_to_device.
  * yl_network_set_nms_mode: yl_network_detect_batch's suppression stage, 1 = one workgroup per
  *   (image, class) (default), 0 = one workgroup per image; same rows either way. */
 int yl_network_set_conv_tile(yl_network *net, int cfg);
+/* schedule variants of the FP32 kernels kept switchable for same-box A/B measurements (results are identical):
+ * bit 0 Winograd U panels by LDS-DMA, bit 1 Winograd epilogue prefetches the fused [shortcut] operand,
+ * bit 2 float4 B-panel rows in the 1x1 direct kernel, bit 3 LDS-free first-layer kernel; -1 = built-in default */
+int yl_network_set_variant(yl_network *net, int bits);
 /* the same for the INT8 convolution (conv_i8_mfma.hip): 0 = heuristic, 1 = 64x128, 2 = 32x256, 3 = 128x128,
  * 4 = 128x256 (8 waves), 5 = 64x256 */
 int yl_network_set_int8_tile(yl_network *net, int cfg);

@@ -264,6 +264,33 @@ def test_int8_fusion_is_bit_identical(width, height, batch, tile):
     plain.close(); fused.close()
 
 
+@pytest.mark.parametrize("width,height,batch", [(96, 96, 2), (160, 96, 3)])
+def test_int8_fusion_with_first_layer_kernel_is_bit_identical(width, height, batch):
+    """-quantized yolov3, fused, layer 0 through the LDS-free first-layer kernel writing ONLY the int8 input of
+    layer 1 (conv_f32_smallk.hip, variant bit 3): same materialised tensors and detections as the unfused run."""
+    cfg, wts = common.model_files("yolov3", width, height)
+    x = common.seeded_input(batch, 3, height, width)
+    plain = Network.load(cfg, wts, batch, 1, device=0)
+    fused = Network.load(cfg, wts, batch, 1, device=0, fuse=True)
+    plain.set_variant(0)
+    fused.set_variant(8)
+    plain.predict(x)
+    fused.predict(x)
+    assert "smallk" in fused.layer_kernel(0), fused.layer_kernel(0)
+    infos = plain.layers()
+    checked = 0
+    for i, li in enumerate(infos):
+        if (li["type"] in (common.SHORTCUT, common.ROUTE, common.YOLO, common.UPSAMPLE) or
+                (li["type"] == common.CONV and li["activation"] == D.LINEAR)) and fused.layer_materialised(i):
+            assert np.array_equal(plain.layer_output(i).view(np.uint32), fused.layer_output(i).view(np.uint32)), i
+            checked += 1
+    assert checked > 30
+    for b in range(batch):
+        assert np.array_equal(plain.get_boxes(b, width, height, 0.24, nms=0.4),
+                              fused.get_boxes(b, width, height, 0.24, nms=0.4))
+    plain.close(); fused.close()
+
+
 @pytest.mark.parametrize("name,width,height,batch,quantized", [
     ("yolov2-voc", 96, 96, 2, 0), ("yolov2-voc", 160, 160, 1, 1), ("tiny-yolo-voc", 96, 64, 2, 0),
     ("yolov3-spp", 64, 64, 2, 0), ("yolov3-spp", 96, 96, 1, 1),

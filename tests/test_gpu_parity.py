@@ -410,3 +410,130 @@ def test_shortcut_fusion_is_bit_identical():
         assert np.array_equal(plain.get_boxes(b, width, height, 0.24, nms=0.4),
                               fused.get_boxes(b, width, height, 0.24, nms=0.4))
     plain.close(); fused.close()
+
+
+# ----------------------------------------------------------------------------
+# schedule variants (yl_network_set_variant): same arithmetic in the same order => bit-identical results
+# ----------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", WINO_SHAPES)
+def test_winograd_variants_bit_identical(shape):
+    """LDS-DMA weight panels (bit 0) and the prefetched [shortcut] operand (bit 1) change the schedule only."""
+    B, Cc, H, W, M, act = shape
+    rng = np.random.default_rng(7 + M + H)
+    wts = rng.normal(0, np.sqrt(2.0 / (Cc * 9)), M * Cc * 9).astype(np.float32)
+    bias = rng.normal(0, 0.5, M).astype(np.float32)
+    x = (rng.standard_normal((B, Cc, H, W)) + 0.3).astype(np.float32)
+    d = D.conv(B, W, H, Cc, M, 3, 1, 1, act, wts, bias)
+    net = _net_from([d], B, W, H, Cc)
+    net.set_conv_tile(31)
+    net.set_variant(0)
+    base = net.predict(x).copy()
+    assert "wino" in net.layer_kernel(0) and "udma" not in net.layer_kernel(0)
+    for v in (1, 2, 3):
+        net.set_variant(v)
+        got = net.predict(x)
+        if v & 1:
+            assert "udma" in net.layer_kernel(0)
+        assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), "variant %d shape %r" % (v, shape)
+    net.close()
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 15])
+def test_variants_whole_network_fused_bit_identical(variant):
+    """yolov3 with conv+[shortcut] fusion (the benched setup): every materialised tensor and the detections of
+    a run with the schedule variants equal the plain schedule's bit for bit (odd and even map sizes)."""
+    name, width, height, batch = "yolov3", 160, 96, 2
+    cfg, wts = common.model_files(name, width, height)
+    x = common.seeded_input(batch, 3, height, width)
+    a = Network.load(cfg, wts, batch, 0, device=0, fuse=True)
+    b = Network.load(cfg, wts, batch, 0, device=0, fuse=True)
+    a.set_variant(0)
+    b.set_variant(variant)
+    a.predict(x)
+    b.predict(x)
+    infos = a.layers()
+    for i, li in enumerate(infos):
+        nxt = infos[i + 1] if i + 1 < len(infos) else None
+        if li["type"] == common.CONV and nxt is not None and nxt["type"] == common.SHORTCUT:
+            continue
+        assert np.array_equal(a.layer_output(i).view(np.uint32), b.layer_output(i).view(np.uint32)), "layer %d" % i
+    kernels = [b.layer_kernel(i) for i in range(b.n)]
+    if variant & 1:
+        assert any("udma" in k for k in kernels)
+    if variant & 8:
+        assert "smallk" in kernels[0]
+    for im in range(batch):
+        assert np.array_equal(a.get_boxes(im, width, height, 0.24, nms=0.4), b.get_boxes(im, width, height, 0.24, nms=0.4))
+    a.close(); b.close()
+
+
+VEC4_SHAPES = [
+    # B, C, H, W, M, act  (1x1 / stride 1, H*W % 4 == 0, C % 32 == 0)
+    (2, 128, 12, 12, 128, D.LEAKY),
+    (3, 64, 8, 6, 255, D.LINEAR),         # M = 255 head-like
+    (5, 32, 2, 2, 40, D.LEAKY),           # 4 pixels per image: every float4 is one image
+    (1, 256, 38, 38, 128, D.LEAKY),
+    (2, 96, 10, 14, 33, D.LEAKY),         # C % 32 == 0 only
+]
+
+
+@pytest.mark.parametrize("shape", VEC4_SHAPES)
+@pytest.mark.parametrize("tile", [0, 11, 12, 13, 14, 15, 17, 20, 22])
+def test_conv_1x1_float4_rows_bit_identical(olib, shape, tile):
+    B, Cc, H, W, M, act = shape
+    rng = np.random.default_rng(31 + M + H)
+    wts = rng.normal(0, np.sqrt(2.0 / Cc), M * Cc).astype(np.float32)
+    bias = rng.normal(0, 0.5, M).astype(np.float32)
+    x = rng.standard_normal((B, Cc, H, W)).astype(np.float32)
+    d = D.conv(B, W, H, Cc, M, 1, 1, 0, act, wts, bias)
+    net = _net_from([d], B, W, H, Cc)
+    net.set_conv_tile(tile)
+    net.set_variant(0)
+    base = net.predict(x).copy()
+    assert ",v4" not in net.layer_kernel(0)
+    net.set_variant(4)
+    got = net.predict(x)
+    assert ",v4" in net.layer_kernel(0), net.layer_kernel(0)
+    assert np.array_equal(got.view(np.uint32), base.view(np.uint32))
+    ref = np.zeros(B * d.outputs, dtype=np.float32)
+    olib.oracle_conv_f32(fp(x), fp(wts), fp(bias), fp(ref), B, Cc, H, W, M, 1, 1, 0, act)
+    ok, ratio, _ = fp32_close(got, ref)
+    assert ok and ratio < 0.2
+    net.close()
+
+
+SMALLK_SHAPES = [
+    # B, C, H, W, M, size, stride, pad, act  (C*size^2 <= 32, M <= 32)
+    (1, 3, 16, 16, 16, 3, 1, 1, D.LEAKY),          # yolov3-tiny's first layer shape class, M = 16
+    (2, 3, 19, 23, 32, 3, 1, 1, D.LEAKY),          # ragged, a tile crosses the image boundary
+    (3, 3, 40, 40, 32, 3, 1, 1, D.LEAKY),          # several tiles per wave, several workgroups
+    (2, 1, 9, 11, 20, 5, 1, 2, D.LEAKY),           # 5x5, K = 25
+    (2, 3, 17, 15, 24, 3, 2, 1, D.LINEAR),         # stride 2
+    (1, 8, 12, 10, 32, 2, 1, 0, D.LEAKY),          # K = 32 exactly (16 k-steps)
+    (4, 30, 6, 6, 7, 1, 1, 0, D.LINEAR),           # 1x1, K = 30, M = 7
+]
+
+
+@pytest.mark.parametrize("shape", SMALLK_SHAPES)
+def test_conv_smallk_vs_oracle(olib, shape):
+    B, Cc, H, W, M, size, stride, pad, act = shape
+    rng = np.random.default_rng(55 + M + size)
+    K = Cc * size * size
+    wts = rng.normal(0, np.sqrt(2.0 / K), M * K).astype(np.float32)
+    bias = rng.normal(0, 0.5, M).astype(np.float32)
+    x = rng.standard_normal((B, Cc, H, W)).astype(np.float32)
+    d = D.conv(B, W, H, Cc, M, size, stride, pad, act, wts, bias)
+    net = _net_from([d], B, W, H, Cc)
+    net.set_conv_tile(41)
+    got = net.predict(x).copy()
+    assert "smallk" in net.layer_kernel(0)
+    ref = np.zeros(B * d.outputs, dtype=np.float32)
+    olib.oracle_conv_f32(fp(x), fp(wts), fp(bias), fp(ref), B, Cc, H, W, M, size, stride, pad, act)
+    ok, ratio, worst = fp32_close(got, ref)
+    assert ok and ratio < 0.2, "shape %r: err/allowed %.3g at %d" % (shape, ratio, worst)
+    # same k pairs in the same order as the LDS-staged kernel: identical bits
+    net.set_conv_tile(13)
+    direct = net.predict(x)
+    assert "smallk" not in net.layer_kernel(0)
+    assert np.array_equal(got.view(np.uint32), direct.view(np.uint32))
+    net.close()

@@ -71,7 +71,11 @@ struct ConvF32Dev {
     int tiles_m;
 };
 
-template <int BM, int BN, int WM, int WN, int KS, int BK, int NWAVES, bool TAPMAJOR>
+// VEC4 (1x1 / stride 1 / pad 0 layers with OH*OW % 4 == 0 and C % BK == 0): a row of the B panel is BN contiguous
+// floats of one channel plane, so a thread fetches 4 consecutive pixels with ONE 16-byte buffer load and stages
+// them with one ds_write_b128 (4x fewer VMEM and LDS-write instructions than the per-pixel gather); the k row of
+// a lane goes into its voffset, the panel's first channel into the scalar offset.
+template <int BM, int BN, int WM, int WN, int KS, int BK, int NWAVES, bool TAPMAJOR, bool VEC4 = false>
 __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32Dev p)
 {
     constexpr int NT = NWAVES * 64;
@@ -87,8 +91,12 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
     constexpr int A_F4 = BK * BM / 4;
     constexpr int APT = (A_F4 + NT - 1) / NT;               // float4 per thread per panel
     constexpr bool A_FULL = (A_F4 % NT) == 0;
-    constexpr int BPT = BK * BN / NT;                       // gathered floats per thread per panel
+    constexpr int BPT = VEC4 ? 1 : BK * BN / NT;            // gathered floats per thread per panel
     constexpr int K_STEP = NT / BN;
+    static_assert(!VEC4 || (KS == 1 && !TAPMAJOR), "float4 rows: 1x1 layers only");
+    constexpr int RPP4 = NT / (BN / 4);                     // VEC4: k rows one pass of the workgroup covers
+    constexpr int BPT4 = VEC4 ? BK / RPP4 : 1;              // VEC4: float4 per thread per panel
+    static_assert(!VEC4 || (BK % RPP4 == 0 && BPT4 >= 1), "VEC4 panel split");
 
     __shared__ __attribute__((aligned(16))) float smem[2 * BK * BM + 2 * BK * BN];
     float *As = smem;
@@ -159,6 +167,19 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
 
     float a_reg[APT][4];
     float b_reg[BPT];
+    float b_reg4[BPT4][4];
+    // VEC4 staging role: float4 column n4 of k row r4 (+ e * RPP4)
+    const int n4 = tid % (BN / 4);
+    const int r4 = tid / (BN / 4);
+    int voff4 = -1;
+    if (VEC4) {
+        const int n_g4 = n0 + 4 * n4;
+        if (n_g4 < p.Ntotal) {
+            const int b4 = n_g4 / p.OHW;
+            const int pix4 = n_g4 - b4 * p.OHW;
+            voff4 = (int)(((unsigned)(b4 - b_first) * (unsigned)CHW + (unsigned)pix4 + (unsigned)r4 * (unsigned)HW) * 4u);
+        }
+    }
 
     // ---- slice helpers (E = element index inside the thread's share of a panel) ----
 #define YL_LOAD_A(KB, E)                                                                           \
@@ -206,6 +227,18 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
         b_reg[E] = __builtin_bit_cast(float,                                                       \
             __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff | tinv | kinv, soff, 0));              \
     }
+#define YL_LOAD_B4(KB, E)                                                                          \
+    {                                                                                              \
+        const int soff = ((KB) * BK + (E) * RPP4) * HW * 4;                                        \
+        const auto q4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff4, soff, 0);               \
+        b_reg4[E][0] = __uint_as_float(q4[0]); b_reg4[E][1] = __uint_as_float(q4[1]);              \
+        b_reg4[E][2] = __uint_as_float(q4[2]); b_reg4[E][3] = __uint_as_float(q4[3]);              \
+    }
+#define YL_STORE_B4(BUF, E)                                                                        \
+    {                                                                                              \
+        *reinterpret_cast<float4 *>(Bs + (BUF) * BK * BN + (r4 + (E) * RPP4) * BN + n4 * 4) =      \
+            make_float4(b_reg4[E][0], b_reg4[E][1], b_reg4[E][2], b_reg4[E][3]);                   \
+    }
 #define YL_STORE_A(BUF, E)                                                                         \
     {                                                                                              \
         const int idx = tid + (E) * NT;                                                            \
@@ -252,19 +285,34 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
     YL_PANEL_SETUP()
 #pragma unroll
     for (int e = 0; e < APT; ++e) YL_LOAD_A(0, e)
+    if constexpr (VEC4) {
 #pragma unroll
-    for (int e = 0; e < BPT; ++e) YL_LOAD_B(0, e)
+        for (int e = 0; e < BPT4; ++e) YL_LOAD_B4(0, e)
+    } else {
+#pragma unroll
+        for (int e = 0; e < BPT; ++e) YL_LOAD_B(0, e)
+    }
 #pragma unroll
     for (int e = 0; e < APT; ++e) YL_STORE_A(0, e)
+    if constexpr (VEC4) {
 #pragma unroll
-    for (int e = 0; e < BPT; ++e) YL_STORE_B(0, e)
+        for (int e = 0; e < BPT4; ++e) YL_STORE_B4(0, e)
+    } else {
+#pragma unroll
+        for (int e = 0; e < BPT; ++e) YL_STORE_B(0, e)
+    }
     YL_PANEL_ADVANCE()
     if (nkb > 1) {
         YL_PANEL_SETUP()
 #pragma unroll
         for (int e = 0; e < APT; ++e) YL_LOAD_A(1, e)
+        if constexpr (VEC4) {
 #pragma unroll
-        for (int e = 0; e < BPT; ++e) YL_LOAD_B(1, e)
+            for (int e = 0; e < BPT4; ++e) YL_LOAD_B4(1, e)
+        } else {
+#pragma unroll
+            for (int e = 0; e < BPT; ++e) YL_LOAD_B(1, e)
+        }
         YL_PANEL_ADVANCE()
     }
     __syncthreads();
@@ -285,9 +333,16 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
                 if (DO_STORE) YL_STORE_A(buf ^ 1, e)                                               \
                 if (DO_LOAD) YL_LOAD_A((KB) + 2, e)                                                \
             }                                                                                      \
-            _Pragma("unroll") for (int e = ks * BPT / KSTEPS; e < (ks + 1) * BPT / KSTEPS; ++e) {  \
-                if (DO_STORE) YL_STORE_B(buf ^ 1, e)                                               \
-                if (DO_LOAD) YL_LOAD_B((KB) + 2, e)                                                \
+            if constexpr (VEC4) {                                                                  \
+                _Pragma("unroll") for (int e = ks * BPT4 / KSTEPS; e < (ks + 1) * BPT4 / KSTEPS; ++e) { \
+                    if (DO_STORE) YL_STORE_B4(buf ^ 1, e)                                          \
+                    if (DO_LOAD) YL_LOAD_B4((KB) + 2, e)                                           \
+                }                                                                                  \
+            } else {                                                                               \
+                _Pragma("unroll") for (int e = ks * BPT / KSTEPS; e < (ks + 1) * BPT / KSTEPS; ++e) { \
+                    if (DO_STORE) YL_STORE_B(buf ^ 1, e)                                           \
+                    if (DO_LOAD) YL_LOAD_B((KB) + 2, e)                                            \
+                }                                                                                  \
             }                                                                                      \
             if (ks + 1 < KSTEPS) {                                                                 \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i)                                     \
@@ -316,6 +371,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
 #undef YL_LOAD_B
 #undef YL_STORE_A
 #undef YL_STORE_B
+#undef YL_LOAD_B4
+#undef YL_STORE_B4
 
     // ---- fused epilogue: +bias, activation (identical arithmetic to v1), then row-wise stores
     //      through a wave-private LDS strip (epilogue.h); the main loop's last barrier has passed,
@@ -352,7 +409,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
 }
 
 template <int BM, int BN, int WM, int WN, int BK, int NWAVES>
-static int launch_pipe(const ConvF32Dev &d, int ks, bool tapmajor, hipStream_t s)
+static int launch_pipe(const ConvF32Dev &d, int ks, bool tapmajor, hipStream_t s, bool vec4 = false)
 {
     ConvF32Dev p = d;
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -367,6 +424,9 @@ static int launch_pipe(const ConvF32Dev &d, int ks, bool tapmajor, hipStream_t s
         if (p.C % BK != 0 || p.size > 5) return (int)hipErrorInvalidValue;
         if (ks == 3) hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 3, BK, NWAVES, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 0, BK, NWAVES, true>), grid, block, 0, s, p);
+    } else if (ks == 1 && vec4) {
+        if (p.C % BK != 0 || p.OHW % 4 != 0 || p.stride != 1) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 1, BK, NWAVES, false, true>), grid, block, 0, s, p);
     } else if (ks == 1) hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 1, BK, NWAVES, false>), grid, block, 0, s, p);
     else if (ks == 3) hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 3, BK, NWAVES, false>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 0, BK, NWAVES, false>), grid, block, 0, s, p);
@@ -375,7 +435,7 @@ static int launch_pipe(const ConvF32Dev &d, int ks, bool tapmajor, hipStream_t s
 
 // cfg: 1 128x128/4w  2 64x128/4w  3 32x256/4w  4 64x64/4w  5 128x128 BK32/4w  6 256x128/8w
 //      7 128x256/8w  8 256x128 BK32/8w  9 128x128/8w(TM1)
-static int launch_conv_f32_direct(const ConvF32Args &a, int cfg, void *stream, char *name, size_t name_len)
+static int launch_conv_f32_direct(const ConvF32Args &a, int cfg, int variant, void *stream, char *name, size_t name_len)
 {
     ConvF32Dev d;
     d.in = a.in; d.wt = a.wt; d.bias = a.bias; d.add = a.add; d.out_add = a.out_add; d.out = a.out;
@@ -399,24 +459,25 @@ static int launch_conv_f32_direct(const ConvF32Args &a, int cfg, void *stream, c
     int ks = 0;
     if (a.size == 1 && a.pad == 0) ks = 1;
     else if (a.size == 3) ks = 3;
+    const bool vec4 = (variant & 4) && ks == 1 && a.stride == 1 && !a.tapmajor && a.C % 32 == 0 && (d.OHW % 4) == 0;
     const char *t = "?";
     int rc;
     switch (cfg) {
-    case 1: t = "128x128";      rc = launch_pipe<128, 128, 2, 2, 16, 4>(d, ks, a.tapmajor != 0, s); break;
-    case 2: t = "64x128";       rc = launch_pipe<64, 128, 2, 2, 16, 4>(d, ks, a.tapmajor != 0, s); break;
-    case 3: t = "32x256";       rc = launch_pipe<32, 256, 1, 4, 16, 4>(d, ks, a.tapmajor != 0, s); break;
-    case 4: t = "64x64";        rc = launch_pipe<64, 64, 2, 2, 16, 4>(d, ks, a.tapmajor != 0, s); break;
-    case 5: t = "128x128k32";   rc = launch_pipe<128, 128, 2, 2, 32, 4>(d, ks, a.tapmajor != 0, s); break;
-    case 6: t = "256x128w8";    rc = launch_pipe<256, 128, 4, 2, 16, 8>(d, ks, a.tapmajor != 0, s); break;
-    case 7: t = "128x256w8";    rc = launch_pipe<128, 256, 2, 4, 16, 8>(d, ks, a.tapmajor != 0, s); break;
-    case 8: t = "256x128w8k32"; rc = launch_pipe<256, 128, 4, 2, 32, 8>(d, ks, a.tapmajor != 0, s); break;
-    case 9: t = "128x128w8";    rc = launch_pipe<128, 128, 4, 2, 16, 8>(d, ks, a.tapmajor != 0, s); break;
-    case 10: t = "128x256w8r";  rc = launch_pipe<128, 256, 4, 2, 16, 8>(d, ks, a.tapmajor != 0, s); break;
-    case 11: t = "256x128w8r";  rc = launch_pipe<256, 128, 8, 1, 16, 8>(d, ks, a.tapmajor != 0, s); break;
-    case 12: t = "128x128r";    rc = launch_pipe<128, 128, 4, 1, 16, 4>(d, ks, a.tapmajor != 0, s); break;
+    case 1: t = "128x128";      rc = launch_pipe<128, 128, 2, 2, 16, 4>(d, ks, a.tapmajor != 0, s, vec4); break;
+    case 2: t = "64x128";       rc = launch_pipe<64, 128, 2, 2, 16, 4>(d, ks, a.tapmajor != 0, s, vec4); break;
+    case 3: t = "32x256";       rc = launch_pipe<32, 256, 1, 4, 16, 4>(d, ks, a.tapmajor != 0, s, vec4); break;
+    case 4: t = "64x64";        rc = launch_pipe<64, 64, 2, 2, 16, 4>(d, ks, a.tapmajor != 0, s, vec4); break;
+    case 5: t = "128x128k32";   rc = launch_pipe<128, 128, 2, 2, 32, 4>(d, ks, a.tapmajor != 0, s, vec4); break;
+    case 6: t = "256x128w8";    rc = launch_pipe<256, 128, 4, 2, 16, 8>(d, ks, a.tapmajor != 0, s, vec4); break;
+    case 7: t = "128x256w8";    rc = launch_pipe<128, 256, 2, 4, 16, 8>(d, ks, a.tapmajor != 0, s, vec4); break;
+    case 8: t = "256x128w8k32"; rc = launch_pipe<256, 128, 4, 2, 32, 8>(d, ks, a.tapmajor != 0, s, vec4); break;
+    case 9: t = "128x128w8";    rc = launch_pipe<128, 128, 4, 2, 16, 8>(d, ks, a.tapmajor != 0, s, vec4); break;
+    case 10: t = "128x256w8r";  rc = launch_pipe<128, 256, 4, 2, 16, 8>(d, ks, a.tapmajor != 0, s, vec4); break;
+    case 11: t = "256x128w8r";  rc = launch_pipe<256, 128, 8, 1, 16, 8>(d, ks, a.tapmajor != 0, s, vec4); break;
+    case 12: t = "128x128r";    rc = launch_pipe<128, 128, 4, 1, 16, 4>(d, ks, a.tapmajor != 0, s, vec4); break;
     default: return (int)hipErrorInvalidValue;
     }
-    if (name) snprintf(name, name_len, "conv_f32_mfma_pipe<%s,ks%d%s>", t, ks, a.tapmajor ? ",tap" : "");
+    if (name) snprintf(name, name_len, "conv_f32_mfma_pipe<%s,ks%d%s%s>", t, ks, a.tapmajor ? ",tap" : "", vec4 ? ",v4" : "");
     return rc;
 }
 
@@ -429,8 +490,10 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
     // layer carries a fused shortcut and is bound by 3 GB of epilogue traffic (2.31 vs 2.2 ms): C >= 64.
     if (a.q_out && a.wino32_u) return (int)hipErrorInvalidValue;      // the planner gives q_out to direct layers only
     if (a.wino32_u && (o.force_tile == 31 || (o.force_tile == 0 && o.winograd && a.C >= 64)))
-        return launch_conv_f32_wino32(a, a.wino32_u, stream, name, name_len);
+        return launch_conv_f32_wino32(a, a.wino32_u, o.variant, stream, name, name_len);
     if (o.force_tile == 31) return (int)hipErrorInvalidValue;   // forced on a layer without packed U
+    if (o.force_tile == 41 || (o.force_tile == 0 && (o.variant & 8) && smallk_applicable(a)))
+        return launch_conv_f32_smallk(a, stream, name, name_len);
     int cfg = o.force_tile >= 10 ? o.force_tile - 10 : 0;
     if (cfg == 0) {
         const long long ntot = (long long)a.B * a.OH * a.OW;
@@ -448,7 +511,7 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
     }
     // BK=32 variants need C % 32 == 0 in tap-major order
     if ((cfg == 5 || cfg == 8) && a.tapmajor) cfg = (cfg == 5) ? 1 : 6;   // tap-major blocks are 16 channels
-    return launch_conv_f32_direct(a, cfg, stream, name, name_len);
+    return launch_conv_f32_direct(a, cfg, o.variant, stream, name, name_len);
 }
 
 }  // namespace yl

@@ -113,8 +113,17 @@ __device__ __forceinline__ void input_transform32(const float (&d)[16], float (&
 
 }  // namespace
 
+// VAR bit 0 (UDMA): the U panels go global -> LDS directly (global_load_lds_dwordx4, the packed panel IS the
+//   lane-linear LDS image): no VGPR round trip, no ds_write for the weights.  The stage a panel lands in was last
+//   read (fragments of panel kb-2) before the barrier the DMA is issued after; every wave drains its own DMAs
+//   (vmcnt(0)) in front of the next barrier, which publishes them.
+// VAR bit 1 (APF): the fused [shortcut] operand of an epilogue round is requested BEFORE the round's LDS exchange
+//   and barrier instead of after them (its HBM latency hides behind the exchange).
+template <int VAR>
 __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p)
 {
+    constexpr bool UDMA = (VAR & 1) != 0;
+    constexpr bool APF = (VAR & 2) != 0;
     __shared__ __attribute__((aligned(16))) float smem[2 * XPA + 2 * XPB];      // 48 KB
     float *As = smem;
     float *Bs = smem + 2 * XPA;
@@ -200,6 +209,15 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
             UR[e][0] = t4.x; UR[e][1] = t4.y; UR[e][2] = t4.z; UR[e][3] = t4.w;                    \
         }                                                                                          \
     }
+#define X_DMA_U(KB, BUF)                                                                           \
+    {                                                                                              \
+        const float4 *src = reinterpret_cast<const float4 *>(u_tile + (size_t)(KB) * XPA);         \
+        float4 *dst = reinterpret_cast<float4 *>(As + (BUF) * XPA);                                \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e)                                              \
+            __builtin_amdgcn_global_load_lds(                                                      \
+                (const __attribute__((address_space(1))) void *)(src + tid + e * 256),             \
+                (__attribute__((address_space(3))) void *)(dst + tid + e * 256), 16, 0, 0);        \
+    }
 #define X_STORE_X(BUF, XR)                                                                             \
     {                                                                                              \
         float va[16];                                                                              \
@@ -251,12 +269,21 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
 
     // ---- prologue: panel 0 -> LDS stage 0 -> fragment set 0; panel 1 -> registers ----
     // (nkb = C/4 is even and >= 4: the launcher requires C % 8 == 0, C >= 16)
-    X_LOAD_X(0, xr)
-    X_LOAD_U(0, ur)
-    X_STORE_X(0, xr)
-    X_STORE_U(0, ur)
-    X_LOAD_X(1, xr)
-    X_LOAD_U(1, ur)
+    if constexpr (UDMA) {
+        X_DMA_U(0, 0)
+        X_DMA_U(1, 1)
+        X_LOAD_X(0, xr)
+        X_STORE_X(0, xr)
+        X_LOAD_X(1, xr)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        X_LOAD_X(0, xr)
+        X_LOAD_U(0, ur)
+        X_STORE_X(0, xr)
+        X_STORE_U(0, ur)
+        X_LOAD_X(1, xr)
+        X_LOAD_U(1, ur)
+    }
     __syncthreads();
     X_READ_FRAGS(0, 0)
 
@@ -274,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
 #define X_ITER(KB, SET, DO_STORE, DO_LOAD)                                                         \
     {                                                                                              \
         const int buf = (KB) & 1;                                                                  \
-        if (DO_STORE && !(X_DBG & 4)) X_STORE_U(buf ^ 1, ur)                                       \
+        if (DO_STORE && !UDMA && !(X_DBG & 4)) X_STORE_U(buf ^ 1, ur)                              \
         if (DO_STORE && !(X_DBG & 4)) X_STORE_X(buf ^ 1, xr)                                       \
         _Pragma("unroll") for (int pp = 0; pp < 8; ++pp)                                           \
             if (!(X_DBG & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][pp].x, fb[SET][pp][0], acc[pp], 0, 0, 0); \
@@ -284,15 +311,17 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
             }                                                                                      \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
+        if (UDMA && DO_STORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
         __syncthreads();                                                                           \
         if (DO_STORE) X_READ_FRAGS((SET) ^ 1, buf ^ 1)                                             \
         if (DO_LOAD && !(X_DBG & 1)) X_LOAD_X((KB) + 2, xr)                                        \
-        if (DO_LOAD && !(X_DBG & 2)) X_LOAD_U((KB) + 2, ur)                                        \
+        if (DO_LOAD && !UDMA && !(X_DBG & 2)) X_LOAD_U((KB) + 2, ur)                               \
+        if (DO_LOAD && UDMA && !(X_DBG & 2)) X_DMA_U((KB) + 2, buf)                                \
         _Pragma("unroll") for (int pp = 0; pp < 8; ++pp)                                           \
             if (!(X_DBG & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][pp].y, fb[SET][pp][1], acc[pp], 0, 0, 0); \
         if (DO_STORE && X_DBG == 0) {                                                              \
             _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                     \
-                X_PIPE(0x100, 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                \
+                X_PIPE(0x100, 2) __builtin_amdgcn_sched_group_barrier(UDMA ? 0x010 : 0x020, 1, 0); \
             }                                                                                      \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
@@ -310,6 +339,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
 #undef X_ITER
 #undef X_PIPE
 #undef X_STORE_U
+#undef X_DMA_U
 #undef X_STORE_X
 #undef X_LOAD_U
 #undef X_LOAD_X
@@ -333,6 +363,33 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     const float *theirs = xch + (wave ^ 2) * 2048 + lane;
 #pragma unroll
     for (int rnd = 0; rnd < 2; ++rnd) {
+        float apf[4][2][2];
+        if constexpr (APF) {
+            if (p.add) {
+#pragma unroll
+                for (int ee = 0; ee < 4; ++ee) {
+                    const int e = 8 * rnd + (ph ? 4 + ee : ee);
+                    const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) apf[ee][i][0] = apf[ee][i][1] = 0.f;
+                    if (m < p.M && t_ok_e) {
+                        const size_t o0 = (((size_t)b_e * p.M + m) * p.H + oy) * p.W + ox;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            if (i == 1 && !row1) break;
+                            const size_t o = o0 + (size_t)i * p.W;
+                            if (vec2) {
+                                const float2 a = *reinterpret_cast<const float2 *>(p.add + o);
+                                apf[ee][i][0] = a.x; apf[ee][i][1] = a.y;
+                            } else {
+                                apf[ee][i][0] = p.add[o];
+                                if (col1) apf[ee][i][1] = p.add[o + 1];
+                            }
+                        }
+                    }
+                }
+            }
+        }
         // send: ph 1 gives (M2, M2 + M3) of rows e = 8*rnd .. +3; ph 0 gives (M0 + M1, M1) of e = 8*rnd+4 .. +7
 #pragma unroll
         for (int ee = 0; ee < 4; ++ee) {
@@ -382,15 +439,17 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
                     if (vec2) {
                         if (p.out) *reinterpret_cast<float2 *>(p.out + o) = make_float2(y[i][0], y[i][1]);
                         if (p.add) {
-                            const float2 a = *reinterpret_cast<const float2 *>(p.add + o);
+                            float2 a;
+                            if constexpr (APF) a = make_float2(apf[ee][i][0], apf[ee][i][1]);
+                            else a = *reinterpret_cast<const float2 *>(p.add + o);
                             *reinterpret_cast<float2 *>(p.out_add + o) =
                                 make_float2(__fadd_rn(y[i][0], a.x), __fadd_rn(y[i][1], a.y));
                         }
                     } else {
                         if (p.out) { p.out[o] = y[i][0]; if (col1) p.out[o + 1] = y[i][1]; }
                         if (p.add) {
-                            p.out_add[o] = __fadd_rn(y[i][0], p.add[o]);
-                            if (col1) p.out_add[o + 1] = __fadd_rn(y[i][1], p.add[o + 1]);
+                            p.out_add[o] = __fadd_rn(y[i][0], APF ? apf[ee][i][0] : p.add[o]);
+                            if (col1) p.out_add[o + 1] = __fadd_rn(y[i][1], APF ? apf[ee][i][1] : p.add[o + 1]);
                         }
                     }
                 }
@@ -446,7 +505,7 @@ void wino32_pack_weights(const float *w, int C, int M, float *dst)
         }
 }
 
-int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, void *stream, char *name, size_t name_len)
+int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, int variant, void *stream, char *name, size_t name_len)
 {
     if (!wino_applicable(a.C, a.M, a.size, a.stride, a.pad) || a.OH != a.H || a.OW != a.W || a.H < 4 || a.W < 4)
         return (int)hipErrorInvalidValue;
@@ -464,8 +523,15 @@ int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, void *st
     d.act = a.act;
     const long long blocks = (long long)d.tiles_m * d.tiles_t;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(conv_f32_wino32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d);
-    if (name) snprintf(name, name_len, "conv_f32_wino<32x64t,f2x2>");
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (variant & 3) {
+    case 0: hipLaunchKernelGGL(conv_f32_wino32_kernel<0>, grid, block, 0, s, d); break;
+    case 1: hipLaunchKernelGGL(conv_f32_wino32_kernel<1>, grid, block, 0, s, d); break;
+    case 2: hipLaunchKernelGGL(conv_f32_wino32_kernel<2>, grid, block, 0, s, d); break;
+    default: hipLaunchKernelGGL(conv_f32_wino32_kernel<3>, grid, block, 0, s, d); break;
+    }
+    if (name) snprintf(name, name_len, "conv_f32_wino<32x64t,f2x2%s%s>", (variant & 1) ? ",udma" : "", (variant & 2) ? ",apf" : "");
     return (int)hipGetLastError();
 }
 

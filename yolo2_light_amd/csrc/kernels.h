@@ -6,6 +6,8 @@
 
 namespace yl {
 
+constexpr int YL_VARIANT_DEFAULT = 0;
+
 // ---- K1: FP32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 ----
 struct ConvF32Args {
     const float *in;      // [B][C][H][W]
@@ -27,8 +29,12 @@ struct ConvF32Args {
 // per-network kernel-selection knobs (snapshotted in Network: two networks driven from two host
 // threads, one per GPU, share no mutable launch state)
 struct ConvF32Opts {
-    int force_tile = 0;   // 0 = heuristic, 11..22 = direct tile 1..12, 31 = Winograd (tuning / tests)
+    int force_tile = 0;   // 0 = heuristic, 11..22 = direct tile 1..12, 31 = Winograd, 41 = small-K first-layer kernel (tuning / tests)
     int winograd = 1;     // Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 layers with C >= 64
+    // schedule variants kept switchable for same-box A/B runs (yl_network_set_variant): bit 0 Winograd U panels by
+    // LDS-DMA, bit 1 Winograd epilogue requests the [shortcut] operand ahead of its LDS exchange, bit 2 1x1 direct
+    // kernel loads the B panel as float4 rows, bit 3 LDS-free small-K kernel for the first layer (C*size^2 <= 32)
+    int variant = YL_VARIANT_DEFAULT;
 };
 // writes the name of the kernel instance it launched into name[name_len]
 int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, char *name, size_t name_len);
@@ -37,7 +43,10 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
 bool wino_applicable(int C, int M, int size, int stride, int pad);
 size_t wino32_packed_floats(int C, int M);
 void wino32_pack_weights(const float *w, int C, int M, float *dst);
-int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, void *stream, char *name, size_t name_len);
+// K1s (conv_f32_smallk.hip): LDS-free kernel for first layers (C*size^2 <= 32, filters <= 32)
+bool smallk_applicable(const ConvF32Args &a);
+int launch_conv_f32_smallk(const ConvF32Args &a, void *stream, char *name, size_t name_len);
+int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, int variant, void *stream, char *name, size_t name_len);
 
 // ---- K2: INT8 path ----
 // K2a: x_q = clamp_abs((int16)(x*mult), 127), FP32 NCHW -> int8 NHWC(Cpad)   (quantized.c:554-560)

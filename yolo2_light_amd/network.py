@@ -181,6 +181,9 @@ class Network:
     def set_conv_tile(self, cfg: int) -> None:
         check(lib.yl_network_set_conv_tile(self._h, cfg), "yl_network_set_conv_tile")
 
+    def set_variant(self, bits: int) -> None:
+        check(lib.yl_network_set_variant(self._h, bits), "yl_network_set_variant")
+
     def set_int8_tile(self, cfg: int) -> None:
         check(lib.yl_network_set_int8_tile(self._h, cfg), "yl_network_set_int8_tile")
 
