@@ -47,6 +47,7 @@ sys.path.insert(0, ROOT)
 
 # /opt/skills/guides/MI355X_MICROARCH.md
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # "Peak FP32 (matrix)": v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA
 INT8_MFMA_PEAK_TOPS = 5000.0        # i8 MFMA = 2x the bf16 rate (~2.5 PF dense): 2048 op/clk/SIMD; ubench 4404
 HBM_PEAK_GBS = 8000.0               # HBM3E spec; 6.29 TB/s measured for a float4 copy
 VALU_POPC_PEAK_TBITMAC = 629.0      # XNOR: one v_xnor + one v_bcnt per 32 bit-MACs, 32 lanes/clk/SIMD, 2.4 GHz
@@ -61,7 +62,7 @@ def parse_args():
     ap.add_argument("--size", type=int, default=608)
     ap.add_argument("--batch", type=int, default=64, help="GLOBAL batch (strong scaling) / images per GPU (weak)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
-    ap.add_argument("--mode", default="both", choices=["both", "fp32", "int8"],
+    ap.add_argument("--mode", default="both", choices=["both", "fp32", "int8", "bf16"],
                     help="both = FP32 leg as `value` + INT8 leg under \"int8\"; fp32 / int8 = that leg only as `value`")
     ap.add_argument("--thresh", type=float, default=0.24)
     ap.add_argument("--cap", type=int, default=1024, help="detection records per image")
@@ -224,7 +225,9 @@ class Leg:
         self.args, self.torch, self.dist = args, torch, dist
         self.quantized, self.B, self.world, self.use_dist = quantized, b_local, world, use_dist
         self.stream = stream
-        self.net = Network.load(cfg, wts, b_local, quantized, device=dev.index, fuse=not args.no_fuse)
+        # quantized: 0 FP32, 1 -quantized INT8, 2 the opt-in BF16 variant of the FP32 path
+        self.net = Network.load(cfg, wts, b_local, 1 if quantized == 1 else 0, device=dev.index, fuse=not args.no_fuse,
+                                bf16=(quantized == 2))
         self.net.set_stream(stream.cuda_stream)
         if args.tile:
             self.net.set_conv_tile(args.tile)
@@ -384,9 +387,10 @@ def fp32_roofline(leg, args):
     }
 
 
-def int8_roofline(leg):
+def int8_roofline(leg, prefix="conv_i8", mfma_peak=None, what="int8"):
+    mfma_peak = mfma_peak or INT8_MFMA_PEAK_TOPS
     kern = leg.kernels()
-    i8 = {n: k for n, k in kern.items() if n.startswith("conv_i8")}
+    i8 = {n: k for n, k in kern.items() if n.startswith(prefix)}
     if not i8:
         return None
     dom_name = max(i8, key=lambda n: i8[n]["ms"])
@@ -401,10 +405,10 @@ def int8_roofline(leg):
     return {
         "bound": "hbm", "kernel": dom_name,
         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-        "achieved_is": "algorithmic bytes (int8 in, weights, FP32 [shortcut] operand in / sum out, int8 side output; "
-                       "yl_network_layer_traffic) of the kernel's launches / their measured duration",
+        "achieved_is": "algorithmic bytes (%s in, weights, FP32 [shortcut] operand in / sum out, %s side output; "
+                       "yl_network_layer_traffic) of the kernel's launches / their measured duration" % (what, what),
         "traffic": None, "traffic_source": "see profiles/r2_pmc_int8_*.txt (own rocprofv3 passes)",
-        "mfma_tops": tops, "mfma_peak_tops": INT8_MFMA_PEAK_TOPS, "mfma_frac": tops / INT8_MFMA_PEAK_TOPS,
+        "mfma_tops": tops, "mfma_peak_tops": mfma_peak, "mfma_frac": tops / mfma_peak,
         "algorithmic_bytes_per_launch": dom["bytes"] / n, "launches_per_step": dom["launches"],
         "avg_launch_ms": dom["ms"] / n,
         "all_int8_conv_gbs": tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0,
@@ -587,6 +591,8 @@ def main():
     xnor_model = args.model == "tiny-yolo-xnor"
     do_fp32 = args.mode in ("both", "fp32")
     do_int8 = args.mode in ("both", "int8") and not xnor_model
+    # the opt-in BF16 variant: its own mode, or an extra leg of the default line (reported under "bf16", never `value`)
+    do_bf16 = (args.mode == "bf16" or (args.mode == "both" and not args.no_extras and world == 1)) and not xnor_model
     cfg_q = cfg
     if do_int8 and not args.no_extras:
         try:
@@ -610,8 +616,8 @@ def main():
 
     result = {}
     rows_fp32 = heads_fp32 = None
-    for quantized in ([0] if do_fp32 else []) + ([1] if do_int8 else []):
-        leg = Leg(args, torch, dist, dev, stream, Network, cfg_q if quantized else cfg, wts, quantized, b_local,
+    for quantized in ([0] if do_fp32 else []) + ([1] if do_int8 else []) + ([2] if do_bf16 else []):
+        leg = Leg(args, torch, dist, dev, stream, Network, cfg_q if quantized == 1 else cfg, wts, quantized, b_local,
                   world, use_dist)
         elapsed = leg.run(x, args.steps, args.warmup)
         info = {"value": args.global_batch * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3}
@@ -621,6 +627,8 @@ def main():
             info["detect_ms_per_step"] = leg.post_ms()
             if xnor_model:
                 info["roofline"] = xnor_roofline(leg)
+            elif quantized == 2:
+                info["roofline"] = int8_roofline(leg, "conv_bf16", BF16_MFMA_PEAK_TFLOPS, "bf16")
             elif quantized:
                 info["roofline"] = int8_roofline(leg)
             else:
@@ -646,9 +654,13 @@ def main():
                             "synthetic i.i.d. weights: quantisation noise is not damped the way a trained detector damps "
                             "it; the number describes this workload, the kernels are bit-exact against the reference's "
                             "-quantized CPU path (tests/test_gpu_headline.py)")
-                        info["agreement_vs_fp32"]["input_calibration"] = (
-                            "recomputed for the synthetic weights with yl_network_calibrate (4 synthetic images)"
-                            if cfg_q != cfg else "the cfg's shipped list")
+                        if quantized == 1:
+                            info["agreement_vs_fp32"]["input_calibration"] = (
+                                "recomputed for the synthetic weights with yl_network_calibrate (4 synthetic images)"
+                                if cfg_q != cfg else "the cfg's shipped list")
+                        else:
+                            info["agreement_vs_fp32"]["note"] = (
+                                "opt-in BF16 operands (nearest even), FP32 accumulation: outside the FP32 path's 1e-4 contract")
                     elif not quantized:
                         rows_fp32, heads_fp32 = rows, heads
                 except Exception as ex:
@@ -658,7 +670,7 @@ def main():
                     info["pcie_inclusive"] = pcie_inclusive(leg.net, torch, stream, args, b_local, leg.rec, leg.cnt)
                 except Exception as ex:      # the headline number must not depend on this leg
                     info["pcie_inclusive"] = {"error": repr(ex)}
-        result["int8" if quantized else "fp32"] = info
+        result[("fp32", "int8", "bf16")[quantized]] = info
         leg.close()
 
     if rank == 0:
@@ -682,9 +694,11 @@ def main():
                         cpu["int8"] = {k: q[k] for k in ("value", "sample")}
             except Exception as e:      # the baseline is reported, never required
                 cpu = {"error": repr(e)}
-        head = result["fp32"] if do_fp32 else result["int8"]
-        dtype = "f32" if do_fp32 else "i8"
+        head = result["fp32"] if do_fp32 else (result["int8"] if do_int8 else result["bf16"])
+        dtype = "f32" if do_fp32 else ("i8" if do_int8 else "bf16")
         modes = ("FP32" if do_fp32 else "") + (" & INT8" if do_fp32 and do_int8 else ("INT8" if do_int8 else ""))
+        if not do_fp32 and not do_int8:
+            modes = "BF16 (opt-in)"
         if xnor_model:
             dtype, modes = "u1", "BIT1-XNOR"      # 1-bit operands (64-bit packed words), FP32 first/last layer
         out = {
@@ -700,7 +714,7 @@ def main():
                                    "HBM, forward + on-device detection decode/compaction + NMS%s; `value` = the %s leg" % (
                                        args.model, args.size, args.size, args.global_batch, b_local, modes,
                                        " + RCCL all-gather of detections" if use_dist else "",
-                                       ("BIT1-XNOR" if xnor_model else "FP32") if do_fp32 else "INT8"),
+                                       ("BIT1-XNOR" if xnor_model else "FP32") if do_fp32 else ("INT8" if do_int8 else "BF16")),
                        "global_batch": args.global_batch,
                        "parallelism": "image-batch sharding x%d (%s scaling)" % (world, args.scaling),
                        "gflop_per_image": head.get("gflop_per_image")},
@@ -716,6 +730,13 @@ def main():
                                                   "detections_per_image", "detect_ms_per_step")}
             out["int8"]["unit"] = "images/sec"
             out["int8"]["speedup_vs_fp32"] = i8["value"] / head["value"]
+        if do_bf16 and (do_fp32 or do_int8):
+            b16 = result["bf16"]
+            out["bf16"] = {k: b16.get(k) for k in ("value", "ms_per_step", "roofline", "agreement_vs_fp32",
+                                                   "detections_per_image", "detect_ms_per_step")}
+            out["bf16"]["unit"] = "images/sec"
+            out["bf16"]["what"] = ("opt-in: yl_network_set_precision(BF16) -- bf16 operands on v_mfma_f32_32x32x16_bf16, "
+                                   "FP32 accumulate; outside the 1e-4 contract, never `value`")
         out.update(extras)
         print(json.dumps(out))
     if use_dist:

@@ -269,8 +269,17 @@ int yl_network_pull_heads(yl_network *net);
 int yl_network_set_conv_tile(yl_network *net, int cfg);
 /* schedule variants of the FP32 kernels kept switchable for same-box A/B measurements (results are identical):
  * bit 0 Winograd U panels by LDS-DMA, bit 1 Winograd epilogue prefetches the fused [shortcut] operand,
- * bit 2 float4 B-panel rows in the 1x1 direct kernel, bit 3 LDS-free first-layer kernel; -1 = built-in default */
+ * bit 2 float4 B-panel rows in the 1x1 direct kernel, bit 3 LDS-free first-layer kernel, bit 4 Winograd from 32
+ * input channels up; -1 = built-in default */
 int yl_network_set_variant(yl_network *net, int bits);
+/* Opt-in BF16 variant of the FP32 path (north_star (a) "FP32/BF16"; BEFORE yl_network_to_device): every FP32
+ * convolution whose input has whole 8-channel groups runs on v_mfma_f32_32x32x16_bf16 with both operands rounded
+ * to bf16 (nearest even) and FP32 accumulation / bias / activation (conv_bf16_mfma.hip); tensors between layers
+ * stay FP32 wherever a [route]/[shortcut]/head reads them.  NOT inside the 1e-4 contract of the FP32 path
+ * (operand rounding ~2^-9 relative): default is YL_PRECISION_FP32. */
+#define YL_PRECISION_FP32 0
+#define YL_PRECISION_BF16 1
+int yl_network_set_precision(yl_network *net, int precision);
 /* the same for the INT8 convolution (conv_i8_mfma.hip): 0 = heuristic, 1 = 64x128, 2 = 32x256, 3 = 128x128,
  * 4 = 128x256 (8 waves), 5 = 64x256 */
 int yl_network_set_int8_tile(yl_network *net, int cfg);

@@ -402,3 +402,23 @@ def test_xnor_sign_domain_fusion_is_bit_identical(name, width, height, batch):
     for b in range(batch):
         assert np.array_equal(plain.get_boxes(b, width, height, 0.05, nms=0.4), fused.get_boxes(b, width, height, 0.05, nms=0.4))
     plain.close(); fused.close()
+
+
+@pytest.mark.parametrize("width,height,batch", [(64, 48, 2), (96, 96, 3)])
+def test_xnor_conv_shortcut_fusion_is_bit_identical(width, height, batch):
+    """conv(xnor, bit path) + [shortcut] folded into one kernel, as the reference GPU path does
+    (src/additionally.c:326-339): the shortcut tensor and everything behind it equal the unfused run bit for bit."""
+    cfg, wts = _mixed_xnor_files(width, height)
+    x = common.seeded_input(batch, 3, height, width)
+    plain = Network.load(cfg, wts, batch, 0, device=0)
+    fused = Network.load(cfg, wts, batch, 0, device=0, fuse=True)
+    plain.predict(x)
+    fused.predict(x)
+    infos = plain.layers()
+    sc = [i for i, li in enumerate(infos) if li["type"] == common.SHORTCUT]
+    assert len(sc) == 1 and "xnor" in fused.layer_kernel(sc[0] - 1)
+    assert not fused.layer_materialised(sc[0] - 1)          # the conv's own tensor is not written
+    for i in range(sc[0], plain.n):
+        if fused.layer_materialised(i):
+            assert np.array_equal(plain.layer_output(i).view(np.uint32), fused.layer_output(i).view(np.uint32)), i
+    plain.close(); fused.close()

@@ -489,7 +489,7 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
     // ([64,288,92416]) Winograd wins stand-alone (1.59 vs 2.16 ms) but not in the network, where the
     // layer carries a fused shortcut and is bound by 3 GB of epilogue traffic (2.31 vs 2.2 ms): C >= 64.
     if (a.q_out && a.wino32_u) return (int)hipErrorInvalidValue;      // the planner gives q_out to direct layers only
-    if (a.wino32_u && (o.force_tile == 31 || (o.force_tile == 0 && o.winograd && a.C >= 64)))
+    if (a.wino32_u && (o.force_tile == 31 || (o.force_tile == 0 && o.winograd && a.C >= ((o.variant & 16) ? 32 : 64))))
         return launch_conv_f32_wino32(a, a.wino32_u, o.variant, stream, name, name_len);
     if (o.force_tile == 31) return (int)hipErrorInvalidValue;   // forced on a layer without packed U
     if (o.force_tile == 41 || (o.force_tile == 0 && (o.variant & 8) && smallk_applicable(a)))

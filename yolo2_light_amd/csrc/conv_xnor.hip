@@ -150,7 +150,9 @@ struct ConvXnorDev {
     const uint64_t *w_bits;
     const float *mean;
     const float *bias;
-    float *out;               // FP32 output, or nullptr when only the sign words are wanted
+    float *out;               // FP32 output, or nullptr when only the sign words / the fused sum are wanted
+    const float *add;         // fused [shortcut] operand (same shape as the output) or nullptr
+    float *out_add;
     uint64_t *out_bits;       // sign words of the activation for a following XNOR layer, or nullptr
     int32_t *dbg;
     int B, C, Cw, H, W, M, act;
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(256) void conv_xnor_kernel(ConvXnorDev p)
             v = __fadd_rn(v, p.bias[m]);
             if (p.act == YL_LEAKY) v = (v > 0.f) ? v : (float)(.1 * (double)v);
             if (p.out) p.out[oi] = v;
+            if (p.add) p.out_add[oi] = __fadd_rn(v, p.add[oi]);       // shortcut_cpu: out = add + conv, linear
             // bit = (x > 0) of the value the next layer would read (src/additionally.c:132,1544)
             if (f < 32) sign_lo |= (v > 0.f ? 1u : 0u) << f;
             else sign_hi |= (v > 0.f ? 1u : 0u) << (f - 32);
@@ -332,6 +335,7 @@ int launch_conv_xnor(const ConvXnorArgs &a, void *stream)
 {
     ConvXnorDev d;
     d.in_bits = a.in_bits; d.w_bits = a.w_bits; d.mean = a.mean; d.bias = a.bias; d.out = a.out; d.dbg = a.dbg;
+    d.add = a.add; d.out_add = a.out_add;
     d.out_bits = a.out_bits; d.out_Cw = (a.M + 63) / 64;
     d.B = a.B; d.C = a.C; d.Cw = a.Cw; d.H = a.H; d.W = a.W; d.M = a.M; d.act = a.act;
     d.HW = a.H * a.W;

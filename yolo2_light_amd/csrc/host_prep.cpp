@@ -152,6 +152,8 @@ void select_conv_modes(Network &net) {
         // forward_convolutional_layer_cpu: `l.xnor && l.align_bit_weights && stride==1 && pad==1`
         // (yolov2_forward_network.c:116)
         else if (l.xnor && l.stride == 1 && l.pad == 1 && l.size == 3) l.conv_mode = CONV_XNOR;
+        // opt-in (yl_network_set_precision): FP32 convolutions with whole 8-channel groups take bf16 operands
+        else if (net.precision == YL_PRECISION_BF16 && !l.xnor && (l.c % 8) == 0 && l.size <= 5) l.conv_mode = CONV_BF16;
         else l.conv_mode = CONV_F32;
     }
 }

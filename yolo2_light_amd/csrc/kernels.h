@@ -6,7 +6,7 @@
 
 namespace yl {
 
-constexpr int YL_VARIANT_DEFAULT = 0;
+constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8;      // measured on MI355X, profiles/r2_ab_fp32_variants.txt: bit 1 +3.3 %, bit 2 +0.4 %, bit 3 +0.6 %, bit 0 -0.5 %
 
 // ---- K1: FP32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 ----
 struct ConvF32Args {
@@ -33,7 +33,8 @@ struct ConvF32Opts {
     int winograd = 1;     // Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 layers with C >= 64
     // schedule variants kept switchable for same-box A/B runs (yl_network_set_variant): bit 0 Winograd U panels by
     // LDS-DMA, bit 1 Winograd epilogue requests the [shortcut] operand ahead of its LDS exchange, bit 2 1x1 direct
-    // kernel loads the B panel as float4 rows, bit 3 LDS-free small-K kernel for the first layer (C*size^2 <= 32)
+    // kernel loads the B panel as float4 rows, bit 3 LDS-free small-K kernel for the first layer (C*size^2 <= 32),
+    // bit 4 Winograd from 32 input channels up (default: from 64)
     int variant = YL_VARIANT_DEFAULT;
 };
 // writes the name of the kernel instance it launched into name[name_len]
@@ -73,6 +74,25 @@ struct ConvI8Args {
 // tile: 0 = heuristic, 1..5 see conv_i8_mfma.hip (tuning / tests); writes the kernel instance name
 int launch_conv_i8(const ConvI8Args &a, int tile, void *stream, char *name, size_t name_len);
 
+// ---- K1b: opt-in BF16 variant of the FP32 path (conv_bf16_mfma.hip) ----
+// FP32 NCHW -> bf16 units act_h[B][Cpad/8][H][W][8] (round to nearest even); (g_off, G_total) as launch_quantize_nhwc
+int launch_pack_bf16(const float *in, void *out, int B, int C, int H, int W, int Cpad, void *stream,
+                     int g_off = 0, int G_total = 0);
+struct ConvBf16Args {
+    const void *in_h;     // act_h[B][Cpad/8][H][W][8] bf16
+    const void *w_h;      // [K8pad][Mpad][8] bf16, K8 = tap * (Cpad/8) + channel group
+    const float *bias;    // [M]
+    float *out;           // [B][M][OH][OW] FP32; may be nullptr when only out_add / h_out is wanted
+    const float *add;     // optional fused [shortcut] (see ConvF32Args)
+    float *out_add;
+    void *h_out;          // optional bf16 side output for the next BF16 conv: act_h[B][h_G][OH][OW][8]
+    int h_G;              // the next layer's channel groups (Cpad/8)
+    int B, Cpad, H, W, M, Mpad, OH, OW;
+    int size, stride, pad;
+    int act;
+};
+int launch_conv_bf16(const ConvBf16Args &a, int tile, void *stream, char *name, size_t name_len);
+
 // ---- K3: XNOR path ----
 // K3a: sign bits of FP32 NCHW packed along channels -> [B][H][W][Cw] 64-bit words, bit = (x > 0)
 int launch_pack_sign_bits(const float *in, uint64_t *out, int B, int C, int H, int W, int Cw, void *stream);
@@ -81,7 +101,9 @@ struct ConvXnorArgs {
     const uint64_t *w_bits;   // [Mpad/2][Cw][2][9] (filter pairs interleaved per channel word); channel-pad bits = 1
     const float *mean;        // [M]
     const float *bias;        // [M]
-    float *out;               // [B][M][H][W], or nullptr when only out_bits is wanted
+    float *out;               // [B][M][H][W], or nullptr when only out_bits / out_add is wanted
+    const float *add = nullptr;     // optional fused [shortcut]: out_add = act(conv) + add (the reference GPU path fuses
+    float *out_add = nullptr;       // the same pair, src/additionally.c:326-339)
     uint64_t *out_bits = nullptr;   // optional sign words of the result for a following XNOR layer: [B][ceil(M/64)][H][W]
     int32_t *dbg;             // optional match counts
     int B, C, Cw, H, W, M, Mpad;

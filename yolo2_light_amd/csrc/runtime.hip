@@ -44,6 +44,15 @@ void set_error(const std::string &msg) { g_err = msg; }
     } while (0)
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// float -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does to the activations on the device)
+static inline uint16_t f32_to_bf16_rne(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);      // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
 
 static void free_device(Network &net)
 {
@@ -166,6 +175,26 @@ static int upload_conv(Network &net, Layer &l)
         YL_HIP(hipMemcpy(l.d_weights_i8, wq.data(), wq.size(), hipMemcpyHostToDevice));
         const size_t qb = (size_t)net.batch * l.h * l.w * l.Cpad;
         if (qb > net.qbuf_bytes) net.qbuf_bytes = qb;
+    } else if (l.conv_mode == CONV_BF16) {
+        // the INT8 layout with 8 bf16 channels per 16-byte unit: [K8pad][Mpad][8], K8 index = tap*G + cg
+        const int taps = l.size * l.size;
+        int G = 1;
+        while (G * 8 < l.c) G *= 2;
+        l.Cpad = G * 8;
+        l.Mpad = round_up(M, 128);
+        const int K8 = taps * G;
+        const int K8pad = round_up(K8, 8);
+        std::vector<uint16_t> wh((size_t)K8pad * l.Mpad * 8, 0);
+        for (int m = 0; m < M; ++m)
+            for (int c = 0; c < l.c; ++c)
+                for (int t = 0; t < taps; ++t) {
+                    const int g = t * G + c / 8;
+                    wh[((size_t)g * l.Mpad + m) * 8 + (c % 8)] = f32_to_bf16_rne(l.weights[((size_t)m * l.c + c) * taps + t]);
+                }
+        YL_HIP(hipMalloc((void **)&l.d_weights_i8, wh.size() * sizeof(uint16_t)));
+        YL_HIP(hipMemcpy(l.d_weights_i8, wh.data(), wh.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        const size_t qb = (size_t)net.batch * l.h * l.w * l.Cpad * 2;
+        if (qb > net.qbuf_bytes) net.qbuf_bytes = qb;
     } else {   // CONV_XNOR
         if (!l.xnor_ready) { set_error("XNOR layer without yl_network_calculate_binary_weights()"); return YL_ERR_STATE; }
         // 64-bit sign words along channels, filter pairs interleaved: [Mpad/2][Cw][2][9]; bit = (w > 0) (src/additionally.c:123,1544);
@@ -193,7 +222,7 @@ static int upload_conv(Network &net, Layer &l)
         if (ob > bb) bb = ob;
         if (bb > net.bitbuf_bytes) net.bitbuf_bytes = bb;
     }
-    if (net.debug && l.conv_mode != CONV_F32) {
+    if (net.debug && l.conv_mode != CONV_F32 && l.conv_mode != CONV_BF16) {
         YL_HIP(hipMalloc((void **)&l.d_debug, sizeof(int32_t) * (size_t)net.batch * l.outputs));
     }
     return YL_OK;
@@ -258,7 +287,7 @@ static int to_device(Network &net, int device)
         for (int i = 1; i < nl; ++i) {
             Layer &sc = net.layers[i];
             Layer &cv = net.layers[i - 1];
-            if (sc.type != YL_SHORTCUT || cv.type != YL_CONVOLUTIONAL || cv.conv_mode == CONV_XNOR) continue;
+            if (sc.type != YL_SHORTCUT || cv.type != YL_CONVOLUTIONAL) continue;
             if (sc.activation != YL_LINEAR) continue;
             if (!(sc.w == sc.out_w && sc.h == sc.out_h && sc.c == sc.out_c)) continue;   // same-shape add only
             if (sc.index == i - 1) continue;
@@ -296,7 +325,8 @@ static int to_device(Network &net, int device)
         };
         for (int j = 1; j < nl; ++j) {
             Layer &cons = net.layers[j];
-            if (cons.type != YL_CONVOLUTIONAL || cons.conv_mode != CONV_INT8) continue;
+            if (cons.type != YL_CONVOLUTIONAL || !(cons.conv_mode == CONV_INT8 || cons.conv_mode == CONV_BF16)) continue;
+            const int uc = cons.conv_mode == CONV_BF16 ? 8 : 16;            // channels per 16-byte unit
             // the tensor layer j consumes is the output of layer j-1
             int prod = j - 1;                                  // layer whose kernel writes that tensor
             const Layer &in_l = net.layers[j - 1];
@@ -305,12 +335,12 @@ static int to_device(Network &net, int device)
             if (pl.type != YL_CONVOLUTIONAL) continue;
             // producer kernels with a quantise-on-store epilogue: K2, and K1's direct kernel (never a layer
             // Winograd could take, never the xnor FP32 fallback): yolov3's layer 0 stops writing 3 GB of FP32
-            const bool f32_direct = pl.conv_mode == CONV_F32 && !pl.xnor &&
+            const bool f32_direct = cons.conv_mode == CONV_INT8 && pl.conv_mode == CONV_F32 && !pl.xnor &&
                                     !wino_applicable(pl.c, pl.n, pl.size, pl.stride, pl.pad);
-            if (pl.conv_mode != CONV_INT8 && !f32_direct) continue;
+            if (pl.conv_mode != cons.conv_mode && !f32_direct) continue;
             if (prod == j - 1 && pl.fused_shortcut >= 0) continue;
             if (pl.q_out_layer >= 0) continue;
-            if ((pl.n % 16) != 0 || cons.Cpad != pl.n) continue;          // no padded channel groups
+            if ((pl.n % uc) != 0 || cons.Cpad != pl.n) continue;          // no padded channel groups
             pl.q_out_layer = j;
             cons.q_from_producer = true;
             if (prod == j - 1) pl.skip_f32_out = !referenced_elsewhere(prod, j);
@@ -320,12 +350,13 @@ static int to_device(Network &net, int device)
         for (int j = 1; j < nl; ++j) {
             Layer &cons = net.layers[j];
             Layer &rt = net.layers[j - 1];
-            if (cons.type != YL_CONVOLUTIONAL || cons.conv_mode != CONV_INT8 || cons.q_from_producer) continue;
+            if (cons.type != YL_CONVOLUTIONAL || !(cons.conv_mode == CONV_INT8 || cons.conv_mode == CONV_BF16) || cons.q_from_producer) continue;
+            const int uc = cons.conv_mode == CONV_BF16 ? 8 : 16;
             if (rt.type != YL_ROUTE || rt.d_output_alias || rt.n < 2 || referenced_elsewhere(j - 1, j)) continue;
-            bool ok = (cons.c % 16) == 0;
+            bool ok = (cons.c % uc) == 0 && cons.Cpad == cons.c;
             for (int k = 0; k < rt.n && ok; ++k) {
                 const Layer &src = net.layers[rt.input_layers[k]];
-                ok = (src.out_c % 16) == 0 && src.out_w == cons.w && src.out_h == cons.h &&
+                ok = (src.out_c % uc) == 0 && src.out_w == cons.w && src.out_h == cons.h &&
                      !(src.type == YL_CONVOLUTIONAL && (src.fused_shortcut >= 0 || src.skip_f32_out));
             }
             if (!ok) continue;
@@ -443,6 +474,35 @@ static int forward_layer(Network &net, size_t i, const float *input)
             // float ALPHA1 = R_MULT / (l.input_quant_multipler * l.weights_quant_multipler);  (quantized.c:596)
             a.alpha1 = 32 / (l.input_quant_multipler * l.weights_quant_multipler);
             YL_LAUNCH(launch_conv_i8(a, net.i8_tile, s, l.kernel_name, sizeof(l.kernel_name)), "conv_i8");
+        } else if (l.conv_mode == CONV_BF16) {
+            int8_t *h_in = net.d_qbuf + (i % 3) * net.qbuf_bytes;
+            if (l.q_from_route) {
+                const Layer &rt = net.layers[i - 1];
+                int g_off = 0;
+                for (int k = 0; k < rt.n; ++k) {
+                    const Layer &src = net.layers[rt.input_layers[k]];
+                    YL_LAUNCH(launch_pack_bf16(src.d_output, h_in, B, src.out_c, l.h, l.w, src.out_c, s, g_off, l.Cpad / 8), "pack_bf16_route");
+                    g_off += src.out_c / 8;
+                }
+            } else if (!l.q_from_producer)
+                YL_LAUNCH(launch_pack_bf16(input, h_in, B, l.c, l.h, l.w, l.Cpad, s), "pack_bf16");
+            ConvBf16Args a;
+            a.in_h = h_in; a.w_h = l.d_weights_i8; a.bias = l.d_biases;
+            a.out = l.skip_f32_out ? nullptr : l.d_output;
+            a.add = nullptr; a.out_add = nullptr; a.h_out = nullptr; a.h_G = 0;
+            if (l.fused_shortcut >= 0) {
+                Layer &sc = net.layers[l.fused_shortcut];
+                a.add = net.layers[sc.index].d_output;
+                a.out_add = sc.d_output;
+                a.out = nullptr;
+            }
+            if (l.q_out_layer >= 0) {
+                a.h_out = net.d_qbuf + (l.q_out_layer % 3) * net.qbuf_bytes;
+                a.h_G = net.layers[l.q_out_layer].Cpad / 8;
+            }
+            a.B = B; a.Cpad = l.Cpad; a.H = l.h; a.W = l.w; a.M = l.n; a.Mpad = l.Mpad; a.OH = l.out_h; a.OW = l.out_w;
+            a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
+            YL_LAUNCH(launch_conv_bf16(a, net.i8_tile, s, l.kernel_name, sizeof(l.kernel_name)), "conv_bf16");
         } else {
             auto ring = [&](int slot) { return net.d_bitbuf + (size_t)(slot % 3) * (net.bitbuf_bytes / sizeof(uint64_t)); };
             uint64_t *in_bits = ring((int)i);
@@ -452,6 +512,12 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.in_bits = in_bits; a.w_bits = l.d_weights_bits; a.mean = l.d_mean; a.bias = l.d_biases;
             a.out = l.skip_f32_out ? nullptr : l.d_output; a.dbg = l.d_debug;
             a.out_bits = l.bits_out_slot >= 0 ? ring(l.bits_out_slot) : nullptr;
+            if (l.fused_shortcut >= 0) {        // conv_xnor + [shortcut] in one pass (src/additionally.c:326-339)
+                Layer &sc = net.layers[l.fused_shortcut];
+                a.add = net.layers[sc.index].d_output;
+                a.out_add = sc.d_output;
+                a.out = nullptr;
+            }
             a.B = B; a.C = l.c; a.Cw = l.Cw; a.H = l.h; a.W = l.w; a.M = l.n; a.Mpad = l.Mpad; a.act = l.activation;
             YL_LAUNCH(launch_conv_xnor(a, s), "conv_xnor");
             snprintf(l.kernel_name, sizeof(l.kernel_name), "conv_xnor");
@@ -715,7 +781,7 @@ int yl_network_layer_info(const yl_network *net, int i, int *info)
     info[0] = l.type; info[1] = l.batch; info[2] = l.w; info[3] = l.h; info[4] = l.c; info[5] = l.n;
     info[6] = l.size; info[7] = l.stride; info[8] = l.pad; info[9] = l.out_w; info[10] = l.out_h;
     info[11] = l.out_c; info[12] = l.outputs; info[13] = l.inputs; info[14] = l.activation;
-    info[15] = l.xnor; info[16] = (l.type == YL_CONVOLUTIONAL && l.conv_mode == CONV_INT8) ? 1 : 0;
+    info[15] = l.xnor; info[16] = (l.type == YL_CONVOLUTIONAL && l.conv_mode == CONV_INT8) ? 1 : ((l.type == YL_CONVOLUTIONAL && l.conv_mode == CONV_BF16) ? 2 : 0);
     info[17] = l.index; info[18] = l.classes; info[19] = l.coords; info[20] = l.total;
     info[21] = l.softmax; info[22] = (l.type == YL_CONVOLUTIONAL) ? l.conv_mode : 0; info[23] = l.batch_normalize;
     return YL_OK;
@@ -759,6 +825,10 @@ int yl_network_layer_traffic(const yl_network *net, int i, double *bytes)
             const double q_in = B * (double)l.h * l.w * (l.Cpad ? l.Cpad : l.c);
             if (!l.q_from_producer) { rd += 4 * in_el; wr += q_in; }      // stand-alone quantise pass
             rd += q_in + wel;
+        } else if (l.conv_mode == CONV_BF16) {
+            const double h_in = 2.0 * B * (double)l.h * l.w * (l.Cpad ? l.Cpad : l.c);
+            if (!l.q_from_producer) { rd += 4 * in_el; wr += h_in; }      // stand-alone pack pass
+            rd += h_in + 2 * wel;
         } else if (l.conv_mode == CONV_XNOR) {
             const double bits = B * (double)l.h * l.w * 8.0 * ((l.c + 63) / 64);
             if (!l.bits_from_producer) { rd += 4 * in_el; wr += bits; }   // stand-alone sign-pack pass
@@ -770,7 +840,7 @@ int yl_network_layer_traffic(const yl_network *net, int i, double *bytes)
         }
         if (fused) { rd += 4 * out_el; wr += 4 * out_el; }                // [shortcut] operand in, sum out
         else if (!l.skip_f32_out) wr += 4 * out_el;
-        if (l.q_out_layer >= 0) wr += out_el;                             // int8 side output (one byte per element)
+        if (l.q_out_layer >= 0) wr += (l.conv_mode == CONV_BF16 ? 2 : 1) * out_el;   // int8 / bf16 side output
         break;
     }
     case YL_SHORTCUT:
@@ -1084,6 +1154,15 @@ int yl_network_set_variant(yl_network *net, int bits)
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }
     if (bits < -1 || bits > 255) { set_error("unknown variant bits"); return YL_ERR_ARG; }
     net->net.conv_opts.variant = bits < 0 ? YL_VARIANT_DEFAULT : bits;
+    return YL_OK;
+}
+
+int yl_network_set_precision(yl_network *net, int precision)
+{
+    if (!net || (precision != YL_PRECISION_FP32 && precision != YL_PRECISION_BF16)) { set_error("bad argument"); return YL_ERR_ARG; }
+    if (net->net.on_device) { set_error("set_precision must precede to_device"); return YL_ERR_STATE; }
+    net->net.precision = precision;
+    select_conv_modes(net->net);
     return YL_OK;
 }
 

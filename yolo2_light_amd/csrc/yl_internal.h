@@ -13,7 +13,7 @@
 namespace yl {
 
 // which convolution implementation a CONVOLUTIONAL layer runs with
-enum ConvMode { CONV_F32 = 0, CONV_INT8 = 1, CONV_XNOR = 2 };
+enum ConvMode { CONV_F32 = 0, CONV_INT8 = 1, CONV_XNOR = 2, CONV_BF16 = 3 };
 
 struct Layer {
     int type = YL_BLANK;
@@ -52,8 +52,8 @@ struct Layer {
     int   Kpad = 0, Mpad = 0;
     int   tapmajor = 0;                  // K order of d_weights_t (see conv_f32_mfma.hip)
     float *d_wino32_u = nullptr;         // FP32 3x3/1/1: Winograd-packed U (conv_f32_wino32.hip), else nullptr
-    int8_t *d_weights_i8 = nullptr;      // INT8: [Mpad][taps][Cpad] (channel-fastest)
-    int   Cpad = 0;
+    int8_t *d_weights_i8 = nullptr;      // INT8: [K16pad][Mpad][16] int8 units; BF16: [K8pad][Mpad][8] bf16 units
+    int   Cpad = 0;                      // channels of the 16-byte-unit activation tensor (INT8: 16 per unit, BF16: 8)
     uint64_t *d_weights_bits = nullptr;  // XNOR: [Mpad][taps][Cw] 64-bit words
     float *d_mean = nullptr;
     int   Cw = 0;
@@ -85,6 +85,7 @@ struct Network {
     int batch = 1, w = 0, h = 0, c = 0;
     int quantized = 0;
     int quant_rule = YL_QUANT_RULE_CPU;  // which convolutions `quantized` applies to (yl_network_set_quant_rule)
+    int precision = YL_PRECISION_FP32;   // opt-in BF16 operands for the FP32 convolutions (yl_network_set_precision)
     std::vector<float> input_calibration;
     std::vector<Layer> layers;
     bool weights_loaded = false;

@@ -63,13 +63,15 @@ class Network:
     @classmethod
     def load(cls, cfg_path: str, weights_path: str, batch: int = 1, quantized: int = 0,
              device: Optional[int] = None, debug: bool = False, fuse: bool = False,
-             quant_rule: int = 0, winograd: bool = True) -> "Network":
+             quant_rule: int = 0, winograd: bool = True, bf16: bool = False) -> "Network":
         """The full prep sequence of test_detector_cpu (src/main.c:160-171)."""
         net = cls.from_cfg(cfg_path, batch, quantized)
         if quant_rule:
             net.set_quant_rule(quant_rule)
         if not winograd:
             check(lib.yl_network_set_winograd(net._h, 0), "yl_network_set_winograd")
+        if bf16:
+            net.set_precision(1)
         net.load_weights(weights_path)
         net.fuse_conv_batchnorm()
         net.calculate_binary_weights()
@@ -180,6 +182,10 @@ class Network:
 
     def set_conv_tile(self, cfg: int) -> None:
         check(lib.yl_network_set_conv_tile(self._h, cfg), "yl_network_set_conv_tile")
+
+    def set_precision(self, precision: int) -> None:
+        """0 = FP32 (default), 1 = opt-in BF16 operands for the FP32 convolutions; before to_device"""
+        check(lib.yl_network_set_precision(self._h, precision), "yl_network_set_precision")
 
     def set_variant(self, bits: int) -> None:
         check(lib.yl_network_set_variant(self._h, bits), "yl_network_set_variant")
