@@ -77,6 +77,11 @@ typedef struct yl_layer_desc {
     float *output;            /* host l.output[batch*outputs]: filled by yl_network_predict for
                                  YOLO/REGION layers and the last layer, like the reference GPU
                                  path does (src/yolov2_forward_network_gpu.cu:404-419,438,570) */
+    /* region with l.softmax_tree (YOLO9000, src/additionally.h:352-364, read_tree src/additionally.c:1895):
+     * tree_n = t->n (0 = no tree), tree_groups = t->groups, tree_parent = t->parent[tree_n],
+     * tree_group_size = t->group_size[tree_groups] */
+    int tree_n, tree_groups;
+    const int *tree_parent, *tree_group_size;
 } yl_layer_desc;
 
 /* thread-local human-readable message of the last failure */
@@ -142,6 +147,9 @@ int yl_network_layer_info(const yl_network *net, int i, int *info);
 /* YOLO/REGION layer i: mask[n] (yolo: l.mask; region: 0..n-1) and anchors[2*total] (l.biases);
  * either pointer may be NULL.  Returns n (anchors of this head), < 0 on error. */
 int yl_network_layer_head(const yl_network *net, int i, int *mask, float *anchors);
+/* softmax tree of REGION layer i (l.softmax_tree, src/additionally.h:352-364): returns the number of groups
+ * (0 = the layer has no tree, <0 on error); parent[classes] / group_size[groups] are copied when non-NULL */
+int yl_network_layer_tree(const yl_network *net, int i, int *parent, int *group_size);
 /* borrowed host pointers to the prepared parameters of conv layer i (NULL if absent) */
 const float  *yl_network_layer_weights(const yl_network *net, int i);
 const float  *yl_network_layer_biases(const yl_network *net, int i);

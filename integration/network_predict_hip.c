@@ -79,6 +79,10 @@ static yl_network *hip_build(network *net)
             d[i].mean_arr = l->xnor ? l->mean_arr : NULL;
         }
         d[i].output = l->output;
+        if (l->type == REGION && l->softmax_tree) {
+            d[i].tree_n = l->softmax_tree->n; d[i].tree_groups = l->softmax_tree->groups;
+            d[i].tree_parent = l->softmax_tree->parent; d[i].tree_group_size = l->softmax_tree->group_size;
+        }
     }
     if (yl_network_create_from_desc(d, net->n, net->batch, net->w, net->h, net->c, net->quantized,
                                     net->input_calibration, net->input_calibration_size, &h) != YL_OK)

@@ -31,6 +31,7 @@ typedef struct oracle_head {
     const float *output;    /* l.output: [batch][outputs] */
     const int *mask;        /* yolo: l.mask[n] */
     const float *anchors;   /* l.biases */
+    const int *tree_parent; /* region with l.softmax_tree: t->parent[classes], else NULL */
 } oracle_head;
 
 typedef struct { float x, y, w, h; } obox;
@@ -179,6 +180,25 @@ int oracle_get_boxes(const oracle_head *heads, int n_heads, int netw, int neth, 
                     cur[index].classes = l->classes;
                     cur[index].bbox = b;                     /* get_region_boxes_cpu runs with w = h = 1 */
                     cur[index].objectness = 1;
+                    if (l->tree_parent) {
+                        /* Yolo 9000, src/yolov2_forward_network.c:690-712: hierarchy_predictions
+                         * (src/additionally.c:1878, only_leaves = 0) on a copy -- the reference multiplies
+                         * l.output in place -- then from the last class down the first one above .5 keeps
+                         * its probability, every other class becomes 0 */
+                        float *pred = (float *)malloc(sizeof(float) * l->classes);
+                        int found = 0;
+                        for (j = 0; j < l->classes; ++j) {
+                            int parent = l->tree_parent[j];
+                            pred[j] = p[box_index + 5 + j];
+                            if (parent >= 0) pred[j] *= pred[parent];
+                        }
+                        for (j = l->classes - 1; j >= 0; --j) {
+                            if (!found && pred[j] > .5) found = 1;
+                            else pred[j] = 0;
+                            cur[index].prob[j] = (scale > thresh) ? pred[j] : 0;
+                        }
+                        free(pred);
+                    } else
                     for (j = 0; j < l->classes && j < classes; ++j) {
                         float prob = scale * p[box_index + 5 + j];
                         cur[index].prob[j] = (prob > thresh) ? prob : 0;

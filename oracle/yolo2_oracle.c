@@ -292,6 +292,33 @@ void oracle_region(const float *in, float *out, int batch, int n, int classes, i
         }
 }
 
+/* forward_region_layer_cpu with l.softmax_tree (YOLO9000): softmax_tree / softmax_cpu per group
+ * src/yolov2_forward_network.c:494-507, :556-562; groups as read_tree builds them (src/additionally.c:1895) */
+void oracle_region_tree(const float *in, float *out, int batch, int n, int classes, int coords, int wh,
+                        const int *group_size, int groups)
+{
+    const int size = coords + classes + 1;
+    const size_t outputs = (size_t)size * n * wh;
+    oracle_region(in, out, batch, n, classes, coords, wh, 0);
+    for (int b = 0; b < batch; ++b)
+        for (int i = 0; i < wh * n; ++i) {
+            float *cl = out + b * outputs + (size_t)size * i + coords + 1;
+            int count = 0;
+            for (int g = 0; g < groups; ++g) {
+                const int gs = group_size[g];
+                float sum = 0, largest = -FLT_MAX;
+                for (int k = count; k < count + gs; ++k) if (cl[k] > largest) largest = cl[k];
+                for (int k = count; k < count + gs; ++k) {
+                    const float e = expf(cl[k] / 1 - largest / 1);
+                    sum += e;
+                    cl[k] = e;
+                }
+                for (int k = count; k < count + gs; ++k) cl[k] /= sum;
+                count += gs;
+            }
+        }
+}
+
 /* forward_reorg_layer_cpu  src/yolov2_forward_network.c:337-373 */
 void oracle_reorg(const float *x, float *out, int batch, int out_c, int out_h, int out_w, int stride)
 {

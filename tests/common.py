@@ -35,7 +35,8 @@ CONV_F32, CONV_INT8, CONV_XNOR = 0, 1, 2
 class OracleHead(C.Structure):
     """struct oracle_head (oracle/detect_oracle.c)"""
     _fields_ = [("type", C.c_int), ("w", C.c_int), ("h", C.c_int), ("n", C.c_int), ("classes", C.c_int),
-                ("outputs", C.c_int), ("output", _fp), ("mask", C.POINTER(C.c_int)), ("anchors", _fp)]
+                ("outputs", C.c_int), ("output", _fp), ("mask", C.POINTER(C.c_int)), ("anchors", _fp),
+                ("tree_parent", C.POINTER(C.c_int))]
 
 
 def _build_oracle() -> None:
@@ -58,6 +59,7 @@ def oracle_lib() -> C.CDLL:
     lib.oracle_upsample.argtypes = [_fp, _fp] + [i] * 5 + [C.c_float]
     lib.oracle_yolo.argtypes = [_fp, _fp] + [i] * 4
     lib.oracle_region.argtypes = [_fp, _fp] + [i] * 6
+    lib.oracle_region_tree.argtypes = [_fp, _fp] + [i] * 5 + [C.POINTER(C.c_int), i]
     lib.oracle_reorg.argtypes = [_fp, _fp] + [i] * 5
     lib.oracle_fuse_bn.argtypes = [_fp, _fp, _fp, _fp, _fp, i, i]
     lib.oracle_binary_mean.argtypes = [_fp, i, i, _fp]
@@ -237,8 +239,14 @@ class OracleNet:
             elif t == YOLO:
                 o.oracle_yolo(fp(cur), fp(out), B, li["n"], li["classes"], li["w"] * li["h"])
             elif t == REGION:
-                o.oracle_region(fp(cur), fp(out), B, li["n"], li["classes"], li["coords"], li["w"] * li["h"],
-                                li["softmax"])
+                tree = self.net.layer_tree(i)
+                if tree is not None:
+                    gs = np.ascontiguousarray(tree[1], dtype=np.int32)
+                    o.oracle_region_tree(fp(cur), fp(out), B, li["n"], li["classes"], li["coords"], li["w"] * li["h"],
+                                         gs.ctypes.data_as(C.POINTER(C.c_int)), len(gs))
+                else:
+                    o.oracle_region(fp(cur), fp(out), B, li["n"], li["classes"], li["coords"], li["w"] * li["h"],
+                                    li["softmax"])
             elif t == REORG:
                 o.oracle_reorg(fp(cur), fp(out), B, li["out_c"], li["out_h"], li["out_w"], li["stride"])
             else:
@@ -286,8 +294,14 @@ class OracleHeads:
             mask = np.ascontiguousarray(mask, dtype=np.int32)
             anchors = np.ascontiguousarray(anchors, dtype=np.float32)
             self.keep += [out, mask, anchors]
+            tree = net.layer_tree(i) if li["type"] == REGION else None
+            tparent = None
+            if tree is not None:
+                tp = np.ascontiguousarray(tree[0], dtype=np.int32)
+                self.keep.append(tp)
+                tparent = tp.ctypes.data_as(C.POINTER(C.c_int))
             heads.append(OracleHead(li["type"], li["w"], li["h"], li["n"], li["classes"], li["outputs"], fp(out),
-                                    mask.ctypes.data_as(C.POINTER(C.c_int)), fp(anchors)))
+                                    mask.ctypes.data_as(C.POINTER(C.c_int)), fp(anchors), tparent))
         self.classes = heads[-1].classes
         self.arr = (OracleHead * len(heads))(*heads)
         self.n = len(heads)

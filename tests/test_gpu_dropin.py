@@ -67,3 +67,21 @@ def test_reference_host_code_quantized():
         g = ref.layer_output(i).astype(np.float64); r = cpu_heads[i]
         assert np.sqrt(np.mean((g - r) ** 2)) / np.sqrt(np.mean(r * r)) < 0.05
     ref.lib.ref_free_hip()
+
+
+def test_reference_host_code_softmax_tree():
+    """A [region] layer with tree= (YOLO9000-style hierarchy): the reference's parser reads the tree, the adaptor
+    hands l.softmax_tree's parent / group arrays through yl_layer_desc, the head tensor matches the CPU path."""
+    import test_softmax_tree as T
+    width, height, batch = 96, 64, 2
+    cfg, wts = T.tree_files(width, height)
+    ref = refbind.RefNetwork(cfg, wts, batch, 0, hip=True)
+    x = common.seeded_input(batch, 3, height, width) * 4.0 - 1.5
+    ref.predict(x)
+    want = ref.layer_output(ref.n - 1).copy()
+    ref.predict_hip(x)
+    got = ref.layer_output(ref.n - 1)
+    sz = 12 + 5
+    assert np.abs(got.reshape(-1, sz)[:, 5:8].sum(axis=1) - 1.0).max() < 1e-5        # the root group is a softmax
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-6)
+    ref.lib.ref_free_hip()

@@ -50,6 +50,7 @@ class LayerDesc(C.Structure):
         ("input_quant_multipler", C.c_float), ("weights_quant_multipler", C.c_float),
         ("mean_arr", c_float_p),
         ("output", c_float_p),
+        ("tree_n", C.c_int), ("tree_groups", C.c_int), ("tree_parent", c_int_p), ("tree_group_size", c_int_p),
     ]
 
 
@@ -105,6 +106,7 @@ _SIGS = {
     "yl_network_set_nms_mode": (C.c_int, [_vp, C.c_int]),
     "yl_network_set_quant_rule": (C.c_int, [_vp, C.c_int]),
     "yl_network_layer_head": (C.c_int, [_vp, C.c_int, c_int_p, c_float_p]),
+    "yl_network_layer_tree": (C.c_int, [_vp, C.c_int, c_int_p, c_int_p]),
     "yl_debug_wino_pack": (C.c_longlong, [c_float_p, C.c_int, C.c_int, C.c_int, c_float_p, C.c_longlong]),
     "yl_network_compact_detections": (C.c_int, [_vp, C.c_float, C.c_int, _vp, _vp]),
     "yl_network_detect_batch": (C.c_int, [_vp, c_int_p, c_int_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,

@@ -113,6 +113,35 @@ int activation_from(const std::string &s, bool &ok) {
 
 }  // namespace
 
+// read_tree (src/additionally.c:1895-1945): one "name parent" line per class; a new softmax group starts wherever
+// the parent changes.  Every line counts as a node (sscanf on a blank line leaves parent = -1), like the reference.
+static int read_tree_file(const std::string &path, std::vector<int> &parent, std::vector<int> &group_size)
+{
+    FILE *fp = fopen(path.c_str(), "r");
+    if (!fp) return YL_ERR_IO;
+    parent.clear(); group_size.clear();
+    int last_parent = -1, gsize = 0;
+    char *line = nullptr;
+    size_t cap = 0;
+    ssize_t len;
+    while ((len = getline(&line, &cap, fp)) >= 0) {
+        char id[256];
+        int par = -1;
+        sscanf(line, "%255s %d", id, &par);
+        parent.push_back(par);
+        if (par != last_parent) {
+            group_size.push_back(gsize);
+            gsize = 0;
+            last_parent = par;
+        }
+        ++gsize;
+    }
+    free(line);
+    fclose(fp);
+    group_size.push_back(gsize);
+    return YL_OK;
+}
+
 int parse_cfg_file(const char *path, int batch, int quantized, Network &net) {
     std::vector<Section> secs;
     if (!read_sections(path, secs)) return YL_ERR_IO;
@@ -286,7 +315,12 @@ int parse_cfg_file(const char *path, int batch, int quantized, Network &net) {
             l.softmax = s.geti("softmax", 0);
             // classfix == -1 zeroes scale < .5 in get_region_boxes_cpu (src/additionally.c:3591); no decode here honours it
             if (s.geti("classfix", 0) != 0) { set_error(std::string(where) + "classfix != 0 is not on the hot path"); return YL_ERR_UNSUPPORTED; }
-            if (s.find("tree") != nullptr || s.find("map") != nullptr) { set_error(std::string(where) + "softmax tree / map (YOLO9000) is not on the hot path"); return YL_ERR_UNSUPPORTED; }
+            if (s.find("map") != nullptr) { set_error(std::string(where) + "map= (YOLO9000 class remapping of the evaluator) is not on the hot path"); return YL_ERR_UNSUPPORTED; }
+            if (const std::string *tf = s.find("tree")) {
+                const int rc = read_tree_file(*tf, l.tree_parent, l.tree_group_size);
+                if (rc != YL_OK) { set_error(std::string(where) + "cannot read tree file " + *tf); return rc; }
+                if ((int)l.tree_parent.size() != l.classes) { set_error(std::string(where) + "tree size != classes"); return YL_ERR_CFG; }
+            }
             if (l.coords != 4) { set_error(std::string(where) + "coords != 4 unsupported"); return YL_ERR_UNSUPPORTED; }
             l.w = pw; l.h = ph; l.c = pc;
             l.outputs = l.h * l.w * l.n * (l.classes + l.coords + 1);

@@ -6,7 +6,7 @@
 
 namespace yl {
 
-constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8;      // measured on MI355X, profiles/r2_ab_fp32_variants.txt: bit 1 +3.3 %, bit 2 +0.4 %, bit 3 +0.6 %, bit 0 -0.5 %
+constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8 | 16;      // measured on MI355X, profiles/r2_ab_fp32_variants.txt: bit 1 +3.3 %, bit 2 +0.4 %, bit 3 +0.6 %, bit 4 +0.9 %, bit 0 -0.5 %
 
 // ---- K1: FP32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 ----
 struct ConvF32Args {
@@ -126,7 +126,9 @@ int launch_shortcut(const float *in, const float *add, float *out, int B,
 int launch_upsample(const float *in, float *out, int B, int C, int H, int W, int stride, float scale, void *stream);
 int launch_copy_rows(const float *src, float *dst, int rows, int row_elems, size_t src_stride, size_t dst_stride, void *stream);
 int launch_yolo(const float *in, float *out, int B, int n, int classes, int wh, void *stream);
-int launch_region(const float *in, float *out, int B, int n, int classes, int coords, int wh, int softmax, void *stream);
+// tree_group_size (device, groups entries) != nullptr: softmax per group of the class vector (softmax_tree, YOLO9000)
+int launch_region(const float *in, float *out, int B, int n, int classes, int coords, int wh, int softmax, void *stream,
+                  const int *tree_group_size = nullptr, int tree_groups = 0);
 // x -> (x > 0 ? 1 : -1)   binarize_cpu, src/additionally.c:128-134
 int launch_binarize(const float *in, float *out, size_t n, void *stream);
 int launch_reorg(const float *in, float *out, int B, int out_c, int out_h, int out_w, int stride, void *stream);
@@ -137,6 +139,7 @@ struct HeadDesc {
     int type;             // YL_YOLO / YL_REGION
     int w, h, n, classes, outputs;
     float anchors_w[16], anchors_h[16];   // already selected through mask[]
+    const int *tree_parent = nullptr;     // REGION with a softmax tree: parent[classes] (device) -> hierarchical decode
 };
 int launch_compact(const HeadDesc *heads, int n_heads, int B, int netw, int neth, float thresh,
                    int cap, int row_stride, float *records, int *counts, void *stream);

@@ -216,7 +216,8 @@ int launch_yolo(const float *in, float *out, int B, int n, int classes, int wh, 
 // ---------------------------------------------------------------- region
 // one lane per (b, cell, anchor): CHW -> HWC flatten, logistic(obj) in float, softmax over classes
 __global__ __launch_bounds__(256) void region_kernel(const float *__restrict__ in, float *__restrict__ out,
-                                                     size_t total, int n, int classes, int coords, int wh, int softmax)
+                                                     size_t total, int n, int classes, int coords, int wh, int softmax,
+                                                     const int *__restrict__ tree_group_size, int tree_groups)
 {
     const int size = coords + classes + 1;
     const int layers = size * n;
@@ -231,7 +232,27 @@ __global__ __launch_bounds__(256) void region_kernel(const float *__restrict__ i
         for (int c = 0; c < coords; ++c) dst[c] = src[(size_t)c * wh];
         const float o = src[(size_t)coords * wh];
         dst[coords] = __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-o)));
-        if (softmax) {
+        if (tree_group_size) {
+            // softmax_tree (src/yolov2_forward_network.c:494-507, :556-562): softmax_cpu over every group of the
+            // class vector; takes precedence over `softmax=1` like the reference's if / else-if
+            int c0 = 0;
+            for (int g = 0; g < tree_groups; ++g) {
+                const int gs = tree_group_size[g];
+                float largest = -FLT_MAX;
+                for (int c = c0; c < c0 + gs; ++c) {
+                    const float v = src[(size_t)(coords + 1 + c) * wh];
+                    if (v > largest) largest = v;
+                }
+                float sum = 0.f;
+                for (int c = c0; c < c0 + gs; ++c) {
+                    const float e = expf(__fsub_rn(src[(size_t)(coords + 1 + c) * wh], largest));
+                    sum = __fadd_rn(sum, e);
+                    dst[coords + 1 + c] = e;
+                }
+                for (int c = c0; c < c0 + gs; ++c) dst[coords + 1 + c] = __fdiv_rn(dst[coords + 1 + c], sum);
+                c0 += gs;
+            }
+        } else if (softmax) {
             float largest = -FLT_MAX;
             for (int c = 0; c < classes; ++c) {
                 const float v = src[(size_t)(coords + 1 + c) * wh];
@@ -251,11 +272,12 @@ __global__ __launch_bounds__(256) void region_kernel(const float *__restrict__ i
     }
 }
 
-int launch_region(const float *in, float *out, int B, int n, int classes, int coords, int wh, int softmax, void *stream)
+int launch_region(const float *in, float *out, int B, int n, int classes, int coords, int wh, int softmax, void *stream,
+                  const int *tree_group_size, int tree_groups)
 {
     const size_t total = (size_t)B * wh * n;
     hipLaunchKernelGGL(region_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       in, out, total, n, classes, coords, wh, softmax);
+                       in, out, total, n, classes, coords, wh, softmax, tree_group_size, tree_groups);
     return (int)hipGetLastError();
 }
 
@@ -470,9 +492,29 @@ __global__ __launch_bounds__(256) void compact_kernel(HeadsDev hd, int B, int ne
                     r[3] = __fdiv_rn(__fmul_rn(expf_host_libm(e[3]), h.anchors_h[n]), (float)h.h);
                     r[4] = 1.f;
                     r[5] = (float)(key_base + cell * h.n + n);
-                    for (int j = 0; j < h.classes; ++j) {
-                        const float prob = __fmul_rn(scale, e[5 + j]);
-                        r[6 + j] = (prob > thresh) ? prob : 0.f;
+                    if (h.tree_parent) {
+                        // YOLO9000 (get_region_boxes_cpu, src/yolov2_forward_network.c:690-712): hierarchy_predictions
+                        // (src/additionally.c:1878: p[j] *= p[parent[j]], parents first), then from the last class down
+                        // the first one above .5 keeps its probability, all others become 0; the box passes when
+                        // scale > thresh.  The record row is the scratch (the reference scribbles over l.output).
+                        for (int j = 0; j < h.classes; ++j) {
+                            const int par = h.tree_parent[j];
+                            float v = e[5 + j];
+                            if (par >= 0) v = __fmul_rn(v, r[6 + par]);
+                            r[6 + j] = v;
+                        }
+                        bool found = false;
+                        for (int j = h.classes - 1; j >= 0; --j) {
+                            float v = r[6 + j];
+                            if (!found && v > .5f) found = true;
+                            else v = 0.f;
+                            r[6 + j] = (scale > thresh) ? v : 0.f;
+                        }
+                    } else {
+                        for (int j = 0; j < h.classes; ++j) {
+                            const float prob = __fmul_rn(scale, e[5 + j]);
+                            r[6 + j] = (prob > thresh) ? prob : 0.f;
+                        }
                     }
                 }
             }

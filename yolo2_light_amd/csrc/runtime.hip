@@ -70,6 +70,8 @@ static void free_device(Network &net)
         if (l.d_weights_bits) (void)hipFree(l.d_weights_bits);
         if (l.d_mean) (void)hipFree(l.d_mean);
         if (l.d_debug) (void)hipFree(l.d_debug);
+        if (l.d_tree) (void)hipFree(l.d_tree);
+        l.d_tree = nullptr;
         l.d_weights_t = nullptr; l.d_biases = nullptr; l.d_weights_i8 = nullptr;
         l.d_weights_bits = nullptr; l.d_mean = nullptr; l.d_debug = nullptr;
     }
@@ -264,6 +266,19 @@ static int to_device(Network &net, int device)
         if (l.type == YL_CONVOLUTIONAL) {
             int rc = upload_conv(net, l);
             if (rc != YL_OK) return rc;
+        }
+        if (l.type == YL_REGION && !l.tree_parent.empty()) {
+            // parents must precede their children (hierarchy_predictions multiplies in index order) and the groups
+            // must tile the class vector: checked here so the kernels need no guards
+            long long covered = 0;
+            for (int g : l.tree_group_size) { if (g < 0) covered = -1; if (covered >= 0) covered += g; }
+            bool ok = covered == (long long)l.classes;
+            for (int j = 0; j < l.classes && ok; ++j) ok = l.tree_parent[j] < j;
+            if (!ok) { set_error("region softmax tree: groups do not tile the classes or a parent follows its child"); return YL_ERR_CFG; }
+            std::vector<int> t(l.tree_parent);
+            t.insert(t.end(), l.tree_group_size.begin(), l.tree_group_size.end());
+            YL_HIP(hipMalloc((void **)&l.d_tree, t.size() * sizeof(int)));
+            YL_HIP(hipMemcpy(l.d_tree, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice));
         }
         const bool is_head = (l.type == YL_YOLO || l.type == YL_REGION);
         if ((is_head || i + 1 == net.layers.size()) && !l.host_output) {
@@ -559,7 +574,8 @@ static int forward_layer(Network &net, size_t i, const float *input)
         YL_LAUNCH(launch_yolo(input, l.d_output, B, l.n, l.classes, l.w * l.h, s), "yolo");
         break;
     case YL_REGION:
-        YL_LAUNCH(launch_region(input, l.d_output, B, l.n, l.classes, l.coords, l.w * l.h, l.softmax, s), "region");
+        YL_LAUNCH(launch_region(input, l.d_output, B, l.n, l.classes, l.coords, l.w * l.h, l.softmax, s,
+                                l.d_tree ? l.d_tree + l.classes : nullptr, (int)l.tree_group_size.size()), "region");
         break;
     case YL_REORG:
         YL_LAUNCH(launch_reorg(input, l.d_output, B, l.out_c, l.out_h, l.out_w, l.stride, s), "reorg");
@@ -710,6 +726,13 @@ int yl_network_create_from_desc(const yl_layer_desc *layers, int n_layers, int b
             if (!d.anchors) { delete n; set_error("region layer without anchors"); return YL_ERR_ARG; }
             l.anchors.assign(d.anchors, d.anchors + (size_t)2 * d.n);
             l.total = d.n;
+            if (d.tree_n > 0) {
+                if (!d.tree_parent || !d.tree_group_size || d.tree_groups <= 0 || d.tree_n != d.classes) {
+                    delete n; set_error("region softmax tree: bad description"); return YL_ERR_ARG;
+                }
+                l.tree_parent.assign(d.tree_parent, d.tree_parent + d.tree_n);
+                l.tree_group_size.assign(d.tree_group_size, d.tree_group_size + d.tree_groups);
+            }
             break;
         case YL_MAXPOOL: case YL_UPSAMPLE: case YL_REORG:
             break;
@@ -1208,6 +1231,15 @@ int yl_network_layer_head(const yl_network *net, int i, int *mask, float *anchor
     return l.n;
 }
 
+int yl_network_layer_tree(const yl_network *net, int i, int *parent, int *group_size)
+{
+    YL_LAYER_OR(YL_ERR_ARG)
+    if (l.type != YL_REGION) { set_error("not a region layer"); return YL_ERR_ARG; }
+    if (parent) for (size_t k = 0; k < l.tree_parent.size(); ++k) parent[k] = l.tree_parent[k];
+    if (group_size) for (size_t k = 0; k < l.tree_group_size.size(); ++k) group_size[k] = l.tree_group_size[k];
+    return l.tree_parent.empty() ? 0 : (int)l.tree_group_size.size();
+}
+
 long long yl_debug_wino_pack(const float *weights, int c, int m, int tiling, float *dst, long long dst_floats)
 {
     if (!weights || c <= 0 || m <= 0 || c % 8 != 0 || tiling != 32) { set_error("bad argument"); return YL_ERR_ARG; }
@@ -1385,6 +1417,7 @@ static int collect_heads(Network &n, HeadDesc *heads, int *nh_out, int *classes_
         if (l.classes != classes) { set_error("heads disagree on classes"); return YL_ERR_UNSUPPORTED; }
         HeadDesc &h = heads[nh++];
         h.out = l.d_output; h.type = l.type; h.w = l.w; h.h = l.h; h.n = l.n; h.classes = l.classes; h.outputs = l.outputs;
+        h.tree_parent = l.d_tree;
         for (int k = 0; k < l.n; ++k) {
             const int an = (l.type == YL_YOLO) ? l.mask[k] : k;
             h.anchors_w[k] = l.anchors[2 * an];

@@ -30,6 +30,7 @@ struct Layer {
     std::vector<int> mask;
     std::vector<float> anchors;
     float scale = 1.f;
+    std::vector<int> tree_parent, tree_group_size;   // region with a softmax tree (read_tree, src/additionally.c:1895)
 
     // conv parameters (host)
     std::vector<float> weights, biases, scales, rolling_mean, rolling_variance;
@@ -58,6 +59,7 @@ struct Layer {
     float *d_mean = nullptr;
     int   Cw = 0;
     int32_t *d_debug = nullptr;          // xnor counts / int8 acc (debug mode)
+    int  *d_tree = nullptr;              // region softmax tree: parent[classes] then group_size[groups]
     char kernel_name[64] = "";           // kernel instance of this layer's last launch
     int   fused_shortcut = -1;           // conv: index of the [shortcut] layer folded into its epilogue
     bool  fused_into_conv = false;       // shortcut: produced by the preceding conv's epilogue

@@ -175,6 +175,18 @@ class Network:
             raise YoloHipError("yl_network_layer_head failed: " + _lib.last_error())
         return np.array(mask[:n], dtype=np.int32), np.array(anchors[:], dtype=np.float32)
 
+    def layer_tree(self, i: int):
+        """(parent[classes], group_size[groups]) of a REGION layer with a softmax tree, or None"""
+        groups = lib.yl_network_layer_tree(self._h, i, None, None)
+        if groups < 0:
+            raise YoloHipError("yl_network_layer_tree failed: " + _lib.last_error())
+        if groups == 0:
+            return None
+        parent = (C.c_int * self.layer_info(i)["classes"])()
+        gs = (C.c_int * groups)()
+        lib.yl_network_layer_tree(self._h, i, parent, gs)
+        return np.array(parent[:], dtype=np.int32), np.array(gs[:], dtype=np.int32)
+
     # ------------------------------------------------------------ device
     def set_quant_rule(self, rule: int) -> None:
         """0 = the reference CPU path's INT8 layer set, 1 = its GPU path's (`l.quantized`); before to_device"""
