@@ -289,7 +289,7 @@ int yl_network_set_variant(yl_network *net, int bits);
 #define YL_PRECISION_BF16 1
 int yl_network_set_precision(yl_network *net, int precision);
 /* the same for the INT8 convolution (conv_i8_mfma.hip): 0 = heuristic, 1 = 64x128, 2 = 32x256, 3 = 128x128,
- * 4 = 128x256 (8 waves), 5 = 64x256 */
+ * 4 = 128x256 (8 waves), 5 = 64x256, 6 / 7 = 128x128 / 64x128 with half-depth LDS panels */
 int yl_network_set_int8_tile(yl_network *net, int cfg);
 int yl_network_set_winograd(yl_network *net, int on);
 int yl_network_set_nms_mode(yl_network *net, int mode);

@@ -87,7 +87,7 @@ INT8_SHAPES += [
 
 
 @pytest.mark.parametrize("shape", INT8_SHAPES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_conv_int8_bit_exact(olib, shape, tile):
     B, Cc, H, W, M, size, stride, pad = shape
     rng = np.random.default_rng(99 + Cc + M)
@@ -234,7 +234,7 @@ def test_int8_network_vs_reference_library_batch1():
     net.close()
 
 
-@pytest.mark.parametrize("width,height,batch,tile", [(96, 96, 2, 0), (96, 96, 2, 1), (96, 96, 2, 3), (96, 96, 2, 4),
+@pytest.mark.parametrize("width,height,batch,tile", [(96, 96, 2, 0), (96, 96, 2, 1), (96, 96, 2, 3), (96, 96, 2, 4), (96, 96, 2, 6),
                                                      (96, 96, 2, 5), (160, 96, 3, 0), (160, 96, 3, 3), (224, 160, 1, 4)])
 def test_int8_fusion_is_bit_identical(width, height, batch, tile):
     """-quantized yolov3 with yl_network_set_fusion: conv+[shortcut] folded, the next layer's int8

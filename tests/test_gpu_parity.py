@@ -386,10 +386,11 @@ def test_compact_detections_matches_host_decode():
     net.close()
 
 
-def test_shortcut_fusion_is_bit_identical():
-    """conv+[shortcut] epilogue fusion (yl_network_set_fusion): every tensor that is still
+@pytest.mark.parametrize("width,height,batch", [(96, 96, 2), (160, 96, 3), (608, 608, 1)])
+def test_shortcut_fusion_is_bit_identical(width, height, batch):
+    """conv+[shortcut] and head-conv+[yolo] epilogue fusion (yl_network_set_fusion): every tensor that is still
     materialised -- all shortcut/route/head outputs -- equals the unfused run bit for bit."""
-    name, width, height, batch = "yolov3", 96, 96, 2
+    name = "yolov3"
     cfg, wts = common.model_files(name, width, height)
     x = common.seeded_input(batch, 3, height, width)
     plain = Network.load(cfg, wts, batch, 0, device=0)
@@ -400,12 +401,16 @@ def test_shortcut_fusion_is_bit_identical():
     skipped = 0
     for i, li in enumerate(infos):
         nxt = infos[i + 1] if i + 1 < len(infos) else None
-        if li["type"] == common.CONV and nxt is not None and nxt["type"] == common.SHORTCUT:
+        folded = li["type"] == common.CONV and nxt is not None and nxt["type"] in (common.SHORTCUT, common.YOLO)
+        assert fused.layer_materialised(i) == (not folded), "layer %d %r" % (i, li)
+        if folded:
             skipped += 1              # folded conv: its own tensor is not materialised
+            if nxt["type"] == common.YOLO:
+                assert ",yolo" in fused.layer_kernel(i), fused.layer_kernel(i)
             continue
         a, b = plain.layer_output(i), fused.layer_output(i)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "layer %d %r" % (i, li)
-    assert skipped == 23              # yolov3 has 23 residual blocks
+    assert skipped == 23 + 3          # yolov3: 23 residual blocks, 3 heads
     for b in range(batch):
         assert np.array_equal(plain.get_boxes(b, width, height, 0.24, nms=0.4),
                               fused.get_boxes(b, width, height, 0.24, nms=0.4))
@@ -451,10 +456,9 @@ def test_variants_whole_network_fused_bit_identical(variant):
     b.set_variant(variant)
     a.predict(x)
     b.predict(x)
-    infos = a.layers()
-    for i, li in enumerate(infos):
-        nxt = infos[i + 1] if i + 1 < len(infos) else None
-        if li["type"] == common.CONV and nxt is not None and nxt["type"] == common.SHORTCUT:
+    for i in range(a.n):
+        if not a.layer_materialised(i):
+            assert not b.layer_materialised(i)
             continue
         assert np.array_equal(a.layer_output(i).view(np.uint32), b.layer_output(i).view(np.uint32)), "layer %d" % i
     kernels = [b.layer_kernel(i) for i in range(b.n)]

@@ -136,7 +136,7 @@ def test_gpu_region_tree_and_hierarchical_decode(olib, batch, nms):
         c0 += sz
     # hierarchical decode + NMS on the GPU's own head tensor: rows identical to the oracle's, order included
     heads = common.OracleHeads(net)
-    rows, counts = net.get_boxes_batch(0.2, nms, cap=1024, sizes=(640, 480), relative=0, letter=0)
+    rows, counts = net.get_boxes_batch(0.2, nms, cap=2048, sizes=(640, 480), relative=0, letter=0)
     nonzero = 0
     for b in range(batch):
         host = common.oracle_boxes(heads, b, 640, 480, 0.2, nms=nms, relative=0)

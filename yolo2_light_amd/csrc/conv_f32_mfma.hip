@@ -69,13 +69,17 @@ struct ConvF32Dev {
     int Ntotal;
     int OHW;
     int tiles_m;
+    int yolo_entries;
 };
 
 // VEC4 (1x1 / stride 1 / pad 0 layers with OH*OW % 4 == 0 and C % BK == 0): a row of the B panel is BN contiguous
 // floats of one channel plane, so a thread fetches 4 consecutive pixels with ONE 16-byte buffer load and stages
 // them with one ds_write_b128 (4x fewer VMEM and LDS-write instructions than the per-pixel gather); the k row of
 // a lane goes into its voffset, the panel's first channel into the scalar offset.
-template <int BM, int BN, int WM, int WN, int KS, int BK, int NWAVES, bool TAPMAJOR, bool VEC4 = false>
+// YOLO: the [yolo] layer behind a linear 1x1 head convolution folded into the epilogue (forward_yolo_layer_cpu,
+// src/yolov2_forward_network.c: logistic_activate on every entry of an anchor except the raw w/h, i.e. rows m with
+// m % (classes + 5) not in {2, 3}); same expression as yolo_kernel (layers.hip), so the tensor is bit-identical.
+template <int BM, int BN, int WM, int WN, int KS, int BK, int NWAVES, bool TAPMAJOR, bool VEC4 = false, bool YOLO = false>
 __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32Dev p)
 {
     constexpr int NT = NWAVES * 64;
@@ -385,10 +389,16 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
         for (int e = 0; e < 16; ++e) {
             const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
             const float bv = (m < p.M) ? p.bias[m] : 0.f;
+            bool logistic = false;
+            if constexpr (YOLO) {
+                const int entry = m % p.yolo_entries;
+                logistic = entry != 2 && entry != 3;
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float v = acc[i][j][e] + bv;
                 if (p.act == YL_LEAKY) v = (v > 0.f) ? v : (float)(.1 * (double)v);
+                if constexpr (YOLO) { if (logistic) v = (float)(1. / (1. + exp((double)(-v)))); }
                 vals[j][e] = v;
             }
         }
@@ -411,6 +421,9 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
 template <int BM, int BN, int WM, int WN, int BK, int NWAVES>
 static int launch_pipe(const ConvF32Dev &d, int ks, bool tapmajor, hipStream_t s, bool vec4 = false)
 {
+    // the folded [yolo] epilogue exists for the two tiles head convolutions take (64x64, 128x128r)
+    constexpr bool YOLO_TILE = (BM == 64 && BN == 64) || (BM == 128 && BN == 128 && WM == 4);
+    if (d.yolo_entries > 0 && !(YOLO_TILE && ks == 1 && !tapmajor)) return (int)hipErrorInvalidValue;
     ConvF32Dev p = d;
     p.tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n = (p.Ntotal + BN - 1) / BN;
@@ -426,8 +439,22 @@ static int launch_pipe(const ConvF32Dev &d, int ks, bool tapmajor, hipStream_t s
         else hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 0, BK, NWAVES, true>), grid, block, 0, s, p);
     } else if (ks == 1 && vec4) {
         if (p.C % BK != 0 || p.OHW % 4 != 0 || p.stride != 1) return (int)hipErrorInvalidValue;
+        if constexpr (YOLO_TILE) {
+            if (p.yolo_entries > 0) {
+                hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 1, BK, NWAVES, false, true, true>), grid, block, 0, s, p);
+                return (int)hipGetLastError();
+            }
+        }
         hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 1, BK, NWAVES, false, true>), grid, block, 0, s, p);
-    } else if (ks == 1) hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 1, BK, NWAVES, false>), grid, block, 0, s, p);
+    } else if (ks == 1) {
+        if constexpr (YOLO_TILE) {
+            if (p.yolo_entries > 0) {
+                hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 1, BK, NWAVES, false, false, true>), grid, block, 0, s, p);
+                return (int)hipGetLastError();
+            }
+        }
+        hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 1, BK, NWAVES, false>), grid, block, 0, s, p);
+    }
     else if (ks == 3) hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 3, BK, NWAVES, false>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((conv_f32_mfma_pipe_kernel<BM, BN, WM, WN, 0, BK, NWAVES, false>), grid, block, 0, s, p);
     return (int)hipGetLastError();
@@ -455,6 +482,11 @@ static int launch_conv_f32_direct(const ConvF32Args &a, int cfg, int variant, vo
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     d.Ntotal = (int)nt;
     d.tiles_m = 0;
+    d.yolo_entries = a.yolo_entries;
+    if (a.yolo_entries > 0) {
+        if (a.size != 1 || a.pad != 0 || a.tapmajor || a.q_out || a.add) return (int)hipErrorInvalidValue;
+        if (cfg != 4 && cfg != 12) cfg = 12;
+    }
     hipStream_t s = (hipStream_t)stream;
     int ks = 0;
     if (a.size == 1 && a.pad == 0) ks = 1;
@@ -477,7 +509,8 @@ static int launch_conv_f32_direct(const ConvF32Args &a, int cfg, int variant, vo
     case 12: t = "128x128r";    rc = launch_pipe<128, 128, 4, 1, 16, 4>(d, ks, a.tapmajor != 0, s, vec4); break;
     default: return (int)hipErrorInvalidValue;
     }
-    if (name) snprintf(name, name_len, "conv_f32_mfma_pipe<%s,ks%d%s%s>", t, ks, a.tapmajor ? ",tap" : "", vec4 ? ",v4" : "");
+    if (name) snprintf(name, name_len, "conv_f32_mfma_pipe<%s,ks%d%s%s%s>", t, ks, a.tapmajor ? ",tap" : "", vec4 ? ",v4" : "",
+                       a.yolo_entries > 0 ? ",yolo" : "");
     return rc;
 }
 
@@ -489,6 +522,10 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
     // ([64,288,92416]) Winograd wins stand-alone (1.59 vs 2.16 ms) but not in the network, where the
     // layer carries a fused shortcut and is bound by 3 GB of epilogue traffic (2.31 vs 2.2 ms): C >= 64.
     if (a.q_out && a.wino32_u) return (int)hipErrorInvalidValue;      // the planner gives q_out to direct layers only
+    if (a.yolo_entries > 0)                                           // folded [yolo]: 1x1 direct kernel, two tiles
+        return launch_conv_f32_direct(a, (o.force_tile == 14 || o.force_tile == 22) ? o.force_tile - 10 :
+                                      (((long long)((a.M + 127) / 128) * (((long long)a.B * a.OH * a.OW + 127) / 128) >= 512) ? 12 : 4),
+                                      o.variant, stream, name, name_len);
     if (a.wino32_u && (o.force_tile == 31 || (o.force_tile == 0 && o.winograd && a.C >= ((o.variant & 16) ? 32 : 64))))
         return launch_conv_f32_wino32(a, a.wino32_u, o.variant, stream, name, name_len);
     if (o.force_tile == 31) return (int)hipErrorInvalidValue;   // forced on a layer without packed U

@@ -100,7 +100,8 @@ int launch_quantize_nhwc(const float *in, int8_t *out, int B, int C, int H, int 
 //   - one LDS panel = BK16 16-byte k-units (128 bytes of K), double-buffered; registers hold
 //     panel kb+1 and are refilled with panel kb+2 in slices interleaved with the MFMAs (as K1)
 //   - when G >= BK16 (C >= 128) a panel lies inside one tap: tap decode once per panel
-constexpr int BK16 = 8;          // 16-byte k-units per LDS panel (= 4 MFMA k-steps of 32)
+//   - BK16 = 16-byte k-units per LDS panel: 8 (= 4 MFMA k-steps of 32; 64 KB of LDS at 128x128: 2 workgroups
+//     per CU) or 4 (half the LDS, a barrier every 2 k-steps, more workgroups per CU to overlap epilogues)
 
 struct ConvI8Dev {
     const int8_t *in_q;
@@ -136,7 +137,7 @@ __device__ __forceinline__ float div10_exact(float y)
     return div10_markstein(y);
 }
 
-template <int BM, int BN, int WM, int WN, bool TAPPANEL, bool MFULL>
+template <int BM, int BN, int WM, int WN, bool TAPPANEL, bool MFULL, int BK16 = 8>
 __global__ __launch_bounds__(WM * WN * 64) void conv_i8_mfma_kernel(ConvI8Dev p)
 {
     constexpr int NT = WM * WN * 64;
@@ -501,9 +502,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_i8_mfma_kernel(ConvI8Dev p)
 #undef YL_ROW_OK
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int BK16 = 8>
 static int launch_i8_tile(ConvI8Dev p, hipStream_t s)
 {
+    p.K16pad = (p.K16 + BK16 - 1) / BK16 * BK16;          // <= the host's padding to 8 units
     p.tiles_m = (p.M + BM - 1) / BM;
     const long long blocks = (long long)p.tiles_m * ((p.Ntotal + BN - 1) / BN);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
@@ -512,15 +514,16 @@ static int launch_i8_tile(ConvI8Dev p, hipStream_t s)
     // a panel of BK16 units lies inside one tap when G is a multiple of BK16 (C >= 128)
     const bool tap = p.G >= BK16;
     dim3 grid((unsigned)blocks), block(NT);
-    if (tap && mfull) hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, p);
-    else if (tap) hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, p);
-    else if (mfull) hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, p);
+    if (tap && mfull) hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, true, true, BK16>), grid, block, 0, s, p);
+    else if (tap) hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, true, false, BK16>), grid, block, 0, s, p);
+    else if (mfull) hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, false, true, BK16>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, false, false, BK16>), grid, block, 0, s, p);
     return (int)hipGetLastError();
 }
 
 // tile: 0 = heuristic, 1 = 64x128 (4 waves, wave tile 32x64), 2 = 32x256, 3 = 128x128 (wave tile 64x64),
-//       4 = 128x256 (8 waves, wave tile 64x64), 5 = 64x256 (wave tile 64x64)
+//       4 = 128x256 (8 waves, wave tile 64x64), 5 = 64x256 (wave tile 64x64), 6 / 7 = 128x128 / 64x128 with half-depth
+//       LDS panels (BK16 = 4)
 int launch_conv_i8(const ConvI8Args &a, int tile, void *stream, char *name, size_t name_len)
 {
     ConvI8Dev d;
@@ -534,7 +537,7 @@ int launch_conv_i8(const ConvI8Args &a, int tile, void *stream, char *name, size
     d.Gshift = 0;
     while ((1 << d.Gshift) < d.G) ++d.Gshift;
     d.K16 = a.size * a.size * d.G;
-    d.K16pad = (d.K16 + BK16 - 1) / BK16 * BK16;
+    d.K16pad = (d.K16 + 7) / 8 * 8;
     d.OHW = a.OH * a.OW;
     const long long nt = (long long)a.B * d.OHW;
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
@@ -551,7 +554,7 @@ int launch_conv_i8(const ConvI8Args &a, int tile, void *stream, char *name, size
         else if (nblocks(128, 128) >= 512) tile = 3;
         else tile = 1;
     }
-    if ((tile == 3 || tile == 4) && a.Mpad % 128 != 0) tile = 1;
+    if ((tile == 3 || tile == 4 || tile == 6) && a.Mpad % 128 != 0) tile = 1;
     const char *t = "?";
     int rc;
     switch (tile) {
@@ -560,6 +563,8 @@ int launch_conv_i8(const ConvI8Args &a, int tile, void *stream, char *name, size
     case 3: t = "128x128"; rc = launch_i8_tile<128, 128, 2, 2>(d, s); break;
     case 4: t = "128x256w8"; rc = launch_i8_tile<128, 256, 2, 4>(d, s); break;
     case 5: t = "64x256"; rc = launch_i8_tile<64, 256, 1, 4>(d, s); break;
+    case 6: t = "128x128k4"; rc = launch_i8_tile<128, 128, 2, 2, 4>(d, s); break;
+    case 7: t = "64x128k4"; rc = launch_i8_tile<64, 128, 2, 2, 4>(d, s); break;
     default: return (int)hipErrorInvalidValue;
     }
     if (name) snprintf(name, name_len, "conv_i8_mfma<%s>", t);

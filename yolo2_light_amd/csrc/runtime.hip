@@ -296,7 +296,7 @@ static int to_device(Network &net, int device)
     }
     if (net.binbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_binbuf, net.binbuf_bytes));
     // ---- optional conv+shortcut fusion plan ----
-    for (Layer &l : net.layers) { l.fused_shortcut = -1; l.fused_into_conv = false; }
+    for (Layer &l : net.layers) { l.fused_shortcut = -1; l.fused_yolo = -1; l.fused_into_conv = false; }
     if (net.fuse && !net.debug) {
         const int nl = (int)net.layers.size();
         for (int i = 1; i < nl; ++i) {
@@ -316,6 +316,28 @@ static int to_device(Network &net, int device)
             if (referenced) continue;
             cv.fused_shortcut = i;
             sc.fused_into_conv = true;
+        }
+    }
+    // ---- [yolo] folded into the linear 1x1 FP32 head convolution in front of it: the activation runs in the conv's
+    //      epilogue and the conv's own tensor (one full write + one full read of the head) is never materialised
+    if (net.fuse && !net.debug) {
+        const int nl = (int)net.layers.size();
+        for (int i = 1; i < nl; ++i) {
+            Layer &yo = net.layers[i];
+            Layer &cv = net.layers[i - 1];
+            if (yo.type != YL_YOLO || cv.type != YL_CONVOLUTIONAL || cv.conv_mode != CONV_F32 || cv.xnor) continue;
+            if (cv.size != 1 || cv.pad != 0 || cv.stride != 1 || cv.activation != YL_LINEAR || cv.fused_shortcut >= 0) continue;
+            if (cv.n != yo.n * (yo.classes + 5)) continue;
+            bool referenced = false;
+            for (int j = i + 1; j < nl && !referenced; ++j) {
+                const Layer &o = net.layers[j];
+                if (o.type == YL_SHORTCUT && o.index == i - 1) referenced = true;
+                if (o.type == YL_ROUTE)
+                    for (int id : o.input_layers) if (id == i - 1) referenced = true;
+            }
+            if (referenced) continue;
+            cv.fused_yolo = i;
+            yo.fused_into_conv = true;
         }
     }
     // ---- optional quantise-on-store plan (INT8): the producer of an INT8 conv's input emits the
@@ -452,6 +474,11 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
             a.tapmajor = l.tapmajor;
             a.wino32_u = l.d_wino32_u;
+            if (l.fused_yolo >= 0) {
+                const Layer &yo = net.layers[l.fused_yolo];
+                a.yolo_entries = yo.classes + 5;
+                a.out = yo.d_output;
+            }
             YL_LAUNCH(launch_conv_f32(a, net.conv_opts, s, l.kernel_name, sizeof(l.kernel_name)), "conv_f32");
         } else if (l.conv_mode == CONV_INT8) {
             int8_t *q_in = net.d_qbuf + (i % 3) * net.qbuf_bytes;
@@ -571,6 +598,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
         YL_LAUNCH(launch_upsample(input, l.d_output, B, l.c, l.h, l.w, l.stride, l.scale, s), "upsample");
         break;
     case YL_YOLO:
+        if (l.fused_into_conv) break;          // written by the head convolution's epilogue
         YL_LAUNCH(launch_yolo(input, l.d_output, B, l.n, l.classes, l.w * l.h, s), "yolo");
         break;
     case YL_REGION:
@@ -611,7 +639,7 @@ static int forward(Network &net, const float *input_dev, int slot)
 static bool layer_materialised(const Layer &l)
 {
     if (l.type == YL_MAXPOOL || l.type == YL_ROUTE) return !l.skip_f32_out;
-    return !(l.type == YL_CONVOLUTIONAL && (l.fused_shortcut >= 0 || l.skip_f32_out));
+    return !(l.type == YL_CONVOLUTIONAL && (l.fused_shortcut >= 0 || l.fused_yolo >= 0 || l.skip_f32_out));
 }
 
 static int pull_heads(Network &net, bool also_last)
@@ -868,6 +896,9 @@ int yl_network_layer_traffic(const yl_network *net, int i, double *bytes)
     }
     case YL_SHORTCUT:
         if (!l.fused_into_conv) { rd += 8 * out_el; wr += 4 * out_el; }
+        break;
+    case YL_YOLO:
+        if (!l.fused_into_conv) { rd += 4 * in_el; wr += 4 * out_el; }
         break;
     case YL_MAXPOOL: {
         const double wi = B * (double)l.h * l.w * 8.0 * ((l.c + 63) / 64), wo = B * (double)l.out_h * l.out_w * 8.0 * ((l.c + 63) / 64);
@@ -1192,7 +1223,7 @@ int yl_network_set_precision(yl_network *net, int precision)
 int yl_network_set_int8_tile(yl_network *net, int cfg)
 {
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }
-    if (cfg < 0 || cfg > 5) { set_error("unknown tile id"); return YL_ERR_ARG; }
+    if (cfg < 0 || cfg > 7) { set_error("unknown tile id"); return YL_ERR_ARG; }
     net->net.i8_tile = cfg;
     return YL_OK;
 }

@@ -62,6 +62,7 @@ struct Layer {
     int  *d_tree = nullptr;              // region softmax tree: parent[classes] then group_size[groups]
     char kernel_name[64] = "";           // kernel instance of this layer's last launch
     int   fused_shortcut = -1;           // conv: index of the [shortcut] layer folded into its epilogue
+    int   fused_yolo = -1;               // FP32 1x1 head conv: index of the [yolo] layer folded into its epilogue
     bool  fused_into_conv = false;       // shortcut: produced by the preceding conv's epilogue
     bool  q_from_producer = false;       // INT8 conv: its quantised input is written by the producing conv
     bool  q_from_route = false;          // INT8 conv: its input is a multi-input [route], quantised source by source
