@@ -119,6 +119,12 @@ int yl_network_calculate_binary_weights(yl_network *net);
 /* quantinization_and_get_multipliers(net)             src/yolov2_forward_network_quantized.c:1402 */
 int yl_network_quantize(yl_network *net);
 
+/* The three passes above on the GPU: yolov2_fuse_conv_batchnorm, calculate_binary_weights' mean_arr
+ * and -- for a network created with quantized != 0 -- quantinization_and_get_multipliers, in that order, with
+ * explicitly rounded device arithmetic: folded weights / biases, mean_arr, weights_int8 and both multipliers are
+ * bit-identical to the host passes (csrc/prep.hip).  Before yl_network_to_device; needs loaded weights. */
+int yl_network_prepare_on_device(yl_network *net, int device);
+
 /* Which convolutions `quantized` applies to.  The reference has two rules:
  *   YL_QUANT_RULE_CPU (default)  yolov2_forward_network_q: every conv with index >= 1 and a non-linear
  *                                activation (src/yolov2_forward_network_quantized.c:1036)

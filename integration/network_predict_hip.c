@@ -88,6 +88,11 @@ static yl_network *hip_build(network *net)
                                     net->input_calibration, net->input_calibration_size, &h) != YL_OK)
         hip_fail("yl_network_create_from_desc");
     free(d);
+    /* opt-in: bf16 operands for the FP32 convolutions (outside the FP32 path's 1e-4 contract) */
+    {
+        const char *bf = getenv("YL_BF16");
+        if (bf && *bf && *bf != '0' && yl_network_set_precision(h, YL_PRECISION_BF16) != YL_OK) hip_fail("yl_network_set_precision");
+    }
     /* conv+[shortcut] epilogue fusion and quantise-on-store: bit-identical head tensors, fewer kernels */
     if (yl_network_set_fusion(h, 1) != YL_OK) hip_fail("yl_network_set_fusion");
     {

@@ -49,6 +49,12 @@ def test_no_gpu_means_loud_failure_not_fallback():
         pass
     else:
         raise AssertionError("predict succeeded without a GPU")
+    # the on-device prep passes have no host fallback either (the host passes are separate entry points)
+    cfg, wts = __import__("common").model_files("yolov3-tiny", 64, 64)
+    net2 = Network.from_cfg(cfg, 1, 0)
+    net2.load_weights(wts)
+    assert _lib.lib.yl_network_prepare_on_device(net2._h, 0) == -4        # YL_ERR_DEVICE
+    assert net2.layer_info(0)["batch_normalize"] == 1                     # nothing was folded on the host instead
 
 
 def test_layer_desc_struct_matches_header_field_order():

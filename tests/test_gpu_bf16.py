@@ -113,10 +113,10 @@ def test_bf16_vs_fp32_deviation_is_reported_and_bounded():
     worst = 0.0
     for i, li in enumerate(f32.layers()):
         if li["type"] == common.YOLO:
-            a, b = f32.layer_output(i - 1), b16.layer_output(i - 1)        # the linear conv feeding the head
+            a, b = f32.layer_output(i), b16.layer_output(i)                # the head tensors the decode reads
             rel = float(np.sqrt(np.mean((a - b) ** 2)) / (np.sqrt(np.mean(a ** 2)) + 1e-30))
             corr = float(np.corrcoef(a, b)[0, 1])
-            print("head conv %d: rel rms %.3e corr %.6f" % (i - 1, rel, corr))
+            print("head %d: rel rms %.3e corr %.6f" % (i, rel, corr))
             worst = max(worst, rel)
             assert corr > 0.999
     assert worst < 5e-2

@@ -88,6 +88,20 @@ void calculate_binary_weights(Network &net) {
     }
 }
 
+// second half of get_multiplier (src/yolov2_forward_network_quantized.c): the window of `bits_length` power-of-two
+// ranges holding the most weights decides the multiplier; count[j] = #{w : 2^(j-16) <= w < 2^(j-15)}
+float multiplier_from_range_counts(const int *count, int bits_length) {
+    const int number_of_ranges = 32;
+    const float start_range = 1.F / 65536;
+    int max_count_range = 0, index_max_count = 0;
+    for (int j = 0; j < number_of_ranges; ++j) {
+        int counter = 0;
+        for (int i = j; i < (j + bits_length) && i < number_of_ranges; ++i) counter += count[i];
+        if (max_count_range < counter) { max_count_range = counter; index_max_count = j; }
+    }
+    return 1 / (start_range * powf(2.f, (float)index_max_count));
+}
+
 namespace {
 
 // get_multiplier(arr, size, bits_length) -- only strictly positive values land in a bin
@@ -104,13 +118,7 @@ float weights_multiplier(const float *arr, size_t n, int bits_length) {
             cur_range *= 2;
         }
     }
-    int max_count_range = 0, index_max_count = 0;
-    for (int j = 0; j < number_of_ranges; ++j) {
-        int counter = 0;
-        for (int i = j; i < (j + bits_length) && i < number_of_ranges; ++i) counter += count[i];
-        if (max_count_range < counter) { max_count_range = counter; index_max_count = j; }
-    }
-    return 1 / (start_range * powf(2.f, (float)index_max_count));
+    return multiplier_from_range_counts(count, bits_length);
 }
 
 inline int max_abs_int(int src, int max_val) {

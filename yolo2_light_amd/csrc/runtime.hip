@@ -804,6 +804,13 @@ int yl_network_quantize(yl_network *net)
     return YL_OK;
 }
 
+int yl_network_prepare_on_device(yl_network *net, int device)
+{
+    if (!net) { set_error("null argument"); return YL_ERR_ARG; }
+    if (!net->net.weights_loaded) { set_error("prepare_on_device: no weights loaded"); return YL_ERR_STATE; }
+    return prepare_on_device(net->net, device);
+}
+
 void yl_network_destroy(yl_network *net)
 {
     if (!net) return;

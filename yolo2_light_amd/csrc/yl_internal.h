@@ -142,6 +142,9 @@ void fuse_conv_batchnorm(Network &net);
 void calculate_binary_weights(Network &net);
 void quantize_network(Network &net);
 void select_conv_modes(Network &net);
+float multiplier_from_range_counts(const int *count, int bits_length);
+// prep.hip: the same three passes on the GPU, results bit-identical to the host passes
+int prepare_on_device(Network &net, int device);
 // host_calib.cpp
 float entropy_from_counts(const uint32_t *counts, int max_bin, float bin_width);
 }  // namespace yl

@@ -63,7 +63,7 @@ class Network:
     @classmethod
     def load(cls, cfg_path: str, weights_path: str, batch: int = 1, quantized: int = 0,
              device: Optional[int] = None, debug: bool = False, fuse: bool = False,
-             quant_rule: int = 0, winograd: bool = True, bf16: bool = False) -> "Network":
+             quant_rule: int = 0, winograd: bool = True, bf16: bool = False, device_prep: bool = False) -> "Network":
         """The full prep sequence of test_detector_cpu (src/main.c:160-171)."""
         net = cls.from_cfg(cfg_path, batch, quantized)
         if quant_rule:
@@ -73,10 +73,15 @@ class Network:
         if bf16:
             net.set_precision(1)
         net.load_weights(weights_path)
-        net.fuse_conv_batchnorm()
-        net.calculate_binary_weights()
-        if quantized:
-            net.quantize()
+        if device_prep:
+            # the same three passes on the GPU, bit-identical results (csrc/prep.hip)
+            check(lib.yl_network_prepare_on_device(net._h, device if device is not None else 0),
+                  "yl_network_prepare_on_device")
+        else:
+            net.fuse_conv_batchnorm()
+            net.calculate_binary_weights()
+            if quantized:
+                net.quantize()
         if debug:
             check(lib.yl_network_set_debug(net._h, 1), "yl_network_set_debug")
         if fuse:
