@@ -402,12 +402,23 @@ def int8_roofline(leg, prefix="conv_i8", mfma_peak=None, what="int8"):
     tot_ms = sum(k["ms"] for k in i8.values())
     tot_bytes = sum(k["bytes"] for k in i8.values())
     tot_ops = sum(k["flops"] for k in i8.values())
+    traffic = None
+    try:
+        if leg.args.model == "yolov3" and leg.args.size == 608 and leg.B == 64:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pt = json.load(f).get(dom_name)
+            if pt:
+                traffic = (2.0 * pt["fetch_kib"] + pt["write_kib"]) * 1024.0
+    except (OSError, ValueError):
+        traffic = None
     return {
         "bound": "hbm", "kernel": dom_name,
         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
         "achieved_is": "algorithmic bytes (%s in, weights, FP32 [shortcut] operand in / sum out, %s side output; "
                        "yl_network_layer_traffic) of the kernel's launches / their measured duration" % (what, what),
-        "traffic": None, "traffic_source": "see profiles/r2_pmc_int8_*.txt (own rocprofv3 passes)",
+        "traffic": traffic,
+        "traffic_source": "committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE in their own "
+                          "runs, gfx950 correction applied), not collected in this run",
         "mfma_tops": tops, "mfma_peak_tops": mfma_peak, "mfma_frac": tops / mfma_peak,
         "algorithmic_bytes_per_launch": dom["bytes"] / n, "launches_per_step": dom["launches"],
         "avg_launch_ms": dom["ms"] / n,

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void fold_bn_kernel(float *__restrict__ w, flo
     const size_t total = (size_t)n * k;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int f = (int)(idx / k);
-        const float den = __fadd_rn(__fsqrt_rn(var[f]), .000001f);
+        const float den = __fadd_rn(sqrtf(var[f]), .000001f);      // sqrtf: correctly rounded (hipcc default); __fsqrt_rn is the NATIVE approximation in this toolchain
         w[idx] = __fdiv_rn(__fmul_rn(w[idx], scales[f]), den);
         if (idx - (size_t)f * k == 0) bias[f] = __fsub_rn(bias[f], __fdiv_rn(__fmul_rn(scales[f], mean[f]), den));
     }
