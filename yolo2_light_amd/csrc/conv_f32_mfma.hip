@@ -526,7 +526,8 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
         return launch_conv_f32_direct(a, (o.force_tile == 14 || o.force_tile == 22) ? o.force_tile - 10 :
                                       (((long long)((a.M + 127) / 128) * (((long long)a.B * a.OH * a.OW + 127) / 128) >= 512) ? 12 : 4),
                                       o.variant, stream, name, name_len);
-    if (a.wino32_u && (o.force_tile == 31 || (o.force_tile == 0 && o.winograd && a.C >= ((o.variant & 16) ? 32 : 64))))
+    if (a.wino32_u && (o.force_tile == 31 || (o.force_tile == 0 && o.winograd && a.C >= ((o.variant & 16) ? 32 : 64) &&
+                                             wino32_fits(a.B, a.M, a.H, a.W))))
         return launch_conv_f32_wino32(a, a.wino32_u, o.variant, stream, name, name_len);
     if (o.force_tile == 31) return (int)hipErrorInvalidValue;   // forced on a layer without packed U
     if (o.force_tile == 41 || (o.force_tile == 0 && (o.variant & 8) && smallk_applicable(a)))

@@ -113,6 +113,142 @@ __device__ __forceinline__ void input_transform32(const float (&d)[16], float (&
 
 }  // namespace
 
+// Epilogue of one wave.  Wave (wt, PH) holds M[i][j] for rows i = 2*PH, 2*PH+1 (planes 8*PH + 4*(i&1) + j) of the
+// 32x32 (m, t) block of tile half wt.  Row i of A^T M A needs planes of both halves, so the two waves of a tile
+// half swap partial row sums through the dead panel stages (xch[wave][32][64] floats, the loop's last barrier has
+// passed), each finishing 8 of the 16 accumulator rows.  Addresses: one 32-bit BYTE offset per lane from the
+// tensor base (the launcher keeps Winograd to tensors below 4 GB), row / filter strides added as constants.
+template <int PH, bool APF>
+__device__ __forceinline__ void wino32_epilogue(const ConvWino32Dev &p, const f32x16 (&acc)[8], float *smem, int wave,
+                                                int lane, int m0, int t0)
+{
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+    const int wt = wave & 1;
+    float *xch = smem;
+    const int tg_e = t0 + wt * 32 + l31;
+    const bool t_ok_e = tg_e < p.T;
+    const int b_e = t_ok_e ? tg_e / p.tpi : 0;
+    const int r_e = tg_e - b_e * p.tpi;
+    const int ti_e = r_e / p.tw;
+    const int tj_e = r_e - ti_e * p.tw;
+    const int oy = 2 * ti_e, ox = 2 * tj_e;
+    const bool row1 = oy + 1 < p.H;
+    const bool col1 = ox + 1 < p.W;
+    const bool vec2 = col1 && ((p.W & 1) == 0);
+    const unsigned HW4 = (unsigned)(p.H * p.W) * 4u;
+    const unsigned W4 = (unsigned)p.W * 4u;
+    // byte offset of (b_e, m0 + 4*half, oy, ox)
+    const unsigned obase = ((((unsigned)b_e * (unsigned)p.M + (unsigned)(m0 + 4 * half)) * (unsigned)p.H + (unsigned)oy) *
+                            (unsigned)p.W + (unsigned)ox) * 4u;
+    const char *addb = reinterpret_cast<const char *>(p.add);
+    char *outb = reinterpret_cast<char *>(p.out);
+    char *oaddb = reinterpret_cast<char *>(p.out_add);
+    float *mine = xch + wave * 2048 + lane;
+    const float *theirs = xch + (wave ^ 2) * 2048 + lane;
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        float apf[4][2][2];
+        if constexpr (APF) {
+            if (p.add) {
+#pragma unroll
+                for (int ee = 0; ee < 4; ++ee) {
+                    const int e = 8 * rnd + (PH ? 4 + ee : ee);
+                    const int mrow = (e & 3) + 8 * (e >> 2);            // + 4*half is in obase
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) apf[ee][i][0] = apf[ee][i][1] = 0.f;
+                    if (m0 + mrow + 4 * half < p.M && t_ok_e) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            if (i == 1 && !row1) break;
+                            const unsigned o = obase + (unsigned)mrow * HW4 + (unsigned)i * W4;
+                            if (vec2) {
+                                const float2 a = *reinterpret_cast<const float2 *>(addb + o);
+                                apf[ee][i][0] = a.x; apf[ee][i][1] = a.y;
+                            } else {
+                                apf[ee][i][0] = *reinterpret_cast<const float *>(addb + o);
+                                if (col1) apf[ee][i][1] = *reinterpret_cast<const float *>(addb + o + 4u);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // send: PH 1 gives (M2, M2 + M3) of rows e = 8*rnd .. +3; PH 0 gives (M0 + M1, M1) of e = 8*rnd+4 .. +7
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+            const int e = 8 * rnd + (PH ? ee : 4 + ee);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = acc[j][e], hi = acc[4 + j][e];
+                mine[(ee * 8 + j) * 64] = PH ? lo : (lo + hi);
+                mine[(ee * 8 + 4 + j) * 64] = PH ? (lo + hi) : hi;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+            const int e = 8 * rnd + (PH ? 4 + ee : ee);
+            const int mrow = (e & 3) + 8 * (e >> 2);
+            const int m = m0 + mrow + 4 * half;
+            float tmp[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float g0 = theirs[(ee * 8 + j) * 64], g1 = theirs[(ee * 8 + 4 + j) * 64];
+                const float lo = acc[j][e], hi = acc[4 + j][e];
+                if (PH) {            // have M2 = lo, M3 = hi; got M0 + M1, M1
+                    tmp[0][j] = g0 + lo;
+                    tmp[1][j] = g1 - (lo + hi);
+                } else {             // have M0 = lo, M1 = hi; got M2, M2 + M3
+                    tmp[0][j] = (lo + hi) + g0;
+                    tmp[1][j] = hi - g1;
+                }
+            }
+            if (m < p.M && t_ok_e) {
+                const float bv = p.bias[m];
+                float y[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    y[i][0] = ((tmp[i][0] + tmp[i][1]) + tmp[i][2]) + bv;
+                    y[i][1] = ((tmp[i][1] - tmp[i][2]) - tmp[i][3]) + bv;
+                    if (p.act == YL_LEAKY) {
+                        y[i][0] = (y[i][0] > 0.f) ? y[i][0] : (float)(.1 * (double)y[i][0]);
+                        y[i][1] = (y[i][1] > 0.f) ? y[i][1] : (float)(.1 * (double)y[i][1]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (i == 1 && !row1) break;
+                    const unsigned o = obase + (unsigned)mrow * HW4 + (unsigned)i * W4;
+                    if (vec2) {
+                        if (p.out) *reinterpret_cast<float2 *>(outb + o) = make_float2(y[i][0], y[i][1]);
+                        if (p.add) {
+                            float2 a;
+                            if constexpr (APF) a = make_float2(apf[ee][i][0], apf[ee][i][1]);
+                            else a = *reinterpret_cast<const float2 *>(addb + o);
+                            *reinterpret_cast<float2 *>(oaddb + o) =
+                                make_float2(__fadd_rn(y[i][0], a.x), __fadd_rn(y[i][1], a.y));
+                        }
+                    } else {
+                        if (p.out) {
+                            *reinterpret_cast<float *>(outb + o) = y[i][0];
+                            if (col1) *reinterpret_cast<float *>(outb + o + 4u) = y[i][1];
+                        }
+                        if (p.add) {
+                            *reinterpret_cast<float *>(oaddb + o) =
+                                __fadd_rn(y[i][0], APF ? apf[ee][i][0] : *reinterpret_cast<const float *>(addb + o));
+                            if (col1)
+                                *reinterpret_cast<float *>(oaddb + o + 4u) =
+                                    __fadd_rn(y[i][1], APF ? apf[ee][i][1] : *reinterpret_cast<const float *>(addb + o + 4u));
+                        }
+                    }
+                }
+            }
+        }
+        if (rnd == 0) __syncthreads();
+    }
+}
+
 // VAR bit 0 (UDMA): the U panels go global -> LDS directly (global_load_lds_dwordx4, the packed panel IS the
 //   lane-linear LDS image): no VGPR round trip, no ds_write for the weights.  The stage a panel lands in was last
 //   read (fragments of panel kb-2) before the barrier the DMA is issued after; every wave drains its own DMAs
@@ -345,118 +481,17 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
 #undef X_LOAD_X
 
     // ---- epilogue ----
-    // wave (wt, ph) holds M[i][j] for rows i = 2*ph, 2*ph+1 (planes 8*ph + 4*(i&1) + j) of the
-    // 32x32 (m, t) block of tile half wt.  Exchange buffer: xch[wave][32][64] floats (32 KB) in the
-    // dead panel stages (the loop's last barrier has passed).
-    float *xch = smem;
-    const int tg_e = t0 + wt * 32 + l31;
-    const bool t_ok_e = tg_e < p.T;
-    const int b_e = t_ok_e ? tg_e / p.tpi : 0;
-    const int r_e = tg_e - b_e * p.tpi;
-    const int ti_e = r_e / p.tw;
-    const int tj_e = r_e - ti_e * p.tw;
-    const int oy = 2 * ti_e, ox = 2 * tj_e;
-    const bool row1 = oy + 1 < p.H;
-    const bool col1 = ox + 1 < p.W;
-    const bool vec2 = col1 && ((p.W & 1) == 0);
-    float *mine = xch + wave * 2048 + lane;
-    const float *theirs = xch + (wave ^ 2) * 2048 + lane;
-#pragma unroll
-    for (int rnd = 0; rnd < 2; ++rnd) {
-        float apf[4][2][2];
-        if constexpr (APF) {
-            if (p.add) {
-#pragma unroll
-                for (int ee = 0; ee < 4; ++ee) {
-                    const int e = 8 * rnd + (ph ? 4 + ee : ee);
-                    const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * half;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) apf[ee][i][0] = apf[ee][i][1] = 0.f;
-                    if (m < p.M && t_ok_e) {
-                        const size_t o0 = (((size_t)b_e * p.M + m) * p.H + oy) * p.W + ox;
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            if (i == 1 && !row1) break;
-                            const size_t o = o0 + (size_t)i * p.W;
-                            if (vec2) {
-                                const float2 a = *reinterpret_cast<const float2 *>(p.add + o);
-                                apf[ee][i][0] = a.x; apf[ee][i][1] = a.y;
-                            } else {
-                                apf[ee][i][0] = p.add[o];
-                                if (col1) apf[ee][i][1] = p.add[o + 1];
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        // send: ph 1 gives (M2, M2 + M3) of rows e = 8*rnd .. +3; ph 0 gives (M0 + M1, M1) of e = 8*rnd+4 .. +7
-#pragma unroll
-        for (int ee = 0; ee < 4; ++ee) {
-            const int e = 8 * rnd + (ph ? ee : 4 + ee);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float lo = acc[j][e], hi = acc[4 + j][e];
-                mine[(ee * 8 + j) * 64] = ph ? lo : (lo + hi);
-                mine[(ee * 8 + 4 + j) * 64] = ph ? (lo + hi) : hi;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ee = 0; ee < 4; ++ee) {
-            const int e = 8 * rnd + (ph ? 4 + ee : ee);
-            const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * half;
-            float tmp[2][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float g0 = theirs[(ee * 8 + j) * 64], g1 = theirs[(ee * 8 + 4 + j) * 64];
-                const float lo = acc[j][e], hi = acc[4 + j][e];
-                if (ph) {            // have M2 = lo, M3 = hi; got M0 + M1, M1
-                    tmp[0][j] = g0 + lo;
-                    tmp[1][j] = g1 - (lo + hi);
-                } else {             // have M0 = lo, M1 = hi; got M2, M2 + M3
-                    tmp[0][j] = (lo + hi) + g0;
-                    tmp[1][j] = hi - g1;
-                }
-            }
-            if (m < p.M && t_ok_e) {
-                const float bv = p.bias[m];
-                float y[2][2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    y[i][0] = ((tmp[i][0] + tmp[i][1]) + tmp[i][2]) + bv;
-                    y[i][1] = ((tmp[i][1] - tmp[i][2]) - tmp[i][3]) + bv;
-                    if (p.act == YL_LEAKY) {
-                        y[i][0] = (y[i][0] > 0.f) ? y[i][0] : (float)(.1 * (double)y[i][0]);
-                        y[i][1] = (y[i][1] > 0.f) ? y[i][1] : (float)(.1 * (double)y[i][1]);
-                    }
-                }
-                const size_t o0 = (((size_t)b_e * p.M + m) * p.H + oy) * p.W + ox;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (i == 1 && !row1) break;
-                    const size_t o = o0 + (size_t)i * p.W;
-                    if (vec2) {
-                        if (p.out) *reinterpret_cast<float2 *>(p.out + o) = make_float2(y[i][0], y[i][1]);
-                        if (p.add) {
-                            float2 a;
-                            if constexpr (APF) a = make_float2(apf[ee][i][0], apf[ee][i][1]);
-                            else a = *reinterpret_cast<const float2 *>(p.add + o);
-                            *reinterpret_cast<float2 *>(p.out_add + o) =
-                                make_float2(__fadd_rn(y[i][0], a.x), __fadd_rn(y[i][1], a.y));
-                        }
-                    } else {
-                        if (p.out) { p.out[o] = y[i][0]; if (col1) p.out[o + 1] = y[i][1]; }
-                        if (p.add) {
-                            p.out_add[o] = __fadd_rn(y[i][0], APF ? apf[ee][i][0] : p.add[o]);
-                            if (col1) p.out_add[o + 1] = __fadd_rn(y[i][1], APF ? apf[ee][i][1] : p.add[o + 1]);
-                        }
-                    }
-                }
-            }
-        }
-        if (rnd == 0) __syncthreads();
-    }
+    // The plane half `ph` is wave-uniform: branch once so that every accumulator index below is a compile-time
+    // constant (with a runtime `ph` the compiler indexed the 128 accumulator registers dynamically: 72
+    // s_set_gpr_idx pairs and 330 v_mov per wave).
+    if (ph) wino32_epilogue<1, APF>(p, acc, smem, wave, lane, m0, t0);
+    else wino32_epilogue<0, APF>(p, acc, smem, wave, lane, m0, t0);
+}
+
+// the epilogue addresses the output (and the fused [shortcut] tensors of the same shape) with 32-bit byte offsets
+bool wino32_fits(int B, int M, int H, int W)
+{
+    return (long long)B * M * H * W * 4 < 0xFFFFFFF0LL;
 }
 
 bool wino_applicable(int C, int M, int size, int stride, int pad)
@@ -515,6 +550,7 @@ int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, int vari
     d.th = (a.H + 1) / 2; d.tw = (a.W + 1) / 2; d.tpi = d.th * d.tw;
     const long long T = (long long)a.B * d.tpi;
     if (T > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    if (!wino32_fits(a.B, a.M, a.H, a.W)) return (int)hipErrorInvalidValue;
     d.T = (int)T;
     d.tiles_m = (a.M + XBM - 1) / XBM;
     d.tiles_t = (int)((T + XBT - 1) / XBT);

@@ -44,6 +44,7 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
 // K1w (conv_f32_wino32.hip): Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 layers,
 // 32 filters x 64 tiles per workgroup, two workgroups per CU
 bool wino_applicable(int C, int M, int size, int stride, int pad);
+bool wino32_fits(int B, int M, int H, int W);     // output tensor below 4 GB (32-bit byte offsets in the epilogue)
 size_t wino32_packed_floats(int C, int M);
 void wino32_pack_weights(const float *w, int C, int M, float *dst);
 // K1s (conv_f32_smallk.hip): LDS-free kernel for first layers (C*size^2 <= 32, filters <= 32)

@@ -390,7 +390,9 @@ static int to_device(Network &net, int device)
             if (cons.type != YL_CONVOLUTIONAL || !(cons.conv_mode == CONV_INT8 || cons.conv_mode == CONV_BF16) || cons.q_from_producer) continue;
             const int uc = cons.conv_mode == CONV_BF16 ? 8 : 16;
             if (rt.type != YL_ROUTE || rt.d_output_alias || rt.n < 2 || referenced_elsewhere(j - 1, j)) continue;
-            bool ok = (cons.c % uc) == 0 && cons.Cpad == cons.c;
+            // channel groups beyond c (Cpad rounds the group count up to a power of two) are never written on this
+            // path: harmless for int8 (anything x zero weights = 0), not for bf16 (stale NaN / Inf x 0 = NaN)
+            bool ok = (cons.c % uc) == 0 && (cons.conv_mode == CONV_INT8 || cons.Cpad == cons.c);
             for (int k = 0; k < rt.n && ok; ++k) {
                 const Layer &src = net.layers[rt.input_layers[k]];
                 ok = (src.out_c % uc) == 0 && src.out_w == cons.w && src.out_h == cons.h &&
