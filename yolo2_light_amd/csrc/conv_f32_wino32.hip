@@ -76,6 +76,7 @@ struct ConvWino32Dev {
     int th, tw, tpi, T;
     int tiles_m, tiles_t, nkb;
     int act;
+    int vec2_any;          // variant bit 5: 8-byte accesses for the 2x2 output rows on odd widths too (4-byte aligned)
 };
 
 __device__ __forceinline__ void fix_rows32(float (&d)[16], bool left, bool inv2, bool inv3)
@@ -135,7 +136,7 @@ __device__ __forceinline__ void wino32_epilogue(const ConvWino32Dev &p, const f3
     const int oy = 2 * ti_e, ox = 2 * tj_e;
     const bool row1 = oy + 1 < p.H;
     const bool col1 = ox + 1 < p.W;
-    const bool vec2 = col1 && ((p.W & 1) == 0);
+    const bool vec2 = col1 && (((p.W & 1) == 0) || p.vec2_any);
     const unsigned HW4 = (unsigned)(p.H * p.W) * 4u;
     const unsigned W4 = (unsigned)p.W * 4u;
     // byte offset of (b_e, m0 + 4*half, oy, ox)
@@ -557,6 +558,7 @@ int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, int vari
     d.nkb = a.C / XBK;
     if (d.nkb < 4 || (d.nkb & 1)) return (int)hipErrorInvalidValue;
     d.act = a.act;
+    d.vec2_any = (variant & 32) ? 1 : 0;
     const long long blocks = (long long)d.tiles_m * d.tiles_t;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks), block(256);
@@ -567,7 +569,8 @@ int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, int vari
     case 2: hipLaunchKernelGGL(conv_f32_wino32_kernel<2>, grid, block, 0, s, d); break;
     default: hipLaunchKernelGGL(conv_f32_wino32_kernel<3>, grid, block, 0, s, d); break;
     }
-    if (name) snprintf(name, name_len, "conv_f32_wino<32x64t,f2x2%s%s>", (variant & 1) ? ",udma" : "", (variant & 2) ? ",apf" : "");
+    if (name) snprintf(name, name_len, "conv_f32_wino<32x64t,f2x2%s%s%s>", (variant & 1) ? ",udma" : "", (variant & 2) ? ",apf" : "",
+                       ((variant & 32) && (a.W & 1)) ? ",u2" : "");
     return (int)hipGetLastError();
 }
 
