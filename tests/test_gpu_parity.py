@@ -434,18 +434,16 @@ def test_winograd_variants_bit_identical(shape):
     net.set_variant(0)
     base = net.predict(x).copy()
     assert "wino" in net.layer_kernel(0) and "udma" not in net.layer_kernel(0)
-    for v in (1, 2, 3, 32, 34):
+    for v in (1, 2, 3):
         net.set_variant(v)
         got = net.predict(x)
         if v & 1:
             assert "udma" in net.layer_kernel(0)
-        if (v & 32) and (W & 1):
-            assert ",u2" in net.layer_kernel(0)
         assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), "variant %d shape %r" % (v, shape)
     net.close()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 15, 62])
+@pytest.mark.parametrize("variant", [1, 2, 3, 15, 30, 31])
 def test_variants_whole_network_fused_bit_identical(variant):
     """yolov3 with conv+[shortcut] fusion (the benched setup): every materialised tensor and the detections of
     a run with the schedule variants equal the plain schedule's bit for bit (odd and even map sizes)."""

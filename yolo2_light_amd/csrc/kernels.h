@@ -36,8 +36,8 @@ struct ConvF32Opts {
     // schedule variants kept switchable for same-box A/B runs (yl_network_set_variant): bit 0 Winograd U panels by
     // LDS-DMA, bit 1 Winograd epilogue requests the [shortcut] operand ahead of its LDS exchange, bit 2 1x1 direct
     // kernel loads the B panel as float4 rows, bit 3 LDS-free small-K kernel for the first layer (C*size^2 <= 32),
-    // bit 4 Winograd from 32 input channels up (default: from 64), bit 5 Winograd epilogue uses 8-byte accesses on odd
-    // map widths too (4-byte aligned float2)
+    // bit 4 Winograd from 32 input channels up (default: from 64).  (An 8-byte-access epilogue for odd map widths was
+    // measured and dropped: no gain, profiles/r2_ab_fp32_variants.txt.)
     int variant = YL_VARIANT_DEFAULT;
 };
 // writes the name of the kernel instance it launched into name[name_len]
