@@ -278,6 +278,21 @@ def fp32_close(got: np.ndarray, ref: np.ndarray, rtol: float = FP32_RTOL):
         float(ratio[worst]) if ratio.size else 0.0, worst
 
 
+def strict_max_rel(got: np.ndarray, ref: np.ndarray, floor_frac: float = 0.01) -> float:
+    """max |got-ref| / |ref| over the elements with |ref| > floor_frac * RMS(ref): the PURE relative error, without
+    fp32_close's RMS-tied absolute allowance (report it next to fp32_close).  Elements below 1 % of
+    the layer RMS are cancellation results whose relative error is set by the summation order, not by the kernel."""
+    got = np.asarray(got, dtype=np.float64).reshape(-1)
+    ref = np.asarray(ref, dtype=np.float64).reshape(-1)
+    if not ref.size:
+        return 0.0
+    rms = float(np.sqrt(np.mean(ref * ref)))
+    sel = np.abs(ref) > floor_frac * max(rms, 1e-30)
+    if not sel.any():
+        return 0.0
+    return float(np.max(np.abs(got[sel] - ref[sel]) / np.abs(ref[sel])))
+
+
 class OracleHeads:
     """The detection heads of a network as the oracle's decode wants them.  `outputs[i]` = the head
     tensor of layer i ([batch*outputs] float32): by default downloaded from the device network."""

@@ -119,6 +119,7 @@ struct ConvI8Dev {
     int K16, K16pad;
     float alpha1;
     int Ntotal, OHW, tiles_m;
+    int no_corner;
 };
 
 // y / 10 correctly rounded (the reference's leaky on this path is `y / 10`, quantized.c:625):
@@ -137,7 +138,9 @@ __device__ __forceinline__ float div10_exact(float y)
     return div10_markstein(y);
 }
 
-template <int BM, int BN, int WM, int WN, bool TAPPANEL, bool MFULL, int BK16 = 8>
+// NOC bit 0 / bit 1: the host proved that the leaky / quantise corner cannot occur in this layer (ConvI8Args::no_corner):
+// their per-output tracking (v_min/v_max over |.|, 2 VALU each) and cold paths are compiled out.
+template <int BM, int BN, int WM, int WN, bool TAPPANEL, bool MFULL, int BK16 = 8, int NOC = 0>
 __global__ __launch_bounds__(WM * WN * 64) void conv_i8_mfma_kernel(ConvI8Dev p)
 {
     constexpr int NT = WM * WN * 64;
@@ -427,12 +430,12 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_i8_mfma_kernel(ConvI8Dev p)
                 const float o = truncf(__fmul_rn((float)c, 0.03125f));
                 float v = __fadd_rn(__fmul_rn(o, alpha1), bias_r[e]);
                 if (leaky) {
-                    tmin = fminf(tmin, fabsf(v));
+                    if constexpr (!(NOC & 1)) tmin = fminf(tmin, fabsf(v));
                     v = fmaxf(v, div10_markstein(v));
                 }
                 y[e] = v;
             }
-            if (leaky && __builtin_amdgcn_ballot_w64(tmin < 1e-30f) != 0ull) {      // cold: zeros / near-subnormal outputs
+            if (!(NOC & 1) && leaky && __builtin_amdgcn_ballot_w64(tmin < 1e-30f) != 0ull) {      // cold: zeros / near-subnormal outputs
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int a = acc[i][j][e];
@@ -467,14 +470,14 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_i8_mfma_kernel(ConvI8Dev p)
 #pragma unroll
                     for (int r4 = 0; r4 < 4; ++r4) {
                         const float t = __fmul_rn(y[g4 * 4 + r4], q_mult);
-                        tmax = fmaxf(tmax, fabsf(t));
+                        if constexpr (!(NOC & 2)) tmax = fmaxf(tmax, fabsf(t));
                         const int ci = (int)t;                          // v_cvt_i32_f32: truncation
                         c[r4] = ci < -127 ? -127 : (ci > 127 ? 127 : ci);
                     }
                     pk[g4] = __builtin_amdgcn_perm((unsigned)c[1], (unsigned)c[0], 0x0C0C0400u) |
                              __builtin_amdgcn_perm((unsigned)c[3], (unsigned)c[2], 0x04000C0Cu);
                 }
-                if (__builtin_amdgcn_ballot_w64(!(tmax < 32768.f)) != 0ull) {    // cold: the int16 wrap-around corner / NaN
+                if (!(NOC & 2) && __builtin_amdgcn_ballot_w64(!(tmax < 32768.f)) != 0ull) {    // cold: the int16 wrap-around corner / NaN
 #pragma unroll
                     for (int g4 = 0; g4 < 4; ++g4) {
                         unsigned w = 0;
@@ -514,6 +517,17 @@ static int launch_i8_tile(ConvI8Dev p, hipStream_t s)
     // a panel of BK16 units lies inside one tap when G is a multiple of BK16 (C >= 128)
     const bool tap = p.G >= BK16;
     dim3 grid((unsigned)blocks), block(NT);
+    // the corner-free instances exist for the common case (whole tap panels, M a multiple of the tile) of the two
+    // tiles the heuristic picks
+    constexpr bool NOC_TILE = BK16 == 8 && ((BM == 128 && BN == 128) || (BM == 64 && BN == 128));
+    if constexpr (NOC_TILE) {
+        if (tap && mfull && p.no_corner) {
+            if (p.no_corner == 3) hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, true, true, BK16, 3>), grid, block, 0, s, p);
+            else if (p.no_corner == 1) hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, true, true, BK16, 1>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, true, true, BK16, 2>), grid, block, 0, s, p);
+            return (int)hipGetLastError();
+        }
+    }
     if (tap && mfull) hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, true, true, BK16>), grid, block, 0, s, p);
     else if (tap) hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, true, false, BK16>), grid, block, 0, s, p);
     else if (mfull) hipLaunchKernelGGL((conv_i8_mfma_kernel<BM, BN, WM, WN, false, true, BK16>), grid, block, 0, s, p);
@@ -530,6 +544,9 @@ int launch_conv_i8(const ConvI8Args &a, int tile, void *stream, char *name, size
     d.in_q = a.in_q; d.w_q = a.w_q; d.bias = a.bias; d.out = a.out; d.dbg = a.dbg;
     d.add = a.add; d.out_add = a.out_add;
     d.q_out = a.q_out; d.q_mult = a.q_mult; d.q_G = a.q_G;
+    d.no_corner = a.no_corner & 3;
+    if (a.add) d.no_corner &= ~2;            // the side output quantises conv + [shortcut]: its range is data
+    if (a.dbg) d.no_corner = 0;
     d.B = a.B; d.G = a.Cpad / 16; d.H = a.H; d.W = a.W; d.M = a.M; d.Mpad = a.Mpad; d.OH = a.OH; d.OW = a.OW;
     d.size = a.size; d.stride = a.stride; d.pad = a.pad; d.act = a.act; d.alpha1 = a.alpha1;
     if (d.G <= 0 || (d.G & (d.G - 1)) != 0 || a.size > 5) return (int)hipErrorInvalidValue;

@@ -74,6 +74,10 @@ struct ConvI8Args {
     int size, stride, pad;
     int act;
     float alpha1;         // R_MULT / (in_mult * w_mult)   (quantized.c:596)
+    // host-proved absence of the two data-dependent corners of the exact epilogue (conv_i8_mfma.hip): bit 0 = no
+    // output can fall in 0 < |y| < 1e-30 (alpha1 and every non-zero bias >= 1e-20), bit 1 = no side-output operand
+    // can reach |y * q_mult| >= 32768 (only without a fused [shortcut]: (32767*alpha1 + max|bias|) * q_mult < 32768)
+    int no_corner = 0;
 };
 // tile: 0 = heuristic, 1..5 see conv_i8_mfma.hip (tuning / tests); writes the kernel instance name
 int launch_conv_i8(const ConvI8Args &a, int tile, void *stream, char *name, size_t name_len);

@@ -177,6 +177,13 @@ static int upload_conv(Network &net, Layer &l)
         YL_HIP(hipMemcpy(l.d_weights_i8, wq.data(), wq.size(), hipMemcpyHostToDevice));
         const size_t qb = (size_t)net.batch * l.h * l.w * l.Cpad;
         if (qb > net.qbuf_bytes) net.qbuf_bytes = qb;
+        l.bias_abs_max = 0.f; l.bias_abs_min_nz = 3.0e38f;
+        for (int m = 0; m < M; ++m) {
+            const float b = fabsf(l.biases[m]);
+            if (!(b <= 3.0e38f)) { l.bias_abs_max = -1.f; break; }          // inf / nan: no proof
+            if (b > l.bias_abs_max) l.bias_abs_max = b;
+            if (b != 0.f && b < l.bias_abs_min_nz) l.bias_abs_min_nz = b;
+        }
     } else if (l.conv_mode == CONV_BF16) {
         // the INT8 layout with 8 bf16 channels per 16-byte unit: [K8pad][Mpad][8], K8 index = tap*G + cg
         const int taps = l.size * l.size;
@@ -517,6 +524,16 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
             // float ALPHA1 = R_MULT / (l.input_quant_multipler * l.weights_quant_multipler);  (quantized.c:596)
             a.alpha1 = 32 / (l.input_quant_multipler * l.weights_quant_multipler);
+            // corners of the exact epilogue that cannot occur in this layer (see ConvI8Args::no_corner): a non-zero
+            // output is a sum of two floats of magnitude >= 1e-20 (>= 6e-28, never inside (0, 1e-30)); a side-output
+            // operand is bounded by (32767 * alpha1 + max|bias|) * q_mult
+            a.no_corner = 0;
+            if (l.bias_abs_max >= 0.f && a.alpha1 >= 1e-20f && a.alpha1 <= 1e20f && l.bias_abs_min_nz >= 1e-20f) {
+                a.no_corner |= 1;
+                if (a.q_out && a.q_mult > 0.f && a.q_mult <= 1e20f &&
+                    (32767.0 * (double)a.alpha1 + (double)l.bias_abs_max) * (double)a.q_mult * 1.00001 < 32768.0)
+                    a.no_corner |= 2;
+            }
             YL_LAUNCH(launch_conv_i8(a, net.i8_tile, s, l.kernel_name, sizeof(l.kernel_name)), "conv_i8");
         } else if (l.conv_mode == CONV_BF16) {
             int8_t *h_in = net.d_qbuf + (i % 3) * net.qbuf_bytes;

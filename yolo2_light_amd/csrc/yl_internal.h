@@ -55,6 +55,8 @@ struct Layer {
     float *d_wino32_u = nullptr;         // FP32 3x3/1/1: Winograd-packed U (conv_f32_wino32.hip), else nullptr
     int8_t *d_weights_i8 = nullptr;      // INT8: [K16pad][Mpad][16] int8 units; BF16: [K8pad][Mpad][8] bf16 units
     int   Cpad = 0;                      // channels of the 16-byte-unit activation tensor (INT8: 16 per unit, BF16: 8)
+    float bias_abs_max = 0.f;            // INT8: max |bias| and the smallest non-zero |bias| (-1 = a bias is not finite):
+    float bias_abs_min_nz = 0.f;         //       the host's proof that the exact epilogue's corners cannot occur
     uint64_t *d_weights_bits = nullptr;  // XNOR: [Mpad][taps][Cw] 64-bit words
     float *d_mean = nullptr;
     int   Cw = 0;
