@@ -110,6 +110,11 @@ int yl_network_create_from_desc(const yl_layer_desc *layers, int n_layers,
 /* load_weights_upto_cpu(&net, filename, net.n)        src/additionally.c:3491 */
 int yl_network_load_weights(yl_network *net, const char *weights_path);
 
+/* load_weights_upto_cpu(&net, filename, cutoff) with the reference's tolerance: only layers [0, cutoff) are read and
+ * a file that ends early is NOT an error (the reference never checks fread; backbone-only files load, the rest
+ * keeps its initial values).  yl_network_load_weights above is strict: a short file is YL_ERR_IO. */
+int yl_network_load_weights_upto(yl_network *net, const char *weights_path, int cutoff);
+
 /* yolov2_fuse_conv_batchnorm(net)                     src/additionally.c:67 */
 int yl_network_fuse_conv_batchnorm(yl_network *net);
 

@@ -160,3 +160,34 @@ def test_gpu_quant_rule_selects_the_reference_parsers_l_quantized(name, width, h
     assert 0 < n_gpu <= n_cpu        # the GPU rule is the stricter one (no 1x1, nothing near the [yolo] heads)
     if name.startswith("yolov3"):
         assert n_gpu < n_cpu
+
+
+def test_load_weights_upto_is_tolerant_like_the_reference(tmp_path):
+    """yl_network_load_weights_upto = load_weights_upto_cpu (src/additionally.c:3491): layers below the cutoff are
+    read, a truncated file is not an error and leaves the remaining parameters at their initial values; the strict
+    entry point refuses the same file."""
+    from yolo2_light_amd._lib import lib
+    cfg, wts = common.model_files("yolov3-tiny", 64, 64)
+    full = Network.from_cfg(cfg, 1, 0)
+    full.load_weights(wts)
+    convs = [i for i, li in enumerate(full.layers()) if li["type"] == common.CONV]
+    # keep the header and the first three conv layers' records only
+    data = open(wts, "rb").read()
+    keep = 20                                            # major, minor, revision, 64-bit seen
+    for i in convs[:3]:
+        li = full.layer_info(i)
+        keep += 4 * (li["n"] * (4 if li["batch_normalize"] else 1) + li["n"] * li["c"] * li["size"] ** 2)
+    short = str(tmp_path / "short.weights")
+    open(short, "wb").write(data[:keep + 10])            # ends inside the fourth conv layer's biases
+    strict = Network.from_cfg(cfg, 1, 0)
+    assert lib.yl_network_load_weights(strict._h, short.encode()) == -2          # YL_ERR_IO
+    part = Network.from_cfg(cfg, 1, 0)
+    assert lib.yl_network_load_weights_upto(part._h, short.encode(), part.n) == 0
+    for i in convs[:3]:
+        assert np.array_equal(part.layer_weights(i), full.layer_weights(i)) and np.array_equal(part.layer_biases(i), full.layer_biases(i))
+    assert not np.array_equal(part.layer_weights(convs[4]), full.layer_weights(convs[4]))
+    # cutoff: nothing at or beyond the cutoff layer is touched even with the whole file
+    cut = Network.from_cfg(cfg, 1, 0)
+    assert lib.yl_network_load_weights_upto(cut._h, wts.encode(), convs[2]) == 0
+    assert np.array_equal(cut.layer_weights(convs[1]), full.layer_weights(convs[1]))
+    assert not np.array_equal(cut.layer_weights(convs[2]), full.layer_weights(convs[2]))

@@ -103,6 +103,7 @@ _SIGS = {
     "yl_network_set_winograd": (C.c_int, [_vp, C.c_int]),
     "yl_network_set_variant": (C.c_int, [_vp, C.c_int]),
     "yl_network_set_precision": (C.c_int, [_vp, C.c_int]),
+    "yl_network_load_weights_upto": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "yl_network_prepare_on_device": (C.c_int, [_vp, C.c_int]),
     "yl_network_set_nms_mode": (C.c_int, [_vp, C.c_int]),
     "yl_network_set_quant_rule": (C.c_int, [_vp, C.c_int]),

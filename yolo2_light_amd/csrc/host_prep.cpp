@@ -19,7 +19,10 @@
 
 namespace yl {
 
-int load_weights_file(Network &net, const char *path) {
+// cutoff < 0: strict (every conv layer must be in the file).  cutoff >= 0: load_weights_upto_cpu's contract
+// (src/additionally.c:3491-3526): only layers [0, cutoff) are read and a file that ends early is not an error --
+// the reference never checks fread, the remaining parameters keep their initial values (backbone-only files).
+int load_weights_file(Network &net, const char *path, int cutoff) {
     FILE *fp = fopen(path, "rb");
     if (!fp) { set_error(std::string("cannot open weights file: ") + path); return YL_ERR_IO; }
     int32_t major = 0, minor = 0, revision = 0;
@@ -29,7 +32,7 @@ int load_weights_file(Network &net, const char *path) {
         else { int32_t seen; ok = fread(&seen, 4, 1, fp) == 1; }
     }
     if (!ok) { fclose(fp); set_error("weights file: truncated header"); return YL_ERR_IO; }
-    for (size_t i = 0; i < net.layers.size(); ++i) {
+    for (size_t i = 0; i < net.layers.size() && (cutoff < 0 || (int)i < cutoff); ++i) {
         Layer &l = net.layers[i];
         if (l.type != YL_CONVOLUTIONAL) continue;
         const size_t num = (size_t)l.n * l.c * l.size * l.size;
@@ -40,8 +43,9 @@ int load_weights_file(Network &net, const char *path) {
                    fread(l.rolling_variance.data(), 4, l.n, fp) == (size_t)l.n;
         }
         if (good) good = fread(l.weights.data(), 4, num, fp) == num;
+        if (!good && cutoff >= 0) break;          // the reference's tolerant form was asked for
         if (!good) {
-            // the reference ignores short reads (it never checks fread); we refuse:
+            // the reference ignores short reads (it never checks fread); the strict entry point refuses:
             // a silently half-loaded model can only produce wrong detections.
             fclose(fp);
             char msg[128];

@@ -802,6 +802,12 @@ int yl_network_load_weights(yl_network *net, const char *weights_path)
     return load_weights_file(net->net, weights_path);
 }
 
+int yl_network_load_weights_upto(yl_network *net, const char *weights_path, int cutoff)
+{
+    if (!net || !weights_path || cutoff < 0) { set_error("bad argument"); return YL_ERR_ARG; }
+    return load_weights_file(net->net, weights_path, cutoff);
+}
+
 int yl_network_fuse_conv_batchnorm(yl_network *net)
 {
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }

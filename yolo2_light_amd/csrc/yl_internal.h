@@ -139,7 +139,7 @@ void set_error(const std::string &msg);
 // host_cfg.cpp
 int parse_cfg_file(const char *path, int batch, int quantized, Network &net);
 // host_prep.cpp
-int load_weights_file(Network &net, const char *path);
+int load_weights_file(Network &net, const char *path, int cutoff = -1);
 void fuse_conv_batchnorm(Network &net);
 void calculate_binary_weights(Network &net);
 void quantize_network(Network &net);
