@@ -278,7 +278,7 @@ int yl_network_pull_heads(yl_network *net);
 
 /* Tuning/test hooks, PER NETWORK (two networks driven from two host threads share no launch state).
  * yl_network_set_conv_tile: force the K1 kernel of every FP32 convolution of this network, any time:
- *   0 = built-in heuristic (default), 11..23 = direct implicit-GEMM tile 1..13 (conv_f32_mfma.hip),
+ *   0 = built-in heuristic (default), 11..22 = direct implicit-GEMM tile 1..12 (conv_f32_mfma.hip),
  *   31 = Winograd F(2x2,3x3) (conv_f32_wino32.hip; a launch fails on layers it does not apply to),
  *   41 = LDS-free first-layer kernel (conv_f32_smallk.hip; C*size^2 <= 32 and filters <= 32 only).
  * yl_network_set_winograd: 0 = never pick Winograd heuristically and do not pack its weights, 1 = default;

@@ -507,7 +507,6 @@ static int launch_conv_f32_direct(const ConvF32Args &a, int cfg, int variant, vo
     case 10: t = "128x256w8r";  rc = launch_pipe<128, 256, 4, 2, 16, 8>(d, ks, a.tapmajor != 0, s, vec4); break;
     case 11: t = "256x128w8r";  rc = launch_pipe<256, 128, 8, 1, 16, 8>(d, ks, a.tapmajor != 0, s, vec4); break;
     case 12: t = "128x128r";    rc = launch_pipe<128, 128, 4, 1, 16, 4>(d, ks, a.tapmajor != 0, s, vec4); break;
-    case 13: t = "128x128rk32"; rc = launch_pipe<128, 128, 4, 1, 32, 4>(d, ks, a.tapmajor != 0, s, vec4); break;
     default: return (int)hipErrorInvalidValue;
     }
     if (name) snprintf(name, name_len, "conv_f32_mfma_pipe<%s,ks%d%s%s%s>", t, ks, a.tapmajor ? ",tap" : "", vec4 ? ",v4" : "",
@@ -550,7 +549,6 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
     }
     // BK=32 variants need C % 32 == 0 in tap-major order
     if ((cfg == 5 || cfg == 8) && a.tapmajor) cfg = (cfg == 5) ? 1 : 6;   // tap-major blocks are 16 channels
-    if (cfg == 13 && (a.tapmajor || a.C % 32 != 0)) cfg = 12;
     return launch_conv_f32_direct(a, cfg, o.variant, stream, name, name_len);
 }
 
