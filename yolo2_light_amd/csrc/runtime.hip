@@ -57,6 +57,9 @@ static inline uint16_t f32_to_bf16_rne(float f)
 static void free_device(Network &net)
 {
     if (net.device >= 0) (void)hipSetDevice(net.device);
+    // nothing of this network may still be queued or running when its buffers go away (asynchronous entry points:
+    // yl_network_forward, _detect_batch, _set_input_u8); the stream is non-blocking, so be explicit
+    if (net.stream) (void)hipStreamSynchronize((hipStream_t)net.stream);
     for (Layer &l : net.layers) {
         if (l.d_output && !l.d_output_alias) (void)hipFree(l.d_output);
         l.d_output = nullptr;
