@@ -91,6 +91,10 @@ const char *yl_last_error(void);
  * the reference selects the device with `-i` -> cuda_set_device (src/main.c:653-661) */
 int yl_device_count(void);
 
+/* wait for every stream of `device` (-1 = all visible devices): cudaDeviceSynchronize of the reference's GPU path
+ * (src/yolov2_forward_network_gpu.cu uses it around its timers) */
+int yl_device_synchronize(int device);
+
 /* ------------------------------------------------------------------ *
  *  Host-side model build (L1 of the reference).  When the reference's
  *  own parser is the caller, use yl_network_create_from_desc instead.

@@ -59,6 +59,7 @@ _vp = C.c_void_p
 _SIGS = {
     "yl_last_error": (C.c_char_p, []),
     "yl_device_count": (C.c_int, []),
+    "yl_device_synchronize": (C.c_int, [C.c_int]),
     "yl_network_create_from_cfg": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
     "yl_network_create_from_desc": (C.c_int, [C.POINTER(LayerDesc), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_int, c_float_p, C.c_int, C.POINTER(_vp)]),

@@ -703,6 +703,18 @@ int yl_device_count(void)
     return n;
 }
 
+int yl_device_synchronize(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device visible (libyolo2hip has no CPU fallback)"); return YL_ERR_DEVICE; }
+    for (int d = (device < 0 ? 0 : device); d < (device < 0 ? n : device + 1); ++d) {
+        if (d >= n) { set_error("device index out of range"); return YL_ERR_ARG; }
+        YL_HIP(hipSetDevice(d));
+        YL_HIP(hipDeviceSynchronize());
+    }
+    return YL_OK;
+}
+
 int yl_network_create_from_cfg(const char *cfg_path, int batch, int quantized, yl_network **out)
 {
     if (!cfg_path || !out) { set_error("null argument"); return YL_ERR_ARG; }
