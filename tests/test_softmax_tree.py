@@ -146,3 +146,27 @@ def test_gpu_region_tree_and_hierarchical_decode(olib, batch, nms):
         nonzero += int((host[:, 6:] > 0).sum())
     assert nonzero > 0
     net.close()
+
+
+def test_tree_cfg_errors_are_reported(tmp_path):
+    """a missing tree file, a tree whose size differs from classes=, and map= (the evaluator's class remapping)
+    are refused with an error code instead of computing something else"""
+    from yolo2_light_amd._lib import lib
+    import ctypes as C
+    width = height = 64
+    tree = str(tmp_path / "t.tree")
+    with open(tree, "w") as f:
+        for name, parent in TREE[:10]:                      # 10 nodes for classes=12
+            f.write("%s %d\n" % (name, parent))
+    cases = {
+        "missing": (CFG % (width, height, str(tmp_path / "nope.tree")), -2),          # YL_ERR_IO
+        "size": (CFG % (width, height, tree), -3),                                      # YL_ERR_CFG
+        "map": ((CFG % (width, height, tree)) + "map=%s\n" % tree, -5),                # YL_ERR_UNSUPPORTED
+    }
+    for what, (text, want) in cases.items():
+        cfg = str(tmp_path / (what + ".cfg"))
+        open(cfg, "w").write(text)
+        h = C.c_void_p()
+        rc = lib.yl_network_create_from_cfg(cfg.encode(), 1, 0, C.byref(h))
+        assert rc == want, (what, rc, lib.yl_last_error())
+        assert lib.yl_last_error()
