@@ -7,7 +7,7 @@
 // arithmetic runs on the device with explicitly rounded operations, so the folded weights / biases, mean_arr,
 // weights_int8 and multipliers are BIT-IDENTICAL to the host passes (tests/test_gpu_prep.py).  The results come
 // back to the host model because the kernel-layout packers (k-major panels, Winograd U in double, int8 / bf16
-// units, sign words) run there; yolov3-608: 62 M weights, ~5 ms of kernels instead of ~0.5 s of host loops.
+// units, sign words) run there.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <vector>
