@@ -160,8 +160,11 @@ int yl_network_input_dims(const yl_network *net, int *dims);
  *           classes, coords, total, softmax, reserved, batch_normalize */
 int yl_network_layer_info(const yl_network *net, int i, int *info);
 /* YOLO/REGION layer i: mask[n] (yolo: l.mask; region: 0..n-1) and anchors[2*total] (l.biases);
- * either pointer may be NULL.  Returns n (anchors of this head), < 0 on error. */
-int yl_network_layer_head(const yl_network *net, int i, int *mask, float *anchors);
+ * either pointer may be NULL; mask_cap / anchors_cap = elements the caller's arrays hold, never more is written
+ * (YL_ERR_ARG when a non-NULL array is too small).  Returns n (anchors of this head), < 0 on error;
+ * anchors_len_out (may be NULL) receives the number of anchor floats the layer has. */
+int yl_network_layer_head(const yl_network *net, int i, int *mask, int mask_cap, float *anchors, int anchors_cap,
+                          int *anchors_len_out);
 /* softmax tree of REGION layer i (l.softmax_tree, src/additionally.h:352-364): returns the number of groups
  * (0 = the layer has no tree, <0 on error); parent[classes] / group_size[groups] are copied when non-NULL */
 int yl_network_layer_tree(const yl_network *net, int i, int *parent, int *group_size);
@@ -293,7 +296,8 @@ int yl_network_set_conv_tile(yl_network *net, int cfg);
 /* schedule variants of the FP32 kernels kept switchable for same-box A/B measurements (results are identical):
  * bit 0 Winograd U panels by LDS-DMA, bit 1 Winograd epilogue prefetches the fused [shortcut] operand,
  * bit 2 float4 B-panel rows in the 1x1 direct kernel, bit 3 LDS-free first-layer kernel, bit 4 Winograd from 32
- * input channels up; -1 = built-in default */
+ * input channels up, bit 5 (takes effect at the next yl_network_to_device: it selects the weight packing) the Winograd
+ * kernel with all 16 planes of a block in one wave and the output transform in registers; -1 = built-in default */
 int yl_network_set_variant(yl_network *net, int bits);
 /* Opt-in BF16 variant of the FP32 path (north_star (a) "FP32/BF16"; BEFORE yl_network_to_device): every FP32
  * convolution whose input has whole 8-channel groups runs on v_mfma_f32_32x32x16_bf16 with both operands rounded
@@ -309,8 +313,9 @@ int yl_network_set_int8_tile(yl_network *net, int cfg);
 int yl_network_set_winograd(yl_network *net, int on);
 int yl_network_set_nms_mode(yl_network *net, int mode);
 /* Test hook (host only, no GPU needed): the Winograd weight transform U = G g G^T of a 3x3 layer
- * (weights[m][c][3][3]) packed the way the kernel reads it: tiling must be 32,
- * [m/32][c/4][xi 16][half 2][m 32][kk 2] with channel = panel*4 + 2*kk + half.
+ * (weights[m][c][3][3]) packed the way the kernel reads it.  tiling 32 (conv_f32_wino32.hip):
+ * [m/32][c/4][xi 16][half 2][m 32][kk 2] with channel = panel*4 + 2*kk + half; tiling 16 (conv_f32_wino16.hip):
+ * [m/32][c/4][xi/2][k 4][m%16][(m%32)/16][xi&1] with channel = panel*4 + k.
  * dst == NULL returns the number of floats needed. */
 long long yl_debug_wino_pack(const float *weights, int c, int m, int tiling, float *dst, long long dst_floats);
 

@@ -91,3 +91,60 @@ void oracle_conv_int8_fast(const float *in, const int8_t *weights_int8, const fl
     }
     free(xq);
 }
+
+/*
+ * FLOAT64 GROUND TRUTH of the FP32 convolution (forward_convolutional_layer_cpu, FP32 branch,
+ * src/yolov2_forward_network.c:204-261): the same function of the same float weights / biases, with the layer
+ * input, every product, the whole sum, the bias add and the activation carried in double.  Products of two
+ * floats are exact in double and a double sum over K <= 9216 terms is good to ~1e-13 relative, so the summation
+ * order is immaterial here (tap-outermost, filters on OpenMP threads).  Used by tests/ and tools/parity_layers.py
+ * to measure how far the reference's own builds (scalar gemm_nn, AVX gemm_nn) and the HIP kernels each sit from
+ * the exact result -- the yardstick VERDICT round 2 (next-round item 2) asks for.  Leaky = .1*x in double
+ * (src/additionally.h:91), logistic = 1./(1.+exp(-x)) (:84).
+ */
+#include <math.h>
+
+void oracle_conv_f64(const double *in, const float *weights, const float *biases, double *out,
+                     int batch, int c, int h, int w, int n, int size, int stride, int pad, int act)
+{
+    const int out_h = (h + 2 * pad - size) / stride + 1;
+    const int out_w = (w + 2 * pad - size) / stride + 1;
+    const int K = c * size * size;
+    const size_t inputs = (size_t)c * h * w;
+    const size_t ohw = (size_t)out_h * out_w;
+    for (int b = 0; b < batch; ++b) {
+        const double *im = in + (size_t)b * inputs;
+        double *o = out + (size_t)b * n * ohw;
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int f = 0; f < n; ++f) {
+            double *acc = o + (size_t)f * ohw;
+            memset(acc, 0, ohw * sizeof(double));
+            for (int ci = 0; ci < c; ++ci)
+                for (int ky = 0; ky < size; ++ky)
+                    for (int kx = 0; kx < size; ++kx) {
+                        const double wv = weights[(size_t)f * K + ((size_t)ci * size + ky) * size + kx];
+                        int lo = 0;
+                        while (lo < out_w && lo * stride - pad + kx < 0) ++lo;
+                        int hi = out_w;
+                        while (hi > lo && (hi - 1) * stride - pad + kx >= w) --hi;
+                        for (int oy = 0; oy < out_h; ++oy) {
+                            const int iy = oy * stride - pad + ky;
+                            if (iy < 0 || iy >= h) continue;
+                            const double *row = im + ((size_t)ci * h + iy) * w - pad + kx;
+                            double *a = acc + (size_t)oy * out_w;
+                            if (stride == 1) {
+                                for (int ox = lo; ox < hi; ++ox) a[ox] += wv * row[ox];
+                            } else {
+                                for (int ox = lo; ox < hi; ++ox) a[ox] += wv * row[ox * stride];
+                            }
+                        }
+                    }
+            for (size_t p = 0; p < ohw; ++p) {
+                double y = acc[p] + (double)biases[f];
+                if (act == ACT_LEAKY) y = (y > 0) ? y : .1 * y;
+                else if (act == 0 /* LOGISTIC */) y = 1. / (1. + exp(-y));
+                acc[p] = y;
+            }
+        }
+    }
+}

@@ -95,6 +95,9 @@ def oracle_fast_lib() -> C.CDLL:
     lib = C.CDLL(ORACLE_FAST_SO)
     lib.oracle_conv_int8_fast.argtypes = [_fp, _i8p, _fp, _fp, _i32p] + [C.c_int] * 9 + [C.c_float, C.c_float]
     lib.oracle_conv_int8_fast.restype = None
+    _dp = C.POINTER(C.c_double)
+    lib.oracle_conv_f64.argtypes = [_dp, _fp, _fp, _dp] + [C.c_int] * 9
+    lib.oracle_conv_f64.restype = None
     return lib
 
 
@@ -255,6 +258,82 @@ class OracleNet:
             cur = out
             if stop_after is not None and i >= stop_after:
                 break
+
+
+class TruthNet:
+    """FLOAT64 ground truth of an FP32 network (yolov3 / yolov3-tiny layer types): the same float weights and
+    biases, every tensor and every operation in double (oracle_conv_f64 + numpy).  `outputs[i]` are float64.
+    Not a reference path -- the yardstick against which the reference's scalar build, its AVX build and the HIP
+    kernels are each measured (tests/test_gpu_parity.py::test_fp32_error_vs_float64_truth)."""
+
+    def __init__(self, net: Network, cfg_text: str):
+        self.net = net
+        self.f = oracle_fast_lib()
+        self.infos = net.layers()
+        self.outputs = [None] * net.n
+        self.route_inputs = {}
+        secs = zoo.parse_sections(cfg_text)[1:]
+        for i, (typ, o) in enumerate(secs):
+            if typ == "route":
+                ids = [int(x) for x in o["layers"].split(",")]
+                self.route_inputs[i] = [j + i if j < 0 else j for j in ids]
+
+    @staticmethod
+    def _maxpool(x, size, stride, pad):
+        B, Cc, H, W = x.shape
+        oh, ow = (H + pad - size) // stride + 1, (W + pad - size) // stride + 1
+        off = pad // 2                                    # window origin -pad/2 (src/additionally.c:1452)
+        xp = np.full((B, Cc, off + (oh - 1) * stride + size + H, off + (ow - 1) * stride + size + W), -np.inf)
+        xp[:, :, off:off + H, off:off + W] = x
+        out = np.full((B, Cc, oh, ow), -np.inf)
+        for ky in range(size):
+            for kx in range(size):
+                out = np.maximum(out, xp[:, :, ky:ky + (oh - 1) * stride + 1:stride, kx:kx + (ow - 1) * stride + 1:stride])
+        return out
+
+    def forward(self, x: np.ndarray) -> None:
+        net, B = self.net, self.net.batch
+        dp = C.POINTER(C.c_double)
+        cur = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        for i, li in enumerate(self.infos):
+            t = li["type"]
+            if t == CONV:
+                assert li["conv_mode"] == CONV_F32 and not li["xnor"]
+                out = np.zeros(B * li["outputs"], dtype=np.float64)
+                wts, bias = net.layer_weights(i), net.layer_biases(i)
+                self.f.oracle_conv_f64(cur.ctypes.data_as(dp), fp(wts), fp(bias), out.ctypes.data_as(dp), B, li["c"],
+                                       li["h"], li["w"], li["n"], li["size"], li["stride"], li["pad"], li["activation"])
+            elif t == MAXPOOL:
+                out = self._maxpool(cur.reshape(B, li["c"], li["h"], li["w"]), li["size"], li["stride"], li["pad"])
+                out = np.ascontiguousarray(out).reshape(-1)
+            elif t == ROUTE:
+                parts = [self.outputs[j].reshape(B, -1) for j in self.route_inputs[i]]
+                out = np.ascontiguousarray(np.concatenate(parts, axis=1)).reshape(-1)
+            elif t == SHORTCUT:
+                add = self.outputs[li["index"]]
+                assert add.size == cur.size and li["activation"] == 3      # same-shape, linear (every shipped cfg)
+                out = cur + add
+            elif t == UPSAMPLE:
+                v = cur.reshape(B, li["c"], li["h"], li["w"])
+                out = np.ascontiguousarray(v.repeat(li["stride"], axis=2).repeat(li["stride"], axis=3)).reshape(-1)
+            elif t == YOLO:
+                v = cur.reshape(B, li["n"], li["classes"] + 5, li["w"] * li["h"]).copy()
+                sel = [0, 1] + list(range(4, li["classes"] + 5))
+                v[:, :, sel] = 1.0 / (1.0 + np.exp(-v[:, :, sel]))
+                out = v.reshape(-1)
+            else:
+                raise NotImplementedError("TruthNet: layer type %d" % t)
+            self.outputs[i] = out
+            cur = out
+
+
+def error_vs_truth(got: np.ndarray, truth: np.ndarray):
+    """(relative RMS error, max |error| / RMS(truth)) of a float32 tensor against the float64 truth"""
+    g = np.asarray(got, dtype=np.float64).reshape(-1)
+    t = np.asarray(truth, dtype=np.float64).reshape(-1)
+    rms = max(float(np.sqrt(np.mean(t * t))), 1e-300)
+    e = g - t
+    return float(np.sqrt(np.mean(e * e))) / rms, float(np.max(np.abs(e))) / rms
 
 
 # ---------------------------------------------------------------------------

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyolo2hip.so")
+# YOLO2HIP_LIB: another build of the SAME library (A/B runs of tools/); never a fallback
+LIB_PATH = os.environ.get("YOLO2HIP_LIB") or os.path.join(_HERE, "libyolo2hip.so")
 
 
 class YoloHipError(RuntimeError):
@@ -108,7 +109,7 @@ _SIGS = {
     "yl_network_prepare_on_device": (C.c_int, [_vp, C.c_int]),
     "yl_network_set_nms_mode": (C.c_int, [_vp, C.c_int]),
     "yl_network_set_quant_rule": (C.c_int, [_vp, C.c_int]),
-    "yl_network_layer_head": (C.c_int, [_vp, C.c_int, c_int_p, c_float_p]),
+    "yl_network_layer_head": (C.c_int, [_vp, C.c_int, c_int_p, C.c_int, c_float_p, C.c_int, c_int_p]),
     "yl_network_layer_tree": (C.c_int, [_vp, C.c_int, c_int_p, c_int_p]),
     "yl_debug_wino_pack": (C.c_longlong, [c_float_p, C.c_int, C.c_int, C.c_int, c_float_p, C.c_longlong]),
     "yl_network_compact_detections": (C.c_int, [_vp, C.c_float, C.c_int, _vp, _vp]),

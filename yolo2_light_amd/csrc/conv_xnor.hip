@@ -319,7 +319,8 @@ __global__ __launch_bounds__(256) void conv_xnor_kernel(ConvXnorDev p)
     if (p.out_bits) {
         uint64_t *dst = p.out_bits + ((size_t)bimg * p.out_Cw + (f0 >> 6)) * p.HW + pix;
         if (FT == 64) *dst = ((uint64_t)sign_hi << 32) | sign_lo;
-        else reinterpret_cast<unsigned *>(dst)[(f0 >> 5) & 1] = sign_lo;      // 32 filters per lane: half a word
+        else if (p.M <= 32) *dst = (uint64_t)sign_lo;       // the word's only writer: upper half 0, not what an earlier layer left in the ring slot
+        else reinterpret_cast<unsigned *>(dst)[(f0 >> 5) & 1] = sign_lo;      // 32 < M < 64: two filter tiles, half a word each
     }
 }
 

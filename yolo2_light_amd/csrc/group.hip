@@ -137,8 +137,9 @@ struct yl_group {
     std::vector<int> first, count;                   // image range of each rank
     std::vector<yl_network *> members;
     std::vector<yl::Worker *> workers;
-    std::vector<std::vector<float>> host_out;        // group-owned host tensors (heads / last layer) when the model has none
+    std::vector<float *> host_own;                   // group-owned PINNED host tensors (heads / last layer) when the model has none
     std::vector<float *> host_out_ptr;               // per layer: base of the [global_batch][outputs] host tensor (or nullptr)
+    std::vector<int> host_kind;                      // per layer: HOST_PINNED (group-owned) or HOST_CALLER (the model's l.output)
     std::vector<ncclComm_t> comms;                   // RCCL, created at the first gather
     std::vector<float *> d_rec;                      // per rank: local detection records / counts staging
     std::vector<int *> d_cnt;
@@ -210,14 +211,28 @@ int yl_group_create(const yl_network *model, const int *devices, int n_devices, 
     // host tensors of the heads / last layer for the GLOBAL batch: the model's (the reference's l.output, given
     // through yl_layer_desc.output) or group-owned ones; every replica pulls its slice straight into them
     const size_t nl = m.layers.size();
-    g->host_out.resize(nl);
+    // Group-owned tensors are pinned (portable: every device DMAs its slice straight into them); caller memory is
+    // never handed to the runtime -- each replica bounces its slice through its own pinned block (staging.hip).
+    g->host_own.assign(nl, nullptr);
     g->host_out_ptr.assign(nl, nullptr);
+    g->host_kind.assign(nl, HOST_NONE);
     for (size_t i = 0; i < nl; ++i) {
         const Layer &l = m.layers[i];
         const bool is_head = (l.type == YL_YOLO || l.type == YL_REGION);
         if (!(is_head || i + 1 == nl)) continue;
-        if (l.host_output) g->host_out_ptr[i] = l.host_output;
-        else { g->host_out[i].assign((size_t)m.batch * l.outputs, 0.f); g->host_out_ptr[i] = g->host_out[i].data(); }
+        if (l.host_output && l.host_kind == HOST_CALLER) { g->host_out_ptr[i] = l.host_output; g->host_kind[i] = HOST_CALLER; }
+        else {
+            const size_t bytes = sizeof(float) * (size_t)m.batch * l.outputs;
+            if (hipSetDevice(devices[0]) != hipSuccess ||
+                hipHostMalloc((void **)&g->host_own[i], bytes, hipHostMallocPortable) != hipSuccess) {
+                set_error("hipHostMalloc of the group's host tensors failed");
+                yl_group_destroy(g);
+                return YL_ERR_DEVICE;
+            }
+            memset(g->host_own[i], 0, bytes);
+            g->host_out_ptr[i] = g->host_own[i];
+            g->host_kind[i] = HOST_PINNED;
+        }
     }
     for (int r = 0; r < n_devices; ++r) {
         yl_network *rep = new yl_network();
@@ -228,9 +243,9 @@ int yl_group_create(const yl_network *model, const int *devices, int n_devices, 
         for (size_t i = 0; i < nl; ++i) {
             Layer &l = rn.layers[i];
             l.batch = rn.batch;
-            l.host_output_own.clear();
-            l.host_registered = false;
+            l.host_in_heads = false;
             l.host_output = g->host_out_ptr[i] ? g->host_out_ptr[i] + (size_t)g->first[r] * l.outputs : nullptr;
+            l.host_kind = g->host_out_ptr[i] ? g->host_kind[i] : HOST_NONE;
         }
         g->members.push_back(rep);
         g->workers.push_back(new Worker());
@@ -247,6 +262,11 @@ int yl_group_create(const yl_network *model, const int *devices, int n_devices, 
 void yl_group_destroy(yl_group *g)
 {
     if (!g) return;
+    // yl_group_detect_batch is asynchronous: sends / receives may still be queued on the members' streams
+    for (int r = 0; r < (int)g->members.size(); ++r) {
+        const Network &rn = g->members[r]->net;
+        if (rn.on_device && rn.stream && hipSetDevice(g->devices[r]) == hipSuccess) (void)hipStreamSynchronize((hipStream_t)rn.stream);
+    }
     if (!g->comms.empty()) {
         Rccl &R = rccl();
         for (ncclComm_t c : g->comms) if (c && R.handle) (void)R.CommDestroy(c);
@@ -262,6 +282,7 @@ void yl_group_destroy(yl_group *g)
         yl_network_destroy(g->members[r]);
     }
     for (Worker *w : g->workers) delete w;
+    for (float *p : g->host_own) if (p) (void)hipHostFree(p);
     delete g;
 }
 
@@ -389,17 +410,14 @@ int yl_group_get_boxes_batch(yl_group *g, const int *img_w, const int *img_h, fl
     if (rc != YL_OK) return rc;
     if (hipSetDevice(g->devices[0]) != hipSuccess) { set_error("hipSetDevice failed"); return YL_ERR_DEVICE; }
     hipStream_t s0 = (hipStream_t)g->members[0]->net.stream;
-    if (hipMemcpyAsync(counts_host, g->d_cnt_root, sizeof(int) * (size_t)g->global_batch, hipMemcpyDeviceToHost, s0) != hipSuccess ||
-        hipStreamSynchronize(s0) != hipSuccess) { set_error("D2H of the counts failed"); return YL_ERR_DEVICE; }
-    for (int b = 0; b < g->global_batch; ++b) {
-        const int c = counts_host[b] < cap ? counts_host[b] : cap;
-        if (c > 0 && hipMemcpyAsync(rows_host + (size_t)b * cap * row, g->d_rec_root + (size_t)b * cap * row,
-                                    sizeof(float) * row * c, hipMemcpyDeviceToHost, s0) != hipSuccess) {
-            set_error("D2H of the rows failed"); return YL_ERR_DEVICE;
-        }
-    }
     if (hipStreamSynchronize(s0) != hipSuccess) { set_error("stream synchronize failed"); return YL_ERR_DEVICE; }
-    return YL_OK;
+    // caller memory: through the pinned staging chunks (staging.hip), only the filled rows travel
+    int rc2 = stage_d2h(g->devices[0], counts_host, g->d_cnt_root, sizeof(int) * (size_t)g->global_batch);
+    for (int b = 0; b < g->global_batch && rc2 == YL_OK; ++b) {
+        const int c = counts_host[b] < cap ? counts_host[b] : cap;
+        if (c > 0) rc2 = stage_d2h(g->devices[0], rows_host + (size_t)b * cap * row, g->d_rec_root + (size_t)b * cap * row, sizeof(float) * row * c);
+    }
+    return rc2;
 }
 
 }  // extern "C"

@@ -6,7 +6,7 @@
 
 namespace yl {
 
-constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8 | 16;      // measured on MI355X, profiles/r2_ab_fp32_variants.txt: bit 1 +3.3 %, bit 2 +0.4 %, bit 3 +0.6 %, bit 4 +0.9 %, bit 0 -0.5 %
+constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8 | 16 | 32;      // measured on MI355X, profiles/r2_ab_fp32_variants.txt: bit 1 +3.3 %, bit 2 +0.4 %, bit 3 +0.6 %, bit 4 +0.9 %, bit 0 -0.5 %
 
 // ---- K1: FP32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 ----
 struct ConvF32Args {
@@ -26,7 +26,8 @@ struct ConvF32Args {
     int size, stride, pad;
     int act;              // YL_LINEAR / YL_LEAKY
     int tapmajor;         // K order of `wt`: 0 = (c,ky,kx) like im2col_cpu, 1 = (ky,kx,c) (needs C % 16 == 0)
-    const float *wino32_u; // Winograd-packed weights (wino32_pack_weights) or nullptr: 3x3/1/1 layers only
+    const float *wino32_u; // Winograd-packed weights (wino16_/wino32_pack_weights) or nullptr: 3x3/1/1 layers only
+    int wino_tiling = 32;  // which packing wino32_u holds: 16 = all-planes-per-wave kernel (conv_f32_wino16.hip), 32 = round-2 kernel
 };
 // per-network kernel-selection knobs (snapshotted in Network: two networks driven from two host
 // threads, one per GPU, share no mutable launch state)
@@ -36,8 +37,10 @@ struct ConvF32Opts {
     // schedule variants kept switchable for same-box A/B runs (yl_network_set_variant): bit 0 Winograd U panels by
     // LDS-DMA, bit 1 Winograd epilogue requests the [shortcut] operand ahead of its LDS exchange, bit 2 1x1 direct
     // kernel loads the B panel as float4 rows, bit 3 LDS-free small-K kernel for the first layer (C*size^2 <= 32),
-    // bit 4 Winograd from 32 input channels up (default: from 64).  (An 8-byte-access epilogue for odd map widths was
-    // measured and dropped: no gain, profiles/r2_ab_fp32_variants.txt.)
+    // bit 4 Winograd from 32 input channels up (default: from 64), bit 5 (read when the weights are uploaded) the
+    // Winograd kernel that keeps all 16 planes of a block in one wave (conv_f32_wino16.hip) instead of round 2's
+    // plane-split kernel.  (An 8-byte-access epilogue for odd map widths was measured and dropped: no gain,
+    // profiles/r2_ab_fp32_variants.txt.)
     int variant = YL_VARIANT_DEFAULT;
 };
 // writes the name of the kernel instance it launched into name[name_len]
@@ -52,6 +55,11 @@ void wino32_pack_weights(const float *w, int C, int M, float *dst);
 bool smallk_applicable(const ConvF32Args &a);
 int launch_conv_f32_smallk(const ConvF32Args &a, void *stream, char *name, size_t name_len);
 int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, int variant, void *stream, char *name, size_t name_len);
+// K1w, round 3 (conv_f32_wino16.hip): the same tile on v_mfma_f32_16x16x4_f32, a wave holds all 16 planes of its
+// 32-filter x 16-tile block, output transform in registers; its own U packing
+size_t wino16_packed_floats(int C, int M);
+void wino16_pack_weights(const float *w, int C, int M, float *dst);
+int launch_conv_f32_wino16(const ConvF32Args &a, const float *u_packed, int variant, void *stream, char *name, size_t name_len);
 
 // ---- K2: INT8 path ----
 // K2a: x_q = clamp_abs((int16)(x*mult), 127), FP32 NCHW -> int8 NHWC(Cpad)   (quantized.c:554-560)

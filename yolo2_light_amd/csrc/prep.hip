@@ -78,6 +78,10 @@ __global__ __launch_bounds__(256) void quantize_weights_kernel(const float *__re
 inline unsigned blocks_for(size_t total) { size_t g = (total + 255) / 256; if (g > 4096) g = 4096; return (unsigned)(g ? g : 1); }
 
 #define PREP_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string("prepare_on_device: ") + hipGetErrorString(e_)); rc = YL_ERR_DEVICE; goto done; } } while (0)
+// staging.hip sets the error text; its D2H wants the producer finished (these kernels run on the null stream,
+// the staging stream is non-blocking, so nothing orders them implicitly)
+#define PREP_RC(x) do { int rc_ = (x); if (rc_ != YL_OK) { rc = rc_; goto done; } } while (0)
+#define PREP_D2H(dst, src, bytes) do { PREP_HIP(hipStreamSynchronize(0)); PREP_RC(stage_d2h(device, dst, src, bytes)); } while (0)
 
 }  // namespace
 
@@ -111,23 +115,23 @@ int prepare_on_device(Network &net, int device)
         if (!d_cnt) PREP_HIP(hipMalloc((void **)&d_cnt, 32 * sizeof(int)));
         float *d_bias = d_small, *d_scales = d_small + cap_n, *d_mean = d_small + 2 * cap_n, *d_var = d_small + 3 * cap_n,
               *d_marr = d_small + 4 * cap_n;
-        PREP_HIP(hipMemcpy(d_w, l.weights.data(), total * sizeof(float), hipMemcpyHostToDevice));
+        PREP_RC(stage_h2d(device, d_w, l.weights.data(), total * sizeof(float)));
         if (l.batch_normalize) {
-            PREP_HIP(hipMemcpy(d_bias, l.biases.data(), l.n * sizeof(float), hipMemcpyHostToDevice));
-            PREP_HIP(hipMemcpy(d_scales, l.scales.data(), l.n * sizeof(float), hipMemcpyHostToDevice));
-            PREP_HIP(hipMemcpy(d_mean, l.rolling_mean.data(), l.n * sizeof(float), hipMemcpyHostToDevice));
-            PREP_HIP(hipMemcpy(d_var, l.rolling_variance.data(), l.n * sizeof(float), hipMemcpyHostToDevice));
+            PREP_RC(stage_h2d(device, d_bias, l.biases.data(), l.n * sizeof(float)));
+            PREP_RC(stage_h2d(device, d_scales, l.scales.data(), l.n * sizeof(float)));
+            PREP_RC(stage_h2d(device, d_mean, l.rolling_mean.data(), l.n * sizeof(float)));
+            PREP_RC(stage_h2d(device, d_var, l.rolling_variance.data(), l.n * sizeof(float)));
             hipLaunchKernelGGL(fold_bn_kernel, dim3(blocks_for(total)), dim3(256), 0, 0, d_w, d_bias, d_scales, d_mean, d_var, l.n, k);
             PREP_HIP(hipGetLastError());
-            PREP_HIP(hipMemcpy(l.weights.data(), d_w, total * sizeof(float), hipMemcpyDeviceToHost));
-            PREP_HIP(hipMemcpy(l.biases.data(), d_bias, l.n * sizeof(float), hipMemcpyDeviceToHost));
+            PREP_D2H(l.weights.data(), d_w, total * sizeof(float));
+            PREP_D2H(l.biases.data(), d_bias, l.n * sizeof(float));
             l.batch_normalize = 0;
         }
         if (l.xnor) {
             hipLaunchKernelGGL(xnor_mean_kernel, dim3((l.n + 63) / 64), dim3(64), 0, 0, d_w, d_marr, l.n, (int)k);
             PREP_HIP(hipGetLastError());
             l.mean_arr.assign(l.n, 0.f);
-            PREP_HIP(hipMemcpy(l.mean_arr.data(), d_marr, l.n * sizeof(float), hipMemcpyDeviceToHost));
+            PREP_D2H(l.mean_arr.data(), d_marr, l.n * sizeof(float));
             l.xnor_ready = true;
         }
         if (net.quantized) {
@@ -135,12 +139,12 @@ int prepare_on_device(Network &net, int device)
             PREP_HIP(hipMemset(d_cnt, 0, 32 * sizeof(int)));
             hipLaunchKernelGGL(range_hist_kernel, dim3(blocks_for(total)), dim3(256), 0, 0, d_w, total, d_cnt);
             PREP_HIP(hipGetLastError());
-            PREP_HIP(hipMemcpy(h_cnt, d_cnt, sizeof(h_cnt), hipMemcpyDeviceToHost));
+            PREP_D2H(h_cnt, d_cnt, sizeof(h_cnt));
             l.weights_quant_multipler = multiplier_from_range_counts(h_cnt, 8) / 4;
             hipLaunchKernelGGL(quantize_weights_kernel, dim3(blocks_for(total)), dim3(256), 0, 0, d_w, d_q, total, l.weights_quant_multipler);
             PREP_HIP(hipGetLastError());
             l.weights_int8.assign(total, 0);
-            PREP_HIP(hipMemcpy(l.weights_int8.data(), d_q, total, hipMemcpyDeviceToHost));
+            PREP_D2H(l.weights_int8.data(), d_q, total);
             // the calibration index counts EVERY conv layer
             l.input_quant_multipler = (counter < (int)net.input_calibration.size()) ? net.input_calibration[counter] : 40.f;
             l.quant_ready = true;

@@ -34,6 +34,13 @@ void set_error(const std::string &msg) { g_err = msg; }
         }                                                                               \
     } while (0)
 
+// stage_h2d / stage_d2h set the error text themselves
+#define YL_STAGE(call)                                                                  \
+    do {                                                                                \
+        int rc_ = (call);                                                               \
+        if (rc_ != YL_OK) return rc_;                                                   \
+    } while (0)
+
 #define YL_LAUNCH(call, what)                                                           \
     do {                                                                                \
         int e_ = (call);                                                                \
@@ -63,8 +70,7 @@ static void free_device(Network &net)
     for (Layer &l : net.layers) {
         if (l.d_output && !l.d_output_alias) (void)hipFree(l.d_output);
         l.d_output = nullptr;
-        if (l.host_registered && l.host_output) (void)hipHostUnregister(l.host_output);
-        l.host_registered = false;
+        if (l.host_in_heads) { l.host_output = nullptr; l.host_kind = HOST_NONE; l.host_in_heads = false; }
         if (l.d_weights_t) (void)hipFree(l.d_weights_t);
         if (l.d_wino32_u) (void)hipFree(l.d_wino32_u);
         l.d_wino32_u = nullptr;
@@ -84,6 +90,12 @@ static void free_device(Network &net)
     if (net.d_binbuf) (void)hipFree(net.d_binbuf);
     net.d_binbuf = nullptr;
     if (net.h_pinned) (void)hipHostFree(net.h_pinned);
+#ifdef YL_REPRO_REGISTER
+    if (net.h_heads) { (void)hipHostUnregister(net.h_heads); free(net.h_heads); }
+#else
+    if (net.h_heads) (void)hipHostFree(net.h_heads);
+#endif
+    net.h_heads = nullptr; net.h_heads_floats = 0;
     if (net.h_u8) (void)hipHostFree(net.h_u8);
     if (net.d_u8) (void)hipFree(net.d_u8);
     for (void *e : net.u8_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
@@ -91,6 +103,8 @@ static void free_device(Network &net)
     net.h_u8 = nullptr; net.d_u8 = nullptr; net.u8_stride = 0;
     if (net.h_det_rows) (void)hipHostFree(net.h_det_rows);
     net.h_det_rows = nullptr; net.h_det_bytes = 0; net.det_cache_valid = false;
+    if (net.h_det_counts) (void)hipHostFree(net.h_det_counts);
+    net.h_det_counts = nullptr;
     if (net.d_det_scratch) (void)hipFree(net.d_det_scratch);
     if (net.d_det_out) (void)hipFree(net.d_det_out);
     if (net.d_det_counts) (void)hipFree(net.d_det_counts);
@@ -115,7 +129,7 @@ static int upload_conv(Network &net, Layer &l)
     const int K = l.size * l.size * l.c;
     const int M = l.n;
     YL_HIP(hipMalloc((void **)&l.d_biases, sizeof(float) * M));
-    YL_HIP(hipMemcpy(l.d_biases, l.biases.data(), sizeof(float) * M, hipMemcpyHostToDevice));
+    YL_STAGE(stage_h2d(net.device, l.d_biases, l.biases.data(), sizeof(float) * M));
     if (l.conv_mode == CONV_F32) {
         // xnor conv outside the 3x3/stride-1/pad-1 bit path: the reference falls back to the FP32
         // GEMM on binarised operands (src/yolov2_forward_network.c:40-50,204-211): weights +-mean
@@ -146,16 +160,18 @@ static int upload_conv(Network &net, Layer &l)
                     wt[(size_t)k_dev * l.Mpad + m] = wv;
                 }
         YL_HIP(hipMalloc((void **)&l.d_weights_t, wt.size() * sizeof(float)));
-        YL_HIP(hipMemcpy(l.d_weights_t, wt.data(), wt.size() * sizeof(float), hipMemcpyHostToDevice));
+        YL_STAGE(stage_h2d(net.device, l.d_weights_t, wt.data(), wt.size() * sizeof(float)));
         // 3x3 / stride 1 / pad 1: also the Winograd F(2x2,3x3) form of the same weights (K1w).
         // Not for the xnor fallback: its +-mean weights would pick up G's halves and the layer is
         // specified by the reference as an exact +-1 GEMM.
         if (net.conv_opts.winograd && !xnor_fallback && wino_applicable(l.c, M, l.size, l.stride, l.pad) &&
             l.out_h == l.h && l.out_w == l.w && l.h >= 4 && l.w >= 4) {
-            std::vector<float> u32(wino32_packed_floats(l.c, M));
-            wino32_pack_weights(l.weights.data(), l.c, M, u32.data());
+            l.wino_tiling = (net.conv_opts.variant & 32) ? 16 : 32;
+            std::vector<float> u32(l.wino_tiling == 16 ? wino16_packed_floats(l.c, M) : wino32_packed_floats(l.c, M));
+            if (l.wino_tiling == 16) wino16_pack_weights(l.weights.data(), l.c, M, u32.data());
+            else wino32_pack_weights(l.weights.data(), l.c, M, u32.data());
             YL_HIP(hipMalloc((void **)&l.d_wino32_u, u32.size() * sizeof(float)));
-            YL_HIP(hipMemcpy(l.d_wino32_u, u32.data(), u32.size() * sizeof(float), hipMemcpyHostToDevice));
+            YL_STAGE(stage_h2d(net.device, l.d_wino32_u, u32.data(), u32.size() * sizeof(float)));
         }
     } else if (l.conv_mode == CONV_INT8) {
         if (!l.quant_ready) { set_error("INT8 layer without yl_network_quantize()"); return YL_ERR_STATE; }
@@ -177,7 +193,7 @@ static int upload_conv(Network &net, Layer &l)
                     wq[((size_t)g * l.Mpad + m) * 16 + (c % 16)] = l.weights_int8[((size_t)m * l.c + c) * taps + t];
                 }
         YL_HIP(hipMalloc((void **)&l.d_weights_i8, wq.size()));
-        YL_HIP(hipMemcpy(l.d_weights_i8, wq.data(), wq.size(), hipMemcpyHostToDevice));
+        YL_STAGE(stage_h2d(net.device, l.d_weights_i8, wq.data(), wq.size()));
         const size_t qb = (size_t)net.batch * l.h * l.w * l.Cpad;
         if (qb > net.qbuf_bytes) net.qbuf_bytes = qb;
         l.bias_abs_max = 0.f; l.bias_abs_min_nz = 3.0e38f;
@@ -204,7 +220,7 @@ static int upload_conv(Network &net, Layer &l)
                     wh[((size_t)g * l.Mpad + m) * 8 + (c % 8)] = f32_to_bf16_rne(l.weights[((size_t)m * l.c + c) * taps + t]);
                 }
         YL_HIP(hipMalloc((void **)&l.d_weights_i8, wh.size() * sizeof(uint16_t)));
-        YL_HIP(hipMemcpy(l.d_weights_i8, wh.data(), wh.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        YL_STAGE(stage_h2d(net.device, l.d_weights_i8, wh.data(), wh.size() * sizeof(uint16_t)));
         const size_t qb = (size_t)net.batch * l.h * l.w * l.Cpad * 2;
         if (qb > net.qbuf_bytes) net.qbuf_bytes = qb;
     } else {   // CONV_XNOR
@@ -226,9 +242,9 @@ static int upload_conv(Network &net, Layer &l)
                     wb[((size_t)(m / 2) * l.Cw + cw) * 18 + (m % 2) * 9 + t] = word;
                 }
         YL_HIP(hipMalloc((void **)&l.d_weights_bits, wb.size() * sizeof(uint64_t)));
-        YL_HIP(hipMemcpy(l.d_weights_bits, wb.data(), wb.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        YL_STAGE(stage_h2d(net.device, l.d_weights_bits, wb.data(), wb.size() * sizeof(uint64_t)));
         YL_HIP(hipMalloc((void **)&l.d_mean, sizeof(float) * M));
-        YL_HIP(hipMemcpy(l.d_mean, l.mean_arr.data(), sizeof(float) * M, hipMemcpyHostToDevice));
+        YL_STAGE(stage_h2d(net.device, l.d_mean, l.mean_arr.data(), sizeof(float) * M));
         size_t bb = (size_t)net.batch * l.h * l.w * l.Cw * sizeof(uint64_t);
         const size_t ob = (size_t)net.batch * l.h * l.w * ((M + 63) / 64) * sizeof(uint64_t);      // sign words of its result
         if (ob > bb) bb = ob;
@@ -288,12 +304,39 @@ static int to_device(Network &net, int device)
             std::vector<int> t(l.tree_parent);
             t.insert(t.end(), l.tree_group_size.begin(), l.tree_group_size.end());
             YL_HIP(hipMalloc((void **)&l.d_tree, t.size() * sizeof(int)));
-            YL_HIP(hipMemcpy(l.d_tree, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice));
+            YL_STAGE(stage_h2d(net.device, l.d_tree, t.data(), t.size() * sizeof(int)));
         }
-        const bool is_head = (l.type == YL_YOLO || l.type == YL_REGION);
-        if ((is_head || i + 1 == net.layers.size()) && !l.host_output) {
-            l.host_output_own.assign(out_elems, 0.f);
-            l.host_output = l.host_output_own.data();
+    }
+    // host side of the heads / last layer (what network_predict_* leaves in l.output): one pinned block.  A layer
+    // without a caller destination owns its region of it; a caller destination (yl_layer_desc.output) is served
+    // by a DMA into the region + memcpy, never by handing the caller's pointer to the runtime (staging.hip).
+    {
+        size_t total = 0;
+        for (size_t i = 0; i < net.layers.size(); ++i) {
+            Layer &l = net.layers[i];
+            const bool is_head = (l.type == YL_YOLO || l.type == YL_REGION);
+            if (!(is_head || i + 1 == net.layers.size()) || l.host_kind == HOST_PINNED) continue;
+            l.h_head_off = total;
+            total += ((size_t)net.batch * l.outputs + 63) & ~(size_t)63;
+        }
+        if (total) {
+#ifdef YL_REPRO_REGISTER        // repro builds only (staging.hip): round 2's registered heap block instead of pinned memory
+            net.h_heads = static_cast<float *>(malloc(total * sizeof(float)));
+            if (!net.h_heads) { set_error("malloc failed"); return YL_ERR_DEVICE; }
+            (void)hipHostRegister(net.h_heads, total * sizeof(float), hipHostRegisterDefault);
+#else
+            YL_HIP(hipHostMalloc((void **)&net.h_heads, total * sizeof(float), hipHostMallocDefault));
+#endif
+            net.h_heads_floats = total;
+            memset(net.h_heads, 0, total * sizeof(float));
+        }
+        for (size_t i = 0; i < net.layers.size(); ++i) {
+            Layer &l = net.layers[i];
+            const bool is_head = (l.type == YL_YOLO || l.type == YL_REGION);
+            if (!(is_head || i + 1 == net.layers.size()) || l.host_kind != HOST_NONE) continue;
+            l.host_output = net.h_heads + l.h_head_off;
+            l.host_kind = HOST_PINNED;
+            l.host_in_heads = true;
         }
     }
     // three quantised-activation buffers used round-robin (layer j reads ring[j % 3]): a producer
@@ -302,7 +345,7 @@ static int to_device(Network &net, int device)
     if (net.bitbuf_bytes) {
         net.bitbuf_bytes = (net.bitbuf_bytes + 255) & ~(size_t)255;
         YL_HIP(hipMalloc((void **)&net.d_bitbuf, 3 * net.bitbuf_bytes));
-        YL_HIP(hipMemset(net.d_bitbuf, 0, 3 * net.bitbuf_bytes));       // half-word writers (32 filters) rely on zeroed upper halves
+        YL_HIP(hipMemsetAsync(net.d_bitbuf, 0, 3 * net.bitbuf_bytes, (hipStream_t)net.stream));       // pad bits start out 0; every writer stores whole 64-bit words (conv_xnor.hip), the ring is reused across layers
     }
     if (net.binbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_binbuf, net.binbuf_bytes));
     // ---- optional conv+shortcut fusion plan ----
@@ -486,6 +529,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
             a.tapmajor = l.tapmajor;
             a.wino32_u = l.d_wino32_u;
+            a.wino_tiling = l.wino_tiling;
             if (l.fused_yolo >= 0) {
                 const Layer &yo = net.layers[l.fused_yolo];
                 a.yolo_entries = yo.classes + 5;
@@ -664,26 +708,46 @@ static bool layer_materialised(const Layer &l)
     return !(l.type == YL_CONVOLUTIONAL && (l.fused_shortcut >= 0 || l.fused_yolo >= 0 || l.skip_f32_out));
 }
 
+// memcpy split over a few host threads (one core moves ~8 GB/s; yolov3-608's heads are 495 MB per batch of 64)
+static void parallel_memcpy(void *dst, const void *src, size_t bytes)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    const unsigned nt = bytes < ((size_t)4 << 20) ? 1u : (hw >= 8 ? 4u : (hw >= 4 ? 2u : 1u));
+    if (nt == 1) { memcpy(dst, src, bytes); return; }
+    const size_t slice = ((bytes / nt) + 63) & ~(size_t)63;
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) {
+        const size_t o = (size_t)t * slice;
+        if (o >= bytes) break;
+        const size_t l = (t + 1 < nt && o + slice < bytes) ? slice : bytes - o;
+        th.emplace_back([=] { memcpy((char *)dst + o, (const char *)src + o, l); });
+    }
+    memcpy(dst, src, slice < bytes ? slice : bytes);
+    for (auto &x : th) x.join();
+}
+
 static int pull_heads(Network &net, bool also_last)
 {
+    hipStream_t s = (hipStream_t)net.stream;
+    bool bounce = false;
     for (size_t i = 0; i < net.layers.size(); ++i) {
         Layer &l = net.layers[i];
         const bool is_head = (l.type == YL_YOLO || l.type == YL_REGION);
         if (!(is_head || (also_last && i + 1 == net.layers.size()))) continue;
         if (!l.host_output) continue;
-        if (!l.host_registered) {
-            // pin the destination once (the reference's calloc'd l.output, or our own vector): a pageable
-            // D2H of yolov3-608's 495 MB of head tensors per batch of 64 was the largest term of
-            // yl_network_predict.  Failure to register is not an error, the copy is just slower.
-            if (hipHostRegister(l.host_output, sizeof(float) * (size_t)net.batch * l.outputs, hipHostRegisterDefault) == hipSuccess)
-                l.host_registered = true;
-            else
-                (void)hipGetLastError();
-        }
-        YL_HIP(hipMemcpyAsync(l.host_output, l.d_output, sizeof(float) * (size_t)net.batch * l.outputs,
-                              hipMemcpyDeviceToHost, (hipStream_t)net.stream));
+        // the DMA always lands in library-pinned memory: the destination itself, or this layer's region of h_heads
+        float *pinned = l.host_kind == HOST_PINNED ? l.host_output : net.h_heads + l.h_head_off;
+        bounce = bounce || l.host_kind != HOST_PINNED;
+        YL_HIP(hipMemcpyAsync(pinned, l.d_output, sizeof(float) * (size_t)net.batch * l.outputs, hipMemcpyDeviceToHost, s));
     }
-    YL_HIP(hipStreamSynchronize((hipStream_t)net.stream));
+    YL_HIP(hipStreamSynchronize(s));
+    if (bounce)
+        for (size_t i = 0; i < net.layers.size(); ++i) {
+            Layer &l = net.layers[i];
+            const bool is_head = (l.type == YL_YOLO || l.type == YL_REGION);
+            if (!(is_head || (also_last && i + 1 == net.layers.size())) || !l.host_output || l.host_kind == HOST_PINNED) continue;
+            parallel_memcpy(l.host_output, net.h_heads + l.h_head_off, sizeof(float) * (size_t)net.batch * l.outputs);
+        }
     return YL_OK;
 }
 
@@ -748,6 +812,7 @@ int yl_network_create_from_desc(const yl_layer_desc *layers, int n_layers, int b
         l.classes = d.classes; l.coords = d.coords ? d.coords : 4; l.total = d.total; l.softmax = d.softmax;
         l.scale = d.scale;
         l.host_output = d.output;
+        l.host_kind = d.output ? HOST_CALLER : HOST_NONE;
         switch (d.type) {
         case YL_CONVOLUTIONAL: {
             if (!d.weights || !d.biases) { delete n; set_error("conv layer without weights/biases"); return YL_ERR_ARG; }
@@ -1087,7 +1152,7 @@ int yl_network_layer_output(yl_network *net, int i, float *dst_host)
     }
     YL_HIP(hipSetDevice(net->net.device));
     YL_HIP(hipStreamSynchronize((hipStream_t)net->net.stream));
-    YL_HIP(hipMemcpy(dst_host, l.d_output, sizeof(float) * (size_t)net->net.batch * l.outputs, hipMemcpyDeviceToHost));
+    YL_STAGE(stage_d2h(net->net.device, dst_host, l.d_output, sizeof(float) * (size_t)net->net.batch * l.outputs));
     return YL_OK;
 }
 
@@ -1102,7 +1167,7 @@ int yl_network_layer_output_image(yl_network *net, int i, int image, float *dst_
     }
     YL_HIP(hipSetDevice(net->net.device));
     YL_HIP(hipStreamSynchronize((hipStream_t)net->net.stream));
-    YL_HIP(hipMemcpy(dst_host, l.d_output + (size_t)image * l.outputs, sizeof(float) * (size_t)l.outputs, hipMemcpyDeviceToHost));
+    YL_STAGE(stage_d2h(net->net.device, dst_host, l.d_output + (size_t)image * l.outputs, sizeof(float) * (size_t)l.outputs));
     return YL_OK;
 }
 
@@ -1125,7 +1190,7 @@ static int pull_debug(yl_network *net, int i, int32_t *dst, int want_mode)
     }
     YL_HIP(hipSetDevice(net->net.device));
     YL_HIP(hipStreamSynchronize((hipStream_t)net->net.stream));
-    YL_HIP(hipMemcpy(dst, l.d_debug, sizeof(int32_t) * (size_t)net->net.batch * l.outputs, hipMemcpyDeviceToHost));
+    YL_STAGE(stage_d2h(net->net.device, dst, l.d_debug, sizeof(int32_t) * (size_t)net->net.batch * l.outputs));
     return YL_OK;
 }
 
@@ -1201,6 +1266,57 @@ int yl_network_profile(yl_network *net, const float *input_dev, int iters, float
 }
 
 
+// decode + NMS of the whole batch on the device, then only the FILLED rows travel: counts first, rows packed densely
+// into the network's pinned block (grown on demand from the counts -- a fixed [batch][cap][6+classes] host image is
+// 90 MB at batch 64 / 80 classes and 1.2 GB for a YOLO9000 head at batch 8).  Leaves n.det_counts / n.det_row_off.
+static int detect_to_pinned(yl_network *net, const int *img_w, const int *img_h, float thresh, int relative, int letter,
+                            float nms, int cap)
+{
+    Network &n = net->net;
+    YL_HIP(hipSetDevice(n.device));
+    const int classes = n.layers.back().classes;
+    const int B = n.batch;
+    const size_t row = (size_t)(6 + classes);
+    const size_t need = sizeof(float) * (size_t)B * cap * row;
+    if (n.det_out_bytes < need) {
+        YL_HIP(hipStreamSynchronize((hipStream_t)n.stream));
+        if (n.d_det_out) (void)hipFree(n.d_det_out);
+        n.d_det_out = nullptr; n.det_out_bytes = 0;
+        YL_HIP(hipMalloc((void **)&n.d_det_out, need));
+        n.det_out_bytes = need;
+    }
+    if (!n.d_det_counts) YL_HIP(hipMalloc((void **)&n.d_det_counts, sizeof(int) * 2 * (size_t)B));
+    if (!n.h_det_counts) YL_HIP(hipHostMalloc((void **)&n.h_det_counts, sizeof(int) * (size_t)B, hipHostMallocDefault));
+    const int rc = yl_network_detect_batch(net, img_w, img_h, thresh, relative, letter, nms, cap, n.d_det_out,
+                                           n.d_det_counts + B);
+    if (rc != YL_OK) return rc;
+    hipStream_t s = (hipStream_t)n.stream;
+    YL_HIP(hipMemcpyAsync(n.h_det_counts, n.d_det_counts + B, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, s));
+    YL_HIP(hipStreamSynchronize(s));
+    n.det_counts.assign(n.h_det_counts, n.h_det_counts + B);
+    n.det_row_off.assign((size_t)B + 1, 0);
+    for (int b = 0; b < B; ++b) {
+        const int c = n.det_counts[b] < cap ? n.det_counts[b] : cap;
+        n.det_row_off[(size_t)b + 1] = n.det_row_off[b] + (size_t)(c > 0 ? c : 0) * row;
+    }
+    const size_t host_need = sizeof(float) * n.det_row_off[B];
+    if (n.h_det_bytes < host_need) {
+        if (n.h_det_rows) (void)hipHostFree(n.h_det_rows);
+        n.h_det_rows = nullptr; n.h_det_bytes = 0;
+        const size_t grow = host_need + host_need / 2 + 4096;
+        YL_HIP(hipHostMalloc((void **)&n.h_det_rows, grow, hipHostMallocDefault));
+        n.h_det_bytes = grow;
+    }
+    for (int b = 0; b < B; ++b) {
+        const size_t fl = n.det_row_off[(size_t)b + 1] - n.det_row_off[b];
+        if (fl)
+            YL_HIP(hipMemcpyAsync(n.h_det_rows + n.det_row_off[b], n.d_det_out + (size_t)b * cap * row, sizeof(float) * fl,
+                                  hipMemcpyDeviceToHost, s));
+    }
+    YL_HIP(hipStreamSynchronize(s));
+    return YL_OK;
+}
+
 int yl_network_get_boxes(yl_network *net, int image, int w, int h, float thresh, int relative, int letter,
                          float nms, float *rows, int max_rows, int *classes_out)
 {
@@ -1217,28 +1333,17 @@ int yl_network_get_boxes(yl_network *net, int image, int w, int h, float thresh,
     // the images of one forward with the same arguments
     DetKey key{n.forward_seq, w, h, thresh, relative, letter, nms};
     if (!n.det_cache_valid || memcmp(&key, &n.det_cache_key, sizeof(key)) != 0) {
-        YL_HIP(hipSetDevice(n.device));
-        const size_t need = sizeof(float) * (size_t)n.batch * cap * row + sizeof(int) * (size_t)n.batch;
-        if (n.h_det_bytes < need) {
-            if (n.h_det_rows) (void)hipHostFree(n.h_det_rows);
-            n.h_det_rows = nullptr; n.h_det_bytes = 0;
-            YL_HIP(hipHostMalloc((void **)&n.h_det_rows, need, hipHostMallocDefault));
-            n.h_det_bytes = need;
-        }
         std::vector<int> ws((size_t)n.batch, w), hs((size_t)n.batch, h);
-        int *counts = reinterpret_cast<int *>(n.h_det_rows + (size_t)n.batch * cap * row);
         n.det_cache_valid = false;
-        const int rc = yl_network_get_boxes_batch(net, ws.data(), hs.data(), thresh, relative, letter, nms, cap,
-                                                  n.h_det_rows, counts);
+        const int rc = detect_to_pinned(net, ws.data(), hs.data(), thresh, relative, letter, nms, cap);
         if (rc != YL_OK) return rc;
         n.det_cache_key = key;
         n.det_cache_valid = true;
     }
-    const int *counts = reinterpret_cast<const int *>(n.h_det_rows + (size_t)n.batch * cap * row);
-    const int count = counts[image];
+    const int count = n.det_counts[image];
     int nrows = count < cap ? count : cap;
     if (nrows > max_rows) nrows = max_rows;
-    if (rows && nrows > 0) memcpy(rows, n.h_det_rows + (size_t)image * cap * row, sizeof(float) * row * nrows);
+    if (rows && nrows > 0) memcpy(rows, n.h_det_rows + n.det_row_off[image], sizeof(float) * row * nrows);
     return count;
 }
 
@@ -1300,10 +1405,16 @@ int yl_network_set_quant_rule(yl_network *net, int rule)
     return YL_OK;
 }
 
-int yl_network_layer_head(const yl_network *net, int i, int *mask, float *anchors)
+int yl_network_layer_head(const yl_network *net, int i, int *mask, int mask_cap, float *anchors, int anchors_cap,
+                          int *anchors_len_out)
 {
     YL_LAYER_OR(YL_ERR_ARG)
     if (l.type != YL_YOLO && l.type != YL_REGION) { set_error("not a detection head"); return YL_ERR_ARG; }
+    if (anchors_len_out) *anchors_len_out = (int)l.anchors.size();
+    if ((mask && mask_cap < l.n) || (anchors && (size_t)(anchors_cap < 0 ? 0 : anchors_cap) < l.anchors.size())) {
+        set_error("yl_network_layer_head: caller array too small");
+        return YL_ERR_ARG;
+    }
     for (int k = 0; k < l.n && mask; ++k) mask[k] = (l.type == YL_YOLO) ? l.mask[k] : k;
     for (size_t k = 0; k < l.anchors.size() && anchors; ++k) anchors[k] = l.anchors[k];
     return l.n;
@@ -1320,11 +1431,12 @@ int yl_network_layer_tree(const yl_network *net, int i, int *parent, int *group_
 
 long long yl_debug_wino_pack(const float *weights, int c, int m, int tiling, float *dst, long long dst_floats)
 {
-    if (!weights || c <= 0 || m <= 0 || c % 8 != 0 || tiling != 32) { set_error("bad argument"); return YL_ERR_ARG; }
-    const size_t need = wino32_packed_floats(c, m);
+    if (!weights || c <= 0 || m <= 0 || c % 8 != 0 || (tiling != 32 && tiling != 16)) { set_error("bad argument"); return YL_ERR_ARG; }
+    const size_t need = tiling == 16 ? wino16_packed_floats(c, m) : wino32_packed_floats(c, m);
     if (!dst) return (long long)need;
     if (dst_floats < (long long)need) { set_error("dst too small"); return YL_ERR_ARG; }
-    wino32_pack_weights(weights, c, m, dst);
+    if (tiling == 16) wino16_pack_weights(weights, c, m, dst);
+    else wino32_pack_weights(weights, c, m, dst);
     return (long long)need;
 }
 
@@ -1357,7 +1469,11 @@ int yl_network_calibrate(yl_network *net, const float *images_host, int n_images
     for (int i : conv_ids) mult[i].assign((size_t)n_images, 0.f);
     unsigned *d_hist = nullptr;
     YL_HIP(hipMalloc((void **)&d_hist, sizeof(unsigned) * (size_t)B * MAX_BIN));
-    std::vector<unsigned> h_hist((size_t)B * MAX_BIN);
+    unsigned *h_hist = nullptr;                // pinned: the per-layer histogram download never touches pageable memory
+    const size_t h_hist_n = (size_t)B * MAX_BIN;
+    if (hipHostMalloc((void **)&h_hist, sizeof(unsigned) * h_hist_n, hipHostMallocDefault) != hipSuccess) {
+        (void)hipFree(d_hist); set_error("hipHostMalloc of the calibration histogram failed"); return YL_ERR_DEVICE;
+    }
     int rc = YL_OK;
     for (int img0 = 0; img0 < n_images && rc == YL_OK; img0 += B) {
         memcpy(n.h_pinned, images_host + (size_t)img0 * n.c * n.h * n.w, n.pinned_bytes);
@@ -1368,7 +1484,7 @@ int yl_network_calibrate(yl_network *net, const float *images_host, int n_images
             if (l.type == YL_CONVOLUTIONAL) {
                 // the layer's input as the forward pass sees it (network_calibrate_cpu: state.input, l.inputs)
                 if (launch_hist_abs(input, (size_t)l.inputs, B, MAX_BIN, BIN_W, d_hist, s) != 0 ||
-                    hipMemcpyAsync(h_hist.data(), d_hist, sizeof(unsigned) * h_hist.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                    hipMemcpyAsync(h_hist, d_hist, sizeof(unsigned) * h_hist_n, hipMemcpyDeviceToHost, s) != hipSuccess ||
                     hipStreamSynchronize(s) != hipSuccess) { set_error("calibration histogram failed"); rc = YL_ERR_DEVICE; break; }
                 // the KL scans of the B images of this layer are independent: one host thread each
                 // (the reference spends most of its calibration time here, single-threaded)
@@ -1377,7 +1493,7 @@ int yl_network_calibrate(yl_network *net, const float *images_host, int n_images
                     const int nt = (int)(hw == 0 ? 1 : (hw > 16 ? 16 : hw));
                     std::vector<std::thread> th;
                     float *dst = mult[i].data() + img0;
-                    const unsigned *hh = h_hist.data();
+                    const unsigned *hh = h_hist;
                     for (int t0 = 1; t0 < nt && t0 < B; ++t0)
                         th.emplace_back([=] {
                             for (int b = t0; b < B; b += nt) dst[b] = entropy_from_counts(hh + (size_t)b * MAX_BIN, MAX_BIN, BIN_W);
@@ -1392,6 +1508,7 @@ int yl_network_calibrate(yl_network *net, const float *images_host, int n_images
     }
     (void)hipStreamSynchronize(s);
     (void)hipFree(d_hist);
+    (void)hipHostFree(h_hist);
     if (rc != YL_OK) return rc;
     // The reference's averaging, slot for slot (src/yolov2_forward_network.c:786-797): multipliers go to
     // input_mult_array[counter + i*max_num] with a 1-based image counter, the mean is taken over slots
@@ -1481,7 +1598,7 @@ int yl_network_input_download(yl_network *net, float *dst_host)
     if (!n.on_device) { set_error("network not on device"); return YL_ERR_STATE; }
     YL_HIP(hipSetDevice(n.device));
     YL_HIP(hipStreamSynchronize((hipStream_t)n.stream));
-    YL_HIP(hipMemcpy(dst_host, n.d_input, sizeof(float) * (size_t)n.batch * n.c * n.h * n.w, hipMemcpyDeviceToHost));
+    YL_STAGE(stage_d2h(n.device, dst_host, n.d_input, sizeof(float) * (size_t)n.batch * n.c * n.h * n.w));
     return YL_OK;
 }
 
@@ -1583,33 +1700,15 @@ int yl_network_get_boxes_batch(yl_network *net, const int *img_w, const int *img
     if (!net || !rows_host || !counts_host || cap <= 0) { set_error("bad argument"); return YL_ERR_ARG; }
     Network &n = net->net;
     if (!n.on_device) { set_error("network not on device"); return YL_ERR_STATE; }
-    YL_HIP(hipSetDevice(n.device));
-    const int classes = n.layers.back().classes;
-    const int B = n.batch;
-    const size_t need = sizeof(float) * (size_t)B * cap * (6 + classes);
-    if (n.det_out_bytes < need) {
-        YL_HIP(hipStreamSynchronize((hipStream_t)n.stream));
-        if (n.d_det_out) (void)hipFree(n.d_det_out);
-        n.d_det_out = nullptr; n.det_out_bytes = 0;
-        YL_HIP(hipMalloc((void **)&n.d_det_out, need));
-        n.det_out_bytes = need;
-    }
-    if (!n.d_det_counts) YL_HIP(hipMalloc((void **)&n.d_det_counts, sizeof(int) * 2 * (size_t)B));
-    const int rc = yl_network_detect_batch(net, img_w, img_h, thresh, relative, letter, nms, cap, n.d_det_out,
-                                           n.d_det_counts + B);
+    n.det_cache_valid = false;                       // the pinned block is about to be overwritten
+    const int rc = detect_to_pinned(net, img_w, img_h, thresh, relative, letter, nms, cap);
     if (rc != YL_OK) return rc;
-    hipStream_t s = (hipStream_t)n.stream;
-    YL_HIP(hipMemcpyAsync(counts_host, n.d_det_counts + B, sizeof(int) * (size_t)B, hipMemcpyDeviceToHost, s));
-    YL_HIP(hipStreamSynchronize(s));
-    // only the filled rows travel
-    const size_t row = (size_t)(6 + classes);
-    for (int b = 0; b < B; ++b) {
-        const int c = counts_host[b] < cap ? counts_host[b] : cap;
-        if (c > 0)
-            YL_HIP(hipMemcpyAsync(rows_host + (size_t)b * cap * row, n.d_det_out + (size_t)b * cap * row,
-                                  sizeof(float) * row * c, hipMemcpyDeviceToHost, s));
+    const size_t row = (size_t)(6 + n.layers.back().classes);
+    for (int b = 0; b < n.batch; ++b) {
+        counts_host[b] = n.det_counts[b];
+        const size_t fl = n.det_row_off[(size_t)b + 1] - n.det_row_off[b];
+        if (fl) memcpy(rows_host + (size_t)b * cap * row, n.h_det_rows + n.det_row_off[b], sizeof(float) * fl);
     }
-    YL_HIP(hipStreamSynchronize(s));
     return YL_OK;
 }
 

@@ -14,6 +14,7 @@ namespace yl {
 
 // which convolution implementation a CONVOLUTIONAL layer runs with
 enum ConvMode { CONV_F32 = 0, CONV_INT8 = 1, CONV_XNOR = 2, CONV_BF16 = 3 };
+enum HostKind { HOST_NONE = 0, HOST_CALLER = 1, HOST_PINNED = 2 };
 
 struct Layer {
     int type = YL_BLANK;
@@ -41,9 +42,14 @@ struct Layer {
     bool xnor_ready = false;
     int conv_mode = CONV_F32;
 
-    float *host_output = nullptr;        // borrowed (desc.output) or owned (host_output_own)
-    std::vector<float> host_output_own;
-    bool host_registered = false;        // host_output pinned with hipHostRegister (heads: fast D2H)
+    // where pull_heads delivers this layer's tensor (heads / last layer only).  The HIP runtime is never handed
+    // caller memory (staging.hip): HOST_CALLER destinations (yl_layer_desc.output = the reference's calloc'd
+    // l.output) are reached through the network's own pinned block + memcpy, HOST_PINNED ones (library-allocated:
+    // net.h_heads or a group's global tensors) take the DMA directly.
+    float *host_output = nullptr;
+    int   host_kind = HOST_NONE;
+    bool  host_in_heads = false;         // host_output points into net.h_heads (dropped together with it)
+    size_t h_head_off = 0;               // floats: this layer's region of net.h_heads
 
     // ---- device state (owned by runtime.hip) ----
     float *d_output = nullptr;           // [batch][out_c][out_h][out_w]
@@ -52,7 +58,8 @@ struct Layer {
     float *d_biases = nullptr;
     int   Kpad = 0, Mpad = 0;
     int   tapmajor = 0;                  // K order of d_weights_t (see conv_f32_mfma.hip)
-    float *d_wino32_u = nullptr;         // FP32 3x3/1/1: Winograd-packed U (conv_f32_wino32.hip), else nullptr
+    float *d_wino32_u = nullptr;         // FP32 3x3/1/1: Winograd-packed U (conv_f32_wino16.hip / _wino32.hip), else nullptr
+    int   wino_tiling = 32;              // which of the two packings d_wino32_u holds
     int8_t *d_weights_i8 = nullptr;      // INT8: [K16pad][Mpad][16] int8 units; BF16: [K8pad][Mpad][8] bf16 units
     int   Cpad = 0;                      // channels of the 16-byte-unit activation tensor (INT8: 16 per unit, BF16: 8)
     float bias_abs_max = 0.f;            // INT8: max |bias| and the smallest non-zero |bias| (-1 = a bias is not finite):
@@ -114,14 +121,19 @@ struct Network {
     float *d_binbuf = nullptr;           // XNOR FP32 fallback: +-1 image scratch
     size_t binbuf_bytes = 0;
     void *h_pinned = nullptr;            // pinned staging for the input
+    float *h_heads = nullptr;            // pinned: head / last-layer tensors (owned destinations and bounce regions)
+    size_t h_heads_floats = 0;
     size_t pinned_bytes = 0;
     float *d_det_scratch = nullptr;      // batched detections: compacted records before NMS
     size_t det_scratch_bytes = 0;
     float *d_det_out = nullptr;          // batched detections: device staging of yl_network_get_boxes_batch
     size_t det_out_bytes = 0;
     int *d_det_counts = nullptr;         // [2][batch]: raw compaction counts, staged output counts
-    float *h_det_rows = nullptr;         // pinned: rows [batch][cap][6+classes] + counts [batch] of yl_network_get_boxes
+    float *h_det_rows = nullptr;         // pinned: the filled detection rows of the last decode, packed image after image
     size_t h_det_bytes = 0;
+    int *h_det_counts = nullptr;         // pinned [batch]
+    std::vector<int> det_counts;         // counts of the last decode (may exceed cap)
+    std::vector<size_t> det_row_off;     // [batch + 1] float offsets into h_det_rows
     DetKey det_cache_key{};
     bool det_cache_valid = false;
     unsigned *d_det_meta = nullptr;      // [batch][1 + class words]: NMS `total` + class bitmap
@@ -135,6 +147,10 @@ struct Network {
 };
 
 void set_error(const std::string &msg);
+
+// staging.hip: caller memory <-> device through library-owned pinned chunks; both return when the bytes have landed
+int stage_h2d(int device, void *dst_dev, const void *src_host, size_t bytes);
+int stage_d2h(int device, void *dst_host, const void *src_dev, size_t bytes);   // producer stream already synchronised
 
 // host_cfg.cpp
 int parse_cfg_file(const char *path, int batch, int quantized, Network &net);

@@ -172,13 +172,15 @@ class Network:
 
     def layer_head(self, i: int):
         """(mask, anchors) of YOLO/REGION layer i"""
-        li = self.layer_info(i)
-        mask = (C.c_int * max(li["n"], 1))()
-        anchors = (C.c_float * (2 * max(li["total"], li["n"], 1)))()
-        n = lib.yl_network_layer_head(self._h, i, mask, anchors)
+        na = C.c_int(0)
+        n = lib.yl_network_layer_head(self._h, i, None, 0, None, 0, C.byref(na))        # sizes first
         if n < 0:
             raise YoloHipError("yl_network_layer_head failed: " + _lib.last_error())
-        return np.array(mask[:n], dtype=np.int32), np.array(anchors[:], dtype=np.float32)
+        mask = (C.c_int * max(n, 1))()
+        anchors = (C.c_float * max(na.value, 1))()
+        if lib.yl_network_layer_head(self._h, i, mask, n, anchors, na.value, None) < 0:
+            raise YoloHipError("yl_network_layer_head failed: " + _lib.last_error())
+        return np.array(mask[:n], dtype=np.int32), np.array(anchors[:na.value], dtype=np.float32)
 
     def layer_tree(self, i: int):
         """(parent[classes], group_size[groups]) of a REGION layer with a softmax tree, or None"""
@@ -343,11 +345,15 @@ class Network:
                   relative: int = 1, letter: int = 0, max_rows: int = 4096) -> np.ndarray:
         classes = self.layer_info(self.n - 1)["classes"]
         max_rows = min(max_rows, 4096)          # YL_DETECT_MAX_CAP
-        rows = np.zeros((max_rows, 6 + classes), dtype=np.float32)
-        n = lib.yl_network_get_boxes(self._h, image, w, h, thresh, relative, letter, nms, _fp(rows), max_rows, None)
+        # count first (the batch's decode is cached in the library), then exactly the rows that exist
+        n = lib.yl_network_get_boxes(self._h, image, w, h, thresh, relative, letter, nms, None, 0, None)
         if n < 0:
             raise YoloHipError("yl_network_get_boxes failed: " + _lib.last_error())
-        return rows[:min(n, max_rows)].copy()
+        k = min(n, max_rows)
+        rows = np.zeros((k, 6 + classes), dtype=np.float32)
+        if k and lib.yl_network_get_boxes(self._h, image, w, h, thresh, relative, letter, nms, _fp(rows), k, None) < 0:
+            raise YoloHipError("yl_network_get_boxes failed: " + _lib.last_error())
+        return rows
 
     @staticmethod
     def _dims(sizes, batch):
