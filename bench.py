@@ -227,12 +227,10 @@ class Leg:
         self.stream = stream
         # quantized: 0 FP32, 1 -quantized INT8, 2 the opt-in BF16 variant of the FP32 path
         self.net = Network.load(cfg, wts, b_local, 1 if quantized == 1 else 0, device=dev.index, fuse=not args.no_fuse,
-                                bf16=(quantized == 2))
+                                bf16=(quantized == 2), variant=(args.variant if args.variant >= 0 else None))
         self.net.set_stream(stream.cuda_stream)
         if args.tile:
             self.net.set_conv_tile(args.tile)
-        if args.variant >= 0:
-            self.net.set_variant(args.variant)
         if args.i8_tile:
             self.net.set_int8_tile(args.i8_tile)
         last = self.net.layer_info(self.net.n - 1)
@@ -344,6 +342,31 @@ class Leg:
         self.torch.cuda.empty_cache()
 
 
+def pmc_traffic(leg, kernel_name: str):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE in their own runs, gfx950 FETCH_SIZE x2 correction), collected on the batch-64 step of
+    the same model and size; other per-GPU batches (strong-scaled ranks) are scaled linearly.  A missing entry is an
+    ERROR (a renamed kernel must not silently lose its counter evidence): said loudly on stderr and in the line."""
+    a = leg.args
+    key = kernel_name if (a.model == "yolov3" and a.size == 608) else "%s@%s-%d" % (kernel_name, a.model, a.size)
+    ref_batch = {"yolov3": 64, "yolov3-tiny": 32, "tiny-yolo-xnor": 128}.get(a.model, 64)
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pt = json.load(f).get(key)
+    except (OSError, ValueError) as ex:
+        pt = None
+        print("bench.py: cannot read profiles/pmc_traffic.json: %r" % (ex,), file=sys.stderr)
+    if not pt:
+        print("bench.py: ERROR: no PMC traffic entry for kernel %r in profiles/pmc_traffic.json -- re-run the "
+              "FETCH_SIZE / WRITE_SIZE passes (tools/gpu_round.sh pmc) for the shipped kernel" % key, file=sys.stderr)
+        return None, "MISSING from profiles/pmc_traffic.json: %s" % key
+    traffic = (2.0 * pt["fetch_kib"] + pt["write_kib"]) * 1024.0 * (leg.B / float(ref_batch))
+    src = "committed rocprofv3 PMC passes (profiles/pmc_traffic.json, batch %d), not collected in this run" % ref_batch
+    if leg.B != ref_batch:
+        src += "; scaled linearly to this rank's batch of %d" % leg.B
+    return traffic, src
+
+
 def fp32_roofline(leg, args):
     kern = leg.kernels()
     dom_name = max(kern, key=lambda n: kern[n]["flops"])
@@ -354,15 +377,7 @@ def fp32_roofline(leg, args):
     conv_ms = sum(k["ms"] for k in kern.values())
     conv_flops = sum(k["flops"] for k in kern.values())
     conv_exec = sum(k["exec_flops"] for k in kern.values())
-    traffic = None
-    try:
-        if args.model == "yolov3" and args.size == 608 and leg.B == 64:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pt = json.load(f).get(dom_name)
-            if pt:
-                traffic = (2.0 * pt["fetch_kib"] + pt["write_kib"]) * 1024.0
-    except (OSError, ValueError):
-        traffic = None
+    traffic, traffic_src = pmc_traffic(leg, dom_name)
     n = max(dom["launches"], 1)
     return {
         "bound": "mfma", "kernel": dom_name,
@@ -372,7 +387,7 @@ def fp32_roofline(leg, args):
         "algorithmic_tflops": algorithmic,                      # 2*M*K*N per launch / the same time
         "algorithmic_speedup": dom["flops"] / dom["exec_flops"] if dom["exec_flops"] else None,
         "traffic": traffic,
-        "traffic_source": "committed rocprofv3 PMC passes (profiles/pmc_traffic.json), not collected in this run",
+        "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": dom["bytes"] / n,
         "algorithmic_flops_per_launch": dom["flops"] / n, "executed_flops_per_launch": dom["exec_flops"] / n,
         "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / n,
@@ -402,23 +417,14 @@ def int8_roofline(leg, prefix="conv_i8", mfma_peak=None, what="int8"):
     tot_ms = sum(k["ms"] for k in i8.values())
     tot_bytes = sum(k["bytes"] for k in i8.values())
     tot_ops = sum(k["flops"] for k in i8.values())
-    traffic = None
-    try:
-        if leg.args.model == "yolov3" and leg.args.size == 608 and leg.B == 64:
-            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                pt = json.load(f).get(dom_name)
-            if pt:
-                traffic = (2.0 * pt["fetch_kib"] + pt["write_kib"]) * 1024.0
-    except (OSError, ValueError):
-        traffic = None
+    traffic, traffic_src = pmc_traffic(leg, dom_name) if what == "int8" else (None, "no PMC pass of the opt-in BF16 leg")
     return {
         "bound": "hbm", "kernel": dom_name,
         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
         "achieved_is": "algorithmic bytes (%s in, weights, FP32 [shortcut] operand in / sum out, %s side output; "
                        "yl_network_layer_traffic) of the kernel's launches / their measured duration" % (what, what),
         "traffic": traffic,
-        "traffic_source": "committed rocprofv3 PMC passes (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE in their own "
-                          "runs, gfx950 correction applied), not collected in this run",
+        "traffic_source": traffic_src,
         "mfma_tops": tops, "mfma_peak_tops": mfma_peak, "mfma_frac": tops / mfma_peak,
         "algorithmic_bytes_per_launch": dom["bytes"] / n, "launches_per_step": dom["launches"],
         "avg_launch_ms": dom["ms"] / n,
@@ -441,6 +447,7 @@ def xnor_roofline(leg):
     sec = dom["ms"] * 1e-3
     gbs = dom["bytes"] / sec / 1e9 if sec > 0 else 0.0
     tbm = dom["flops"] / 2 / sec / 1e12 if sec > 0 else 0.0
+    traffic, traffic_src = pmc_traffic(leg, dom_name)
     # with sign words handed from layer to layer the bit convolutions move almost no HBM bytes: the roof that
     # binds them is the VALU's xnor + popcount rate (no 1-bit MFMA exists on CDNA4)
     return {
@@ -450,7 +457,7 @@ def xnor_roofline(leg):
                        "peak = one v_xnor_b32 + one v_bcnt_u32_b32 per 32 bit-MACs and lane at 32 lanes/clk/SIMD, 2.4 GHz",
         "hbm_gbs": gbs, "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": gbs / HBM_PEAK_GBS,
         "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
-        "traffic": None,
+        "traffic": traffic, "traffic_source": traffic_src,
     }
 
 
@@ -555,6 +562,86 @@ def group_leg(args, torch, dev, Network, cfg, wts, x, steps=4):
     grp.close()
     return {"value": B / t, "unit": "images/sec", "ms_per_step": t * 1e3, "devices": 1, "detections": dets,
             "what": "yl_group_forward + yl_group_detect_batch (ncclSend/ncclRecv gather to the root) on 1 device"}
+
+
+def side_leg(args, torch, dist, dev, stream, Network, weights, zoo, model, size, batch, steps=10, warmup=2):
+    """BASELINE configs 2 and 5 as short extra legs of the default line: the same step
+    (forward + on-device decode + NMS, inputs resident in HBM) on yolov3-tiny 416 batch 32 FP32 / tiny-yolo-xnor 416
+    batch 128, each with the roofline block of its dominant kernel."""
+    import copy
+    a = copy.copy(args)
+    a.model, a.size, a.batch, a.global_batch = model, size, batch, batch
+    work = tempfile.mkdtemp(prefix="yl_bench_side_")
+    cfg = zoo.write_cfg(model, work, size, size)
+    wts = os.path.join(work, "synthetic.weights")
+    with open(cfg) as f:
+        cfg_text = f.read()
+    weights.write_synthetic_weights(cfg_text, wts, seed=1)
+    if not args.raw_head:
+        deltas = calibrate_head(Network, cfg, wts, size, dev.index, args.thresh)
+        if deltas:
+            weights.write_synthetic_weights(cfg_text, wts, seed=1, head_bias_delta=deltas)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2222222)
+    x = torch.rand((batch, 3, size, size), generator=gen, device=dev, dtype=torch.float32)
+    leg = Leg(a, torch, dist, dev, stream, Network, cfg, wts, 0, batch, 1, False)
+    elapsed = leg.run(x, steps, warmup)
+    xnor = model == "tiny-yolo-xnor"
+    det_counts = leg.cnt.cpu().numpy()
+    out = {
+        "workload": "%s.cfg %dx%d batch=%d %s, 1 GPU, same step as `value`" % (model, size, size, batch,
+                                                                              "BIT1-XNOR" if xnor else "FP32"),
+        "value": batch * steps / elapsed, "unit": "images/sec", "ms_per_step": elapsed / steps * 1e3,
+        "steps": steps, "warmup": warmup, "dtype": "u1" if xnor else "f32",
+        "roofline": xnor_roofline(leg) if xnor else fp32_roofline(leg, a),
+        "detections_per_image": {"mean": float(det_counts.mean()), "max": int(det_counts.max())},
+        "gflop_per_image": leg.net.flops_per_image / 1e9,
+    }
+    leg.close()
+    del x
+    torch.cuda.empty_cache()
+    return out
+
+
+def int8_vs_reference_int8(Network, cfg_q, wts, size, device, thresh, nms, images=2):
+    """Config 4's accuracy figure against the right baseline: the HIP -quantized path against
+    the REFERENCE's own network_predict_quantized (src/yolov2_forward_network_quantized.c:1160, the library bench.py
+    already times as cpu_baseline) on the same images -- head tensors and detections.  The integer arithmetic of
+    the two is bit-exact layer by layer (tests/test_gpu_headline.py, teacher-forced); end to end the FP32 layers of the
+    -quantized path (layer 0, the linear head convolutions) sum in a different order, and a last-bit difference
+    there can flip an int8 code downstream, so the comparison is statistical."""
+    from oracle import refbind
+    if not refbind.available(fast=True):
+        return None
+    ref = refbind.RefNetwork(cfg_q, wts, 1, 1, fast=True)
+    hip = Network.load(cfg_q, wts, 1, 1, device=device, fuse=True)
+    rng = np.random.default_rng(2222222)
+    heads = [i for i in range(hip.n) if hip.layer_info(i)["type"] in (21, 22)]
+    ref_rows, hip_rows = [], []
+    err2 = {i: 0.0 for i in heads}; nrm2 = {i: 0.0 for i in heads}; exact = {i: 0 for i in heads}; total = {i: 0 for i in heads}
+    for _ in range(images):
+        x = rng.random((1, 3, size, size), dtype=np.float32)
+        ref.predict(x)
+        hip.predict(x)
+        for i in heads:
+            r = ref.layer_output(i).astype(np.float64); g = hip.layer_output(i).astype(np.float64)
+            err2[i] += float(((g - r) ** 2).sum()); nrm2[i] += float((r ** 2).sum())
+            exact[i] += int((g == r).sum()); total[i] += r.size
+        ref_rows.append(ref.get_detections(0, size, size, thresh, nms=nms))
+        hip_rows.append(hip.get_boxes(0, size, size, thresh, nms=nms))
+    hip.close()
+    agree = detection_agreement(ref_rows, hip_rows)
+    return {
+        "images": images,
+        "reference_int8_detections": agree["fp32_detections"], "hip_int8_detections": agree["int8_detections"],
+        "matched": agree["matched"], "recall_vs_reference_int8": agree["recall_vs_fp32"],
+        "precision_vs_reference_int8": agree["precision_vs_fp32"], "mean_iou_of_matched": agree["mean_iou_of_matched"],
+        "mean_abs_objectness_diff": agree["mean_abs_objectness_diff"], "rule": agree["rule"],
+        "head_tensors": [{"layer": i, "rel_rms_err": (err2[i] / max(nrm2[i], 1e-300)) ** 0.5,
+                          "bit_equal_fraction": exact[i] / max(total[i], 1)} for i in heads],
+        "what": "HIP -quantized path vs the reference's network_predict_quantized (AVX=1 OPENMP=1 build) on the same "
+                "%d synthetic 608-style images, batch 1 each" % images,
+    }
 
 
 def main():
@@ -695,6 +782,15 @@ def main():
                 extras["group_n1"] = group_leg(args, torch, dev, Network, cfg, wts, x)
             except Exception as ex:
                 extras["group_n1"] = {"error": repr(ex)}
+            if args.model == "yolov3" and args.size == 608:
+                del x
+                torch.cuda.empty_cache()
+                for key, (m, sz, b) in (("config2_yolov3_tiny_416_b32_fp32", ("yolov3-tiny", 416, 32)),
+                                        ("config5_tiny_yolo_xnor_416_b128", ("tiny-yolo-xnor", 416, 128))):
+                    try:
+                        extras[key] = side_leg(args, torch, dist, dev, stream, Network, weights, zoo, m, sz, b)
+                    except Exception as ex:
+                        extras[key] = {"error": repr(ex)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -703,6 +799,12 @@ def main():
                     q = cpu_baseline(cfg_q, wts, args.size, args.size, 1, args.cpu_seconds / 2)
                     if q:
                         cpu["int8"] = {k: q[k] for k in ("value", "sample")}
+                        if not args.no_extras and not xnor_model:
+                            try:
+                                cpu["int8"]["hip_int8_vs_reference_int8"] = int8_vs_reference_int8(
+                                    Network, cfg_q, wts, args.size, local_rank, args.thresh, args.nms if args.nms > 0 else 0.4)
+                            except Exception as ex:
+                                cpu["int8"]["hip_int8_vs_reference_int8"] = {"error": repr(ex)}
             except Exception as e:      # the baseline is reported, never required
                 cpu = {"error": repr(e)}
         head = result["fp32"] if do_fp32 else (result["int8"] if do_int8 else result["bf16"])

@@ -297,7 +297,8 @@ int yl_network_set_conv_tile(yl_network *net, int cfg);
  * bit 0 Winograd U panels by LDS-DMA, bit 1 Winograd epilogue prefetches the fused [shortcut] operand,
  * bit 2 float4 B-panel rows in the 1x1 direct kernel, bit 3 LDS-free first-layer kernel, bit 4 Winograd from 32
  * input channels up, bit 5 (takes effect at the next yl_network_to_device: it selects the weight packing) the Winograd
- * kernel with all 16 planes of a block in one wave and the output transform in registers; -1 = built-in default */
+ * kernel with all 16 planes of a block in one wave and the output transform in registers, bit 6 (with bit 5) its
+ * warp-specialised form (4 matrix waves that only issue MFMAs + 4 staging waves); -1 = built-in default */
 int yl_network_set_variant(yl_network *net, int bits);
 /* Opt-in BF16 variant of the FP32 path (north_star (a) "FP32/BF16"; BEFORE yl_network_to_device): every FP32
  * convolution whose input has whole 8-channel groups runs on v_mfma_f32_32x32x16_bf16 with both operands rounded
@@ -312,6 +313,15 @@ int yl_network_set_precision(yl_network *net, int precision);
 int yl_network_set_int8_tile(yl_network *net, int cfg);
 int yl_network_set_winograd(yl_network *net, int on);
 int yl_network_set_nms_mode(yl_network *net, int mode);
+/* Kernel-layout weight packing at yl_network_to_device (the reference packs on one host core:
+ * binary_align_weights src/additionally.c:196-302, init_gpu_int8x4 src/yolov2_forward_network_quantized.c:1489):
+ * 1 (default) = the prepared weights are uploaded as they are and packed by kernels on the device (csrc/pack.hip),
+ * 0 = packed by host loops and uploaded inflated.  Bit-identical images either way.  BEFORE yl_network_to_device. */
+int yl_network_set_device_pack(yl_network *net, int on);
+/* Test hook: the packed weight image of conv layer i as it sits on the device: which = 0 k-major FP32 panels,
+ * 1 Winograd U, 2 int8 / bf16 units, 3 XNOR sign words.  Returns its size in bytes (0 = the layer has none);
+ * copies it when dst_host != NULL (dst_bytes >= size). */
+long long yl_debug_layer_packed(yl_network *net, int i, int which, void *dst_host, long long dst_bytes);
 /* Test hook (host only, no GPU needed): the Winograd weight transform U = G g G^T of a 3x3 layer
  * (weights[m][c][3][3]) packed the way the kernel reads it.  tiling 32 (conv_f32_wino32.hip):
  * [m/32][c/4][xi 16][half 2][m 32][kk 2] with channel = panel*4 + 2*kk + half; tiling 16 (conv_f32_wino16.hip):

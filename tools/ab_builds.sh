@@ -1,15 +1,28 @@
 #!/bin/bash
-# A/B builds of the library on the same GPU box: tools/ab/libyolo2hip_<v>.so for v in $VARIANTS
-cp yolo2_light_amd/libyolo2hip.so /tmp/keep.so
-for round in 1; do
-for v in ${VARIANTS:-old new}; do
-  cp tools/ab/libyolo2hip_$v.so yolo2_light_amd/libyolo2hip.so
-  echo "== $v"
-  timeout 200 python tools/sweep_conv.py --batch 64 --tiles ${TILES:-31} --only ${SHAPES:-9,12,15} --iters 5 2>&1 | grep -E "^\{" | python -c "
+# Timing-experiment builds of the round-2 Winograd kernel (conv_f32_wino32.hip, -DX_DBG=<bits>, see that file): one
+# library per value under tools/ab/ (git-ignored, travels with gpurun), then `run` times them side by side on ONE
+# GPU box on the Winograd shapes of yolov3-608 at batch 64.  Results of X_DBG != 0 builds are garbage by design.
+#   bash tools/ab_builds.sh build "0 7 64 128 256"       (here, cross-compiles)
+#   bash tools/ab_builds.sh run   "0 7 64 128 256" [variant]   (on the GPU box)
+set -e
+cd "$(dirname "$0")/.."
+MODE=$1; VALS=${2:-0}; VARIANT=${3:-30}
+if [ "$MODE" = build ]; then
+  mkdir -p tools/ab yolo2_light_amd/csrc/build_repro
+  for v in $VALS; do
+    ( cd yolo2_light_amd/csrc
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -DX_DBG=$v -c conv_f32_wino32.hip -o build_repro/wino32_x$v.o
+      objs=$(ls build/*.o | grep -v "build/conv_f32_wino32.o")
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ab/libyolo2hip_x$v.so $objs build_repro/wino32_x$v.o -ldl -lpthread )
+    echo "built tools/ab/libyolo2hip_x$v.so"
+  done
+else
+  for v in $VALS; do
+    echo "== X_DBG=$v variant=$VARIANT"
+    YOLO2HIP_LIB=$PWD/tools/ab/libyolo2hip_x$v.so timeout 300 python tools/sweep_conv.py --batch 64 --tiles 31 --only ${SHAPES:-6,9,12,15} --iters 5 --variant $VARIANT 2>&1 | grep -E "^\{" | python -c "
 import sys, json
 for l in sys.stdin:
-    r=json.loads(l); print(r['shape'], r['M'], r['C'], r['H'], r['tile'], '%.3f ms %.1f TF' % (r['ms'], r['tflops']))
+    r=json.loads(l); print(r['shape'], r['M'], r['C'], r['H'], r['kernel'], '%.3f ms %.1f TF' % (r['ms'], r['tflops']))
 "
-done
-done
-cp /tmp/keep.so yolo2_light_amd/libyolo2hip.so
+  done
+fi

@@ -34,6 +34,7 @@ def main():
                     help="forced tile ids: 11..22 = direct kernel tiles, 0 = heuristic, 31 = Winograd (3x3/1/1 only)")
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--only", default="", help="comma list of shape indices")
+    ap.add_argument("--variant", type=int, default=-1, help="yl_network_set_variant bits, applied before to_device")
     args = ap.parse_args()
     import torch
     import descs as D
@@ -53,6 +54,8 @@ def main():
         bias = rng.normal(0, 0.1, M).astype(np.float32)
         d = D.conv(B, H, H, Cc, M, size, stride, pad, D.LEAKY, wts, bias)
         net = Network.from_desc([d], B, H, H, Cc)
+        if args.variant >= 0:
+            net.set_variant(args.variant)
         net.to_device(0)
         x = torch.rand((B, Cc, H, H), device="cuda:0", dtype=torch.float32) - 0.3
         flops = 2.0 * M * K * d.out_h * d.out_w * B

@@ -98,6 +98,114 @@ __device__ __forceinline__ void input_transform16(const float (&d)[16], float (&
 
 }  // namespace
 
+// Epilogue of one wave: Y = A^T M A on the lane's own registers, + bias, leaky, fused [shortcut]; no LDS, no barrier.
+// wt = which 16-tile quarter of the workgroup's 64 tiles this wave owns.
+template <bool APF>
+__device__ __forceinline__ void wino16_epilogue(const ConvWino16Dev &p, const f32x4 (&acc)[16][2], int wt, int lane, int m0, int t0)
+{
+    const int l15 = lane & 15;
+    const int lk = lane >> 4;
+    const int HW = p.H * p.W;
+    // ---- epilogue: Y = A^T M A on the lane's own registers, + bias, leaky, fused [shortcut]; no LDS, no barrier ----
+    const int tg_e = t0 + wt * 16 + l15;
+    const bool t_ok_e = tg_e < p.T;
+    const int b_e = t_ok_e ? tg_e / p.tpi : 0;
+    const int r_e = tg_e - b_e * p.tpi;
+    const int ti_e = r_e / p.tw;
+    const int tj_e = r_e - ti_e * p.tw;
+    const int oy = 2 * ti_e, ox = 2 * tj_e;
+    const bool row1 = oy + 1 < p.H;
+    const bool col1 = ox + 1 < p.W;
+    const bool vec2 = col1 && ((p.W & 1) == 0);
+    const unsigned HW4 = (unsigned)HW * 4u;
+    const unsigned W4 = (unsigned)p.W * 4u;
+    // byte offset of (b_e, m0 + 4 * lk, oy, ox): 32-bit (the launcher keeps Winograd to tensors below 4 GB)
+    const unsigned obase = ((((unsigned)b_e * (unsigned)p.M + (unsigned)(m0 + 4 * lk)) * (unsigned)p.H + (unsigned)oy) *
+                            (unsigned)p.W + (unsigned)ox) * 4u;
+    const char *addb = reinterpret_cast<const char *>(p.add);
+    char *outb = reinterpret_cast<char *>(p.out);
+    char *oaddb = reinterpret_cast<char *>(p.out_add);
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+        float apf[4][2][2];
+        if constexpr (APF) {
+            if (p.add) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) apf[rr][i][0] = apf[rr][i][1] = 0.f;
+                    if (m0 + 16 * fb + 4 * lk + rr < p.M && t_ok_e) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            if (i == 1 && !row1) break;
+                            const unsigned o = obase + (unsigned)(16 * fb + rr) * HW4 + (unsigned)i * W4;
+                            if (vec2) {
+                                const float2 a = *reinterpret_cast<const float2 *>(addb + o);
+                                apf[rr][i][0] = a.x; apf[rr][i][1] = a.y;
+                            } else {
+                                apf[rr][i][0] = *reinterpret_cast<const float *>(addb + o);
+                                if (col1) apf[rr][i][1] = *reinterpret_cast<const float *>(addb + o + 4u);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int m = m0 + 16 * fb + 4 * lk + rr;
+            // rows of A^T M: tmp0 = (M0 + M1) + M2, tmp1 = M1 - (M2 + M3)   (same association as conv_f32_wino32.hip)
+            float tmp[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float M0 = acc[0 + j][fb][rr], M1 = acc[4 + j][fb][rr], M2 = acc[8 + j][fb][rr], M3 = acc[12 + j][fb][rr];
+                tmp[0][j] = (M0 + M1) + M2;
+                tmp[1][j] = M1 - (M2 + M3);
+            }
+            if (m < p.M && t_ok_e) {
+                const float bv = p.bias[m];
+                float y[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    y[i][0] = ((tmp[i][0] + tmp[i][1]) + tmp[i][2]) + bv;
+                    y[i][1] = ((tmp[i][1] - tmp[i][2]) - tmp[i][3]) + bv;
+                    if (p.act == YL_LEAKY) {
+                        y[i][0] = (y[i][0] > 0.f) ? y[i][0] : (float)(.1 * (double)y[i][0]);
+                        y[i][1] = (y[i][1] > 0.f) ? y[i][1] : (float)(.1 * (double)y[i][1]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (i == 1 && !row1) break;
+                    const unsigned o = obase + (unsigned)(16 * fb + rr) * HW4 + (unsigned)i * W4;
+                    if (vec2) {
+                        if (p.out) *reinterpret_cast<float2 *>(outb + o) = make_float2(y[i][0], y[i][1]);
+                        if (p.add) {
+                            float2 a;
+                            if constexpr (APF) a = make_float2(apf[rr][i][0], apf[rr][i][1]);
+                            else a = *reinterpret_cast<const float2 *>(addb + o);
+                            *reinterpret_cast<float2 *>(oaddb + o) =
+                                make_float2(__fadd_rn(y[i][0], a.x), __fadd_rn(y[i][1], a.y));
+                        }
+                    } else {
+                        if (p.out) {
+                            *reinterpret_cast<float *>(outb + o) = y[i][0];
+                            if (col1) *reinterpret_cast<float *>(outb + o + 4u) = y[i][1];
+                        }
+                        if (p.add) {
+                            *reinterpret_cast<float *>(oaddb + o) =
+                                __fadd_rn(y[i][0], APF ? apf[rr][i][0] : *reinterpret_cast<const float *>(addb + o));
+                            if (col1)
+                                *reinterpret_cast<float *>(oaddb + o + 4u) =
+                                    __fadd_rn(y[i][1], APF ? apf[rr][i][1] : *reinterpret_cast<const float *>(addb + o + 4u));
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // APF: the fused [shortcut] operand of a filter block is requested before that block's output transform
 template <bool APF>
 __global__ __launch_bounds__(256, 2) void conv_f32_wino16_kernel(ConvWino16Dev p)
@@ -297,104 +405,204 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino16_kernel(ConvWino16Dev p
 #undef Y_LOAD_U
 #undef Y_LOAD_X
 
-    // ---- epilogue: Y = A^T M A on the lane's own registers, + bias, leaky, fused [shortcut]; no LDS, no barrier ----
-    const int tg_e = t0 + wave * 16 + l15;
-    const bool t_ok_e = tg_e < p.T;
-    const int b_e = t_ok_e ? tg_e / p.tpi : 0;
-    const int r_e = tg_e - b_e * p.tpi;
-    const int ti_e = r_e / p.tw;
-    const int tj_e = r_e - ti_e * p.tw;
-    const int oy = 2 * ti_e, ox = 2 * tj_e;
-    const bool row1 = oy + 1 < p.H;
-    const bool col1 = ox + 1 < p.W;
-    const bool vec2 = col1 && ((p.W & 1) == 0);
-    const unsigned HW4 = (unsigned)HW * 4u;
-    const unsigned W4 = (unsigned)p.W * 4u;
-    // byte offset of (b_e, m0 + 4 * lk, oy, ox): 32-bit (the launcher keeps Winograd to tensors below 4 GB)
-    const unsigned obase = ((((unsigned)b_e * (unsigned)p.M + (unsigned)(m0 + 4 * lk)) * (unsigned)p.H + (unsigned)oy) *
-                            (unsigned)p.W + (unsigned)ox) * 4u;
-    const char *addb = reinterpret_cast<const char *>(p.add);
-    char *outb = reinterpret_cast<char *>(p.out);
-    char *oaddb = reinterpret_cast<char *>(p.out_add);
+    wino16_epilogue<APF>(p, acc, wave, lane, m0, t0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K1w, warp-specialised form (round 3).  Same tile, same packing, same arithmetic in the same order as the kernel
+// above (bit-identical results) -- what changes is WHO does what:
+//
+//   waves 0-3  "matrix" waves, one per SIMD: nothing but ds_read_b128 fragments + 32 MFMAs per panel + the epilogue
+//   waves 4-7  "staging" waves, one per SIMD: patch loads, fix-up, B^T d B, LDS stores of panel kb+2, U loads/stores
+//
+// Why (same-box ablation of the round-2 kernel, profiles/r3_wino_ablation.txt): with loads, transform and LDS stores
+// compiled out the kernel runs 0.78 ms on the [512,2304,1444] layer against 1.13 ms with them -- the staging work,
+// issued by the SAME waves between their MFMAs, costs 30 % of the time; barriers 1-2 %; a second workgroup per CU
+// adds only 17 % over a single one.  An in-order wave that stalls on a patch load or an LDS store cannot issue its
+// next MFMA; a wave that issues nothing but MFMAs and fragment reads never stalls, and the VALU / VMEM / LDS-store
+// work of a different wave co-issues beside it (separate pipes).  One workgroup of 8 waves per CU; LDS is a ring of
+// THREE 24 KB stages so that one barrier per panel is enough and no LDS latency is ever in front of an MFMA:
+//
+//   staging, iteration j:  registers (panel j+2) -> transform -> stage (j+2)%3 ; panel j+3 -> registers ; barrier j
+//   matrix,  iteration j:  planes 0-7 of panel j (fragments fetched during j-1) while fetching planes 8-15 of panel j;
+//                          planes 8-15 while fetching planes 0-7 of panel j+1 (published by barrier j-1) ; barrier j
+//   stage (j+2)%3 last held panel j-1, whose last fragment reads were issued before barrier j-1.
+//
+// A global load issued in iteration j is consumed in iteration j+1: a whole panel (>= 1024 cycles) of latency budget.
+template <bool APF>
+__global__ __launch_bounds__(512) void conv_f32_wino16ws_kernel(ConvWino16Dev p)
+{
+    constexpr int STAGE = YPA + YPB;                                            // 6144 floats = 24 KB
+    __shared__ __attribute__((aligned(16))) float smem[3 * STAGE];              // 72 KB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15;
+    const int lk = lane >> 4;
+
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    constexpr int GT = 8;
+    const int per_group = GT * p.tiles_m;
+    const int tg = logical / per_group;
+    const int rem_g = logical - tg * per_group;
+    const int t_in_last = p.tiles_t - tg * GT;
+    const int gsz = t_in_last < GT ? t_in_last : GT;
+    const int tile_m = __builtin_amdgcn_readfirstlane(rem_g / gsz);
+    const int tile_t = __builtin_amdgcn_readfirstlane(tg * GT + (rem_g - tile_m * gsz));
+    const int m0 = tile_m * YBM;
+    const int t0 = tile_t * YBT;
+    const int nkb = p.nkb;
+
+    if (wave >= 4) {
+        // ================================================================== staging waves
+        const int ch = wave - 4;                       // channel of every panel this wave stages
+        const int HW = p.H * p.W;
+        const int CHW = p.C * HW;
+        const int t_s = lane;
+        const int tg_s = t0 + t_s;
+        const bool t_ok = tg_s < p.T;
+        const int b_s = t_ok ? tg_s / p.tpi : 0;
+        const int r_s = tg_s - b_s * p.tpi;
+        const int ti_s = r_s / p.tw;
+        const int tj_s = r_s - ti_s * p.tw;
+        const int b_first = __builtin_amdgcn_readfirstlane(t0 / p.tpi);
+        const float *tile_base = p.in + (size_t)b_first * CHW - (ptrdiff_t)(p.W + 1);
+        size_t rec = ((size_t)p.B - b_first) * CHW * sizeof(float) + (size_t)(p.W + 1) * sizeof(float);
+        if (rec > 0xFFFFFFFEull) rec = 0xFFFFFFFEull;
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc((void *)tile_base, 0, (int)(unsigned)rec, 0x00020000);
+        int pvr[4];
+        const bool left_s = (tj_s == 0);
+        const bool inv2_s = (2 * tj_s + 1 >= p.W);
+        const bool inv3_s = (2 * tj_s + 2 >= p.W);
+        {
+            const unsigned base = ((unsigned)(b_s - b_first) * (unsigned)CHW + (unsigned)(2 * ti_s) * (unsigned)p.W +
+                                   (unsigned)(2 * tj_s) + (left_s ? 1u : 0u)) * 4u;
 #pragma unroll
-    for (int fb = 0; fb < 2; ++fb) {
-        float apf[4][2][2];
-        if constexpr (APF) {
-            if (p.add) {
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) apf[rr][i][0] = apf[rr][i][1] = 0.f;
-                    if (m0 + 16 * fb + 4 * lk + rr < p.M && t_ok_e) {
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            if (i == 1 && !row1) break;
-                            const unsigned o = obase + (unsigned)(16 * fb + rr) * HW4 + (unsigned)i * W4;
-                            if (vec2) {
-                                const float2 a = *reinterpret_cast<const float2 *>(addb + o);
-                                apf[rr][i][0] = a.x; apf[rr][i][1] = a.y;
-                            } else {
-                                apf[rr][i][0] = *reinterpret_cast<const float *>(addb + o);
-                                if (col1) apf[rr][i][1] = *reinterpret_cast<const float *>(addb + o + 4u);
-                            }
-                        }
-                    }
-                }
+            for (int rr = 0; rr < 4; ++rr) {
+                const int iy = 2 * ti_s - 1 + rr;
+                const bool ok = t_ok && iy >= 0 && iy < p.H;
+                pvr[rr] = ok ? (int)(base + (unsigned)(rr * p.W) * 4u) : -1;      // halo rows: range check -> 0.0
             }
         }
+        const float *u_tile = p.u + (size_t)tile_m * nkb * YPA;
+        const int stid = tid - 256;                    // 0..255 within the staging half
+        float xr[16];
+        float ur[2][4];
+        auto load_panel = [&](int kb) {
+            const int s0 = (kb * YBK + ch) * HW * 4;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int m = m0 + 16 * fb + 4 * lk + rr;
-            // rows of A^T M: tmp0 = (M0 + M1) + M2, tmp1 = M1 - (M2 + M3)   (same association as conv_f32_wino32.hip)
-            float tmp[2][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float M0 = acc[0 + j][fb][rr], M1 = acc[4 + j][fb][rr], M2 = acc[8 + j][fb][rr], M3 = acc[12 + j][fb][rr];
-                tmp[0][j] = (M0 + M1) + M2;
-                tmp[1][j] = M1 - (M2 + M3);
+            for (int rr = 0; rr < 4; ++rr) {
+                const u32x4v q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, pvr[rr], s0, 0);
+                xr[rr * 4 + 0] = __uint_as_float(q0[0]); xr[rr * 4 + 1] = __uint_as_float(q0[1]);
+                xr[rr * 4 + 2] = __uint_as_float(q0[2]); xr[rr * 4 + 3] = __uint_as_float(q0[3]);
             }
-            if (m < p.M && t_ok_e) {
-                const float bv = p.bias[m];
-                float y[2][2];
+            const float4 *src = reinterpret_cast<const float4 *>(u_tile + (size_t)kb * YPA);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    y[i][0] = ((tmp[i][0] + tmp[i][1]) + tmp[i][2]) + bv;
-                    y[i][1] = ((tmp[i][1] - tmp[i][2]) - tmp[i][3]) + bv;
-                    if (p.act == YL_LEAKY) {
-                        y[i][0] = (y[i][0] > 0.f) ? y[i][0] : (float)(.1 * (double)y[i][0]);
-                        y[i][1] = (y[i][1] > 0.f) ? y[i][1] : (float)(.1 * (double)y[i][1]);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (i == 1 && !row1) break;
-                    const unsigned o = obase + (unsigned)(16 * fb + rr) * HW4 + (unsigned)i * W4;
-                    if (vec2) {
-                        if (p.out) *reinterpret_cast<float2 *>(outb + o) = make_float2(y[i][0], y[i][1]);
-                        if (p.add) {
-                            float2 a;
-                            if constexpr (APF) a = make_float2(apf[rr][i][0], apf[rr][i][1]);
-                            else a = *reinterpret_cast<const float2 *>(addb + o);
-                            *reinterpret_cast<float2 *>(oaddb + o) =
-                                make_float2(__fadd_rn(y[i][0], a.x), __fadd_rn(y[i][1], a.y));
-                        }
-                    } else {
-                        if (p.out) {
-                            *reinterpret_cast<float *>(outb + o) = y[i][0];
-                            if (col1) *reinterpret_cast<float *>(outb + o + 4u) = y[i][1];
-                        }
-                        if (p.add) {
-                            *reinterpret_cast<float *>(oaddb + o) =
-                                __fadd_rn(y[i][0], APF ? apf[rr][i][0] : *reinterpret_cast<const float *>(addb + o));
-                            if (col1)
-                                *reinterpret_cast<float *>(oaddb + o + 4u) =
-                                    __fadd_rn(y[i][1], APF ? apf[rr][i][1] : *reinterpret_cast<const float *>(addb + o + 4u));
-                        }
-                    }
-                }
+            for (int e = 0; e < 2; ++e) {
+                const float4 t4 = src[stid + e * 256];
+                ur[e][0] = t4.x; ur[e][1] = t4.y; ur[e][2] = t4.z; ur[e][3] = t4.w;
             }
+        };
+        auto store_panel = [&](int stage) {
+            float *As = smem + stage * STAGE;
+            float *Bs = As + YPA;
+            float4 *adst = reinterpret_cast<float4 *>(As);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) adst[stid + e * 256] = make_float4(ur[e][0], ur[e][1], ur[e][2], ur[e][3]);
+            float va[16];
+            fix_rows16(xr, left_s, inv2_s, inv3_s);
+            input_transform16(xr, va);
+            float *dst = Bs + (ch * 64 + t_s) * 4;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd)
+                *reinterpret_cast<float4 *>(dst + qd * 1024) = make_float4(va[4 * qd], va[4 * qd + 1], va[4 * qd + 2], va[4 * qd + 3]);
+        };
+        // prologue: panels 0, 1 -> stages 0, 1; panel 2 -> registers   (nkb = C/4 is even and >= 4)
+        load_panel(0);
+        store_panel(0);
+        load_panel(1);
+        store_panel(1);
+        load_panel(2);
+        __syncthreads();                               // barrier -1: panels 0 and 1 are published
+        int st = 2;                                    // stage of panel j + 2
+        for (int j = 0; j < nkb; ++j) {
+            if (j + 2 < nkb) store_panel(st);
+            if (j + 3 < nkb) load_panel(j + 3);
+            st = (st == 2) ? 0 : st + 1;
+            __syncthreads();                           // barrier j
         }
+        return;
     }
+
+    // ====================================================================== matrix waves
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[xi][fb][e] = 0.f;
+    float4 fa[2][4];
+    float4 fbv[2][2];
+    const int a_off = lane * 4;
+    const int b_off = YPA + (lk * 64 + wave * 16 + l15) * 4;
+#define W_READ_FRAGS(HALF, STG)                                                                    \
+    {                                                                                              \
+        const float *Ab = smem + (STG) * STAGE + (HALF) * 1024 + a_off;                            \
+        const float *Bb = smem + (STG) * STAGE + (HALF) * 2048 + b_off;                            \
+        _Pragma("unroll") for (int pp = 0; pp < 4; ++pp)                                           \
+            fa[HALF][pp] = *reinterpret_cast<const float4 *>(Ab + pp * 256);                       \
+        _Pragma("unroll") for (int qq = 0; qq < 2; ++qq)                                           \
+            fbv[HALF][qq] = *reinterpret_cast<const float4 *>(Bb + qq * 1024);                     \
+    }
+#define W_MFMAS(HALF)                                                                              \
+    _Pragma("unroll") for (int pp = 0; pp < 4; ++pp)                                               \
+        _Pragma("unroll") for (int pr = 0; pr < 2; ++pr) {                                         \
+            const int xi_ = 8 * (HALF) + 2 * pp + pr;                                              \
+            const float4 bq = fbv[HALF][pp >> 1];                                                  \
+            const int bi = 2 * (pp & 1) + pr;                                                      \
+            const float bv_ = bi == 0 ? bq.x : (bi == 1 ? bq.y : (bi == 2 ? bq.z : bq.w));         \
+            const float a0 = pr ? fa[HALF][pp].y : fa[HALF][pp].x;                                 \
+            const float a1 = pr ? fa[HALF][pp].w : fa[HALF][pp].z;                                 \
+            acc[xi_][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv_, acc[xi_][0], 0, 0, 0);     \
+            acc[xi_][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv_, acc[xi_][1], 0, 0, 0);     \
+        }
+    __syncthreads();                                   // barrier -1
+    W_READ_FRAGS(0, 0)
+    int st = 0, st1 = 1;                               // stages of panels j and j + 1
+    for (int j = 0; j < nkb; ++j) {
+        W_READ_FRAGS(1, st)                            // planes 8-15 of panel j: used by the second half below
+        W_MFMAS(0)
+#pragma unroll
+        for (int i_ = 0; i_ < 6; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // planes 0-7 of panel j+1 (published by barrier j-1).  Unconditional: behind the last panel the stage holds stale
+        // data nobody uses, and a branch here makes the compiler merge LDS wait counts across the join (it then waits
+        // for these reads in front of the MFMAs below)
+        W_READ_FRAGS(0, st1)
+        W_MFMAS(1)
+#pragma unroll
+        for (int i_ = 0; i_ < 6; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        st = st1;
+        st1 = (st1 == 2) ? 0 : st1 + 1;
+        __syncthreads();                               // barrier j
+    }
+#undef W_MFMAS
+#undef W_READ_FRAGS
+    wino16_epilogue<APF>(p, acc, wave, lane, m0, t0);
 }
 
 size_t wino16_packed_floats(int C, int M)
@@ -460,9 +668,13 @@ int launch_conv_f32_wino16(const ConvF32Args &a, const float *u_packed, int vari
     if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks), block(256);
     hipStream_t s = (hipStream_t)stream;
-    if (variant & 2) hipLaunchKernelGGL(conv_f32_wino16_kernel<true>, grid, block, 0, s, d);
+    if (variant & 64) {          // warp-specialised: 4 matrix + 4 staging waves, one workgroup per CU
+        const dim3 block8(512);
+        if (variant & 2) hipLaunchKernelGGL(conv_f32_wino16ws_kernel<true>, grid, block8, 0, s, d);
+        else hipLaunchKernelGGL(conv_f32_wino16ws_kernel<false>, grid, block8, 0, s, d);
+    } else if (variant & 2) hipLaunchKernelGGL(conv_f32_wino16_kernel<true>, grid, block, 0, s, d);
     else hipLaunchKernelGGL(conv_f32_wino16_kernel<false>, grid, block, 0, s, d);
-    if (name) snprintf(name, name_len, "conv_f32_wino<32x64t,f2x2,p16%s>", (variant & 2) ? ",apf" : "");
+    if (name) snprintf(name, name_len, "conv_f32_wino<32x64t,f2x2,p16%s%s>", (variant & 64) ? ",ws" : "", (variant & 2) ? ",apf" : "");
     return (int)hipGetLastError();
 }
 

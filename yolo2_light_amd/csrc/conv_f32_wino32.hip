@@ -44,7 +44,8 @@
 
 // X_DBG (build-time timing experiments, -DX_DBG=<bits>; results are garbage): 1 no patch loads in the
 // K loop, 2 no weight loads, 4 no transform / LDS stores, 8 no MFMAs, 16 transform without the patch
-// stores, 32 patch stores without the transform.  tools/ab_builds.sh runs such builds side by side
+// stores, 32 patch stores without the transform, 64 no barriers inside the K loop, 128 no epilogue, 256 one
+// workgroup per CU (48 KB of dead LDS more).  tools/ab_builds.sh runs such builds side by side
 // on one GPU box (DESIGN.md, K1w "what still bounds it").
 #ifndef X_DBG
 #define X_DBG 0
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
 {
     constexpr bool UDMA = (VAR & 1) != 0;
     constexpr bool APF = (VAR & 2) != 0;
-    __shared__ __attribute__((aligned(16))) float smem[2 * XPA + 2 * XPB];      // 48 KB
+    __shared__ __attribute__((aligned(16))) float smem[2 * XPA + 2 * XPB + ((X_DBG & 256) ? 12288 : 0)];      // 48 KB
     float *As = smem;
     float *Bs = smem + 2 * XPA;
 
@@ -448,11 +449,13 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         if (UDMA && DO_STORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
-        __syncthreads();                                                                           \
+        if (!(X_DBG & 64)) __syncthreads();                                                        \
         if (DO_STORE) X_READ_FRAGS((SET) ^ 1, buf ^ 1)                                             \
+        /* the DMA is issued BEFORE the patch loads: vmcnt retires in order, so waiting for patch row r   */ \
+        /* (vmcnt(3 - r)) covers the older DMAs and the rows are still consumed one by one                */ \
+        if (DO_LOAD && UDMA && !(X_DBG & 2)) X_DMA_U((KB) + 2, buf)                                \
         if (DO_LOAD && !(X_DBG & 1)) X_LOAD_X((KB) + 2, xr)                                        \
         if (DO_LOAD && !UDMA && !(X_DBG & 2)) X_LOAD_U((KB) + 2, ur)                               \
-        if (DO_LOAD && UDMA && !(X_DBG & 2)) X_DMA_U((KB) + 2, buf)                                \
         _Pragma("unroll") for (int pp = 0; pp < 8; ++pp)                                           \
             if (!(X_DBG & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][pp].y, fb[SET][pp][1], acc[pp], 0, 0, 0); \
         if (DO_STORE && X_DBG == 0) {                                                              \
@@ -484,6 +487,15 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     // The plane half `ph` is wave-uniform: branch once so that every accumulator index below is a compile-time
     // constant (with a runtime `ph` the compiler indexed the 128 accumulator registers dynamically: 72
     // s_set_gpr_idx pairs and 330 v_mov per wave).
+    if (X_DBG & 128) {          // timing experiment: keep the accumulators alive, store almost nothing
+        float s = 0.f;
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s += acc[pp][e];
+        if (s == 12345.678f && p.out) p.out[0] = s;
+        return;
+    }
     if (ph) wino32_epilogue<1, APF>(p, acc, smem, wave, lane, m0, t0);
     else wino32_epilogue<0, APF>(p, acc, smem, wave, lane, m0, t0);
 }

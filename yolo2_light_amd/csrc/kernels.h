@@ -39,7 +39,8 @@ struct ConvF32Opts {
     // kernel loads the B panel as float4 rows, bit 3 LDS-free small-K kernel for the first layer (C*size^2 <= 32),
     // bit 4 Winograd from 32 input channels up (default: from 64), bit 5 (read when the weights are uploaded) the
     // Winograd kernel that keeps all 16 planes of a block in one wave (conv_f32_wino16.hip) instead of round 2's
-    // plane-split kernel.  (An 8-byte-access epilogue for odd map widths was measured and dropped: no gain,
+    // plane-split kernel, bit 6 (with bit 5) its warp-specialised form: 4 matrix + 4 staging waves, one workgroup
+    // per CU.  (An 8-byte-access epilogue for odd map widths was measured and dropped: no gain,
     // profiles/r2_ab_fp32_variants.txt.)
     int variant = YL_VARIANT_DEFAULT;
 };

@@ -84,6 +84,8 @@ static void free_device(Network &net)
         l.d_weights_t = nullptr; l.d_biases = nullptr; l.d_weights_i8 = nullptr;
         l.d_weights_bits = nullptr; l.d_mean = nullptr; l.d_debug = nullptr;
     }
+    if (net.d_pack_src) (void)hipFree(net.d_pack_src);
+    net.d_pack_src = nullptr; net.pack_src_bytes = 0;
     if (net.d_input) (void)hipFree(net.d_input);
     if (net.d_qbuf) (void)hipFree(net.d_qbuf);
     if (net.d_bitbuf) (void)hipFree(net.d_bitbuf);
@@ -124,12 +126,36 @@ static void free_device(Network &net)
 }
 
 // ------------------------------------------------------------------ upload
+// One layer's prepared weights, as they are, into the device scratch the pack kernels read (pack.hip).  The
+// previous layer's pack kernels (same stream) must have finished with the scratch first.
+static int pack_source_to_device(Network &net, const void *src, size_t bytes, const float *mean, int M)
+{
+    const size_t mean_off = (bytes + 255) & ~(size_t)255;
+    const size_t need = mean_off + (mean ? sizeof(float) * (size_t)M : 0);
+    YL_HIP(hipStreamSynchronize((hipStream_t)net.stream));
+    if (need > net.pack_src_bytes) {
+        if (net.d_pack_src) (void)hipFree(net.d_pack_src);
+        net.d_pack_src = nullptr; net.pack_src_bytes = 0;
+        YL_HIP(hipMalloc((void **)&net.d_pack_src, need + need / 4));
+        net.pack_src_bytes = need + need / 4;
+    }
+    YL_STAGE(stage_h2d(net.device, net.d_pack_src, src, bytes));
+    if (mean) YL_STAGE(stage_h2d(net.device, net.d_pack_src + mean_off, mean, sizeof(float) * (size_t)M));
+    return YL_OK;
+}
+
+// Kernel-layout weight images of one convolution.  net.device_pack (default): the prepared weights travel once and
+// pack.hip's kernels write the images; otherwise the host loops below build them (the reference implementation the
+// device packers are checked against bit for bit, tests/test_gpu_prep.py) and the inflated images are uploaded.
 static int upload_conv(Network &net, Layer &l)
 {
     const int K = l.size * l.size * l.c;
     const int M = l.n;
+    const int taps = l.size * l.size;
+    void *s = net.stream;
     YL_HIP(hipMalloc((void **)&l.d_biases, sizeof(float) * M));
     YL_STAGE(stage_h2d(net.device, l.d_biases, l.biases.data(), sizeof(float) * M));
+    for (size_t &b : l.packed_bytes) b = 0;
     if (l.conv_mode == CONV_F32) {
         // xnor conv outside the 3x3/stride-1/pad-1 bit path: the reference falls back to the FP32
         // GEMM on binarised operands (src/yolov2_forward_network.c:40-50,204-211): weights +-mean
@@ -147,37 +173,52 @@ static int upload_conv(Network &net, Layer &l)
         l.Kpad = round_up(K, 32);
         l.Mpad = round_up(M, 256);
         l.tapmajor = (l.size > 1 && l.size <= 5 && (l.c % 16) == 0) ? 1 : 0;
-        const int taps = l.size * l.size;
-        std::vector<float> wt((size_t)l.Kpad * l.Mpad, 0.f);
-        for (int m = 0; m < M; ++m)
-            for (int c = 0; c < l.c; ++c)
-                for (int t = 0; t < taps; ++t) {
-                    const int k_ref = c * taps + t;
-                    // tap-major inside 16-channel blocks: k = ((c/16)*taps + t)*16 + c%16
-                    const int k_dev = l.tapmajor ? (((c / 16) * taps + t) * 16 + (c % 16)) : k_ref;
-                    float wv = l.weights[(size_t)m * K + k_ref];
-                    if (xnor_fallback) wv = (wv > 0.f) ? l.mean_arr[m] : -l.mean_arr[m];
-                    wt[(size_t)k_dev * l.Mpad + m] = wv;
-                }
-        YL_HIP(hipMalloc((void **)&l.d_weights_t, wt.size() * sizeof(float)));
-        YL_STAGE(stage_h2d(net.device, l.d_weights_t, wt.data(), wt.size() * sizeof(float)));
         // 3x3 / stride 1 / pad 1: also the Winograd F(2x2,3x3) form of the same weights (K1w).
         // Not for the xnor fallback: its +-mean weights would pick up G's halves and the layer is
         // specified by the reference as an exact +-1 GEMM.
-        if (net.conv_opts.winograd && !xnor_fallback && wino_applicable(l.c, M, l.size, l.stride, l.pad) &&
-            l.out_h == l.h && l.out_w == l.w && l.h >= 4 && l.w >= 4) {
-            l.wino_tiling = (net.conv_opts.variant & 32) ? 16 : 32;
-            std::vector<float> u32(l.wino_tiling == 16 ? wino16_packed_floats(l.c, M) : wino32_packed_floats(l.c, M));
-            if (l.wino_tiling == 16) wino16_pack_weights(l.weights.data(), l.c, M, u32.data());
-            else wino32_pack_weights(l.weights.data(), l.c, M, u32.data());
-            YL_HIP(hipMalloc((void **)&l.d_wino32_u, u32.size() * sizeof(float)));
-            YL_STAGE(stage_h2d(net.device, l.d_wino32_u, u32.data(), u32.size() * sizeof(float)));
+        const bool wino = net.conv_opts.winograd && !xnor_fallback && wino_applicable(l.c, M, l.size, l.stride, l.pad) &&
+                          l.out_h == l.h && l.out_w == l.w && l.h >= 4 && l.w >= 4;
+        l.wino_tiling = (net.conv_opts.variant & 32) ? 16 : 32;
+        const size_t wt_floats = (size_t)l.Kpad * l.Mpad;
+        const size_t u_floats = !wino ? 0 : (l.wino_tiling == 16 ? wino16_packed_floats(l.c, M) : wino32_packed_floats(l.c, M));
+        YL_HIP(hipMalloc((void **)&l.d_weights_t, wt_floats * sizeof(float)));
+        l.packed_bytes[0] = wt_floats * sizeof(float);
+        if (wino) {
+            YL_HIP(hipMalloc((void **)&l.d_wino32_u, u_floats * sizeof(float)));
+            l.packed_bytes[1] = u_floats * sizeof(float);
+        }
+        if (net.device_pack) {
+            int rc = pack_source_to_device(net, l.weights.data(), sizeof(float) * (size_t)M * K, xnor_fallback ? l.mean_arr.data() : nullptr, M);
+            if (rc != YL_OK) return rc;
+            const float *d_src = reinterpret_cast<const float *>(net.d_pack_src);
+            const float *d_mean = xnor_fallback ? reinterpret_cast<const float *>(net.d_pack_src + ((sizeof(float) * (size_t)M * K + 255) & ~(size_t)255)) : nullptr;
+            YL_HIP(hipMemsetAsync(l.d_weights_t, 0, wt_floats * sizeof(float), (hipStream_t)s));
+            YL_LAUNCH(dev_pack_kmajor(d_src, d_mean, l.d_weights_t, M, l.c, taps, l.Mpad, l.tapmajor, s), "pack_kmajor");
+            if (wino) YL_LAUNCH(dev_pack_wino(d_src, l.d_wino32_u, l.c, M, l.wino_tiling, s), "pack_wino");
+        } else {
+            std::vector<float> wt(wt_floats, 0.f);
+            for (int m = 0; m < M; ++m)
+                for (int c = 0; c < l.c; ++c)
+                    for (int t = 0; t < taps; ++t) {
+                        const int k_ref = c * taps + t;
+                        // tap-major inside 16-channel blocks: k = ((c/16)*taps + t)*16 + c%16
+                        const int k_dev = l.tapmajor ? (((c / 16) * taps + t) * 16 + (c % 16)) : k_ref;
+                        float wv = l.weights[(size_t)m * K + k_ref];
+                        if (xnor_fallback) wv = (wv > 0.f) ? l.mean_arr[m] : -l.mean_arr[m];
+                        wt[(size_t)k_dev * l.Mpad + m] = wv;
+                    }
+            YL_STAGE(stage_h2d(net.device, l.d_weights_t, wt.data(), wt.size() * sizeof(float)));
+            if (wino) {
+                std::vector<float> u32(u_floats);
+                if (l.wino_tiling == 16) wino16_pack_weights(l.weights.data(), l.c, M, u32.data());
+                else wino32_pack_weights(l.weights.data(), l.c, M, u32.data());
+                YL_STAGE(stage_h2d(net.device, l.d_wino32_u, u32.data(), u32.size() * sizeof(float)));
+            }
         }
     } else if (l.conv_mode == CONV_INT8) {
         if (!l.quant_ready) { set_error("INT8 layer without yl_network_quantize()"); return YL_ERR_STATE; }
         // k-major panels of 16-byte units [K16pad][Mpad][16], K16 index = tap*G + cg, zero padded;
         // G = channel groups of 16 rounded up to a power of two (shift/mask decode in the kernel)
-        const int taps = l.size * l.size;
         if (l.size > 5) { set_error("INT8 conv: size > 5 unsupported"); return YL_ERR_UNSUPPORTED; }
         int G = 1;
         while (G * 16 < l.c) G *= 2;
@@ -185,15 +226,24 @@ static int upload_conv(Network &net, Layer &l)
         l.Mpad = round_up(M, 128);
         const int K16 = taps * G;
         const int K16pad = round_up(K16, 8);
-        std::vector<int8_t> wq((size_t)K16pad * l.Mpad * 16, 0);
-        for (int m = 0; m < M; ++m)
-            for (int c = 0; c < l.c; ++c)
-                for (int t = 0; t < taps; ++t) {
-                    const int g = t * G + c / 16;
-                    wq[((size_t)g * l.Mpad + m) * 16 + (c % 16)] = l.weights_int8[((size_t)m * l.c + c) * taps + t];
-                }
-        YL_HIP(hipMalloc((void **)&l.d_weights_i8, wq.size()));
-        YL_STAGE(stage_h2d(net.device, l.d_weights_i8, wq.data(), wq.size()));
+        const size_t bytes = (size_t)K16pad * l.Mpad * 16;
+        YL_HIP(hipMalloc((void **)&l.d_weights_i8, bytes));
+        l.packed_bytes[2] = bytes;
+        if (net.device_pack) {
+            int rc = pack_source_to_device(net, l.weights_int8.data(), (size_t)M * K, nullptr, M);
+            if (rc != YL_OK) return rc;
+            YL_HIP(hipMemsetAsync(l.d_weights_i8, 0, bytes, (hipStream_t)s));
+            YL_LAUNCH(dev_pack_i8_units(reinterpret_cast<const int8_t *>(net.d_pack_src), l.d_weights_i8, M, l.c, taps, G, l.Mpad, s), "pack_i8_units");
+        } else {
+            std::vector<int8_t> wq(bytes, 0);
+            for (int m = 0; m < M; ++m)
+                for (int c = 0; c < l.c; ++c)
+                    for (int t = 0; t < taps; ++t) {
+                        const int g = t * G + c / 16;
+                        wq[((size_t)g * l.Mpad + m) * 16 + (c % 16)] = l.weights_int8[((size_t)m * l.c + c) * taps + t];
+                    }
+            YL_STAGE(stage_h2d(net.device, l.d_weights_i8, wq.data(), wq.size()));
+        }
         const size_t qb = (size_t)net.batch * l.h * l.w * l.Cpad;
         if (qb > net.qbuf_bytes) net.qbuf_bytes = qb;
         l.bias_abs_max = 0.f; l.bias_abs_min_nz = 3.0e38f;
@@ -205,22 +255,31 @@ static int upload_conv(Network &net, Layer &l)
         }
     } else if (l.conv_mode == CONV_BF16) {
         // the INT8 layout with 8 bf16 channels per 16-byte unit: [K8pad][Mpad][8], K8 index = tap*G + cg
-        const int taps = l.size * l.size;
         int G = 1;
         while (G * 8 < l.c) G *= 2;
         l.Cpad = G * 8;
         l.Mpad = round_up(M, 128);
         const int K8 = taps * G;
         const int K8pad = round_up(K8, 8);
-        std::vector<uint16_t> wh((size_t)K8pad * l.Mpad * 8, 0);
-        for (int m = 0; m < M; ++m)
-            for (int c = 0; c < l.c; ++c)
-                for (int t = 0; t < taps; ++t) {
-                    const int g = t * G + c / 8;
-                    wh[((size_t)g * l.Mpad + m) * 8 + (c % 8)] = f32_to_bf16_rne(l.weights[((size_t)m * l.c + c) * taps + t]);
-                }
-        YL_HIP(hipMalloc((void **)&l.d_weights_i8, wh.size() * sizeof(uint16_t)));
-        YL_STAGE(stage_h2d(net.device, l.d_weights_i8, wh.data(), wh.size() * sizeof(uint16_t)));
+        const size_t elems = (size_t)K8pad * l.Mpad * 8;
+        YL_HIP(hipMalloc((void **)&l.d_weights_i8, elems * sizeof(uint16_t)));
+        l.packed_bytes[2] = elems * sizeof(uint16_t);
+        if (net.device_pack) {
+            int rc = pack_source_to_device(net, l.weights.data(), sizeof(float) * (size_t)M * K, nullptr, M);
+            if (rc != YL_OK) return rc;
+            YL_HIP(hipMemsetAsync(l.d_weights_i8, 0, elems * sizeof(uint16_t), (hipStream_t)s));
+            YL_LAUNCH(dev_pack_bf16_units(reinterpret_cast<const float *>(net.d_pack_src), reinterpret_cast<uint16_t *>(l.d_weights_i8),
+                                          M, l.c, taps, G, l.Mpad, s), "pack_bf16_units");
+        } else {
+            std::vector<uint16_t> wh(elems, 0);
+            for (int m = 0; m < M; ++m)
+                for (int c = 0; c < l.c; ++c)
+                    for (int t = 0; t < taps; ++t) {
+                        const int g = t * G + c / 8;
+                        wh[((size_t)g * l.Mpad + m) * 8 + (c % 8)] = f32_to_bf16_rne(l.weights[((size_t)m * l.c + c) * taps + t]);
+                    }
+            YL_STAGE(stage_h2d(net.device, l.d_weights_i8, wh.data(), wh.size() * sizeof(uint16_t)));
+        }
         const size_t qb = (size_t)net.batch * l.h * l.w * l.Cpad * 2;
         if (qb > net.qbuf_bytes) net.qbuf_bytes = qb;
     } else {   // CONV_XNOR
@@ -229,20 +288,29 @@ static int upload_conv(Network &net, Layer &l)
         // channel-pad bits are 1 in the weights and 0 in the activations so they never match.
         l.Cw = (l.c + 63) / 64;
         l.Mpad = round_up(M, 64);
-        std::vector<uint64_t> wb((size_t)l.Mpad * l.Cw * 9 + 18, ~0ull);       // + one step: the kernel's last prefetch
-        for (int m = 0; m < M; ++m)
-            for (int t = 0; t < 9; ++t)
-                for (int cw = 0; cw < l.Cw; ++cw) {
-                    uint64_t word = 0;
-                    for (int b = 0; b < 64; ++b) {
-                        const int c = cw * 64 + b;
-                        const bool bit = (c < l.c) ? (l.weights[((size_t)m * l.c + c) * 9 + t] > 0.f) : true;
-                        if (bit) word |= (1ull << b);
+        const size_t words = (size_t)l.Mpad * l.Cw * 9 + 18;       // + one step: the kernel's last prefetch
+        YL_HIP(hipMalloc((void **)&l.d_weights_bits, words * sizeof(uint64_t)));
+        l.packed_bytes[3] = words * sizeof(uint64_t);
+        if (net.device_pack) {
+            int rc = pack_source_to_device(net, l.weights.data(), sizeof(float) * (size_t)M * K, nullptr, M);
+            if (rc != YL_OK) return rc;
+            YL_HIP(hipMemsetAsync(l.d_weights_bits, 0xFF, words * sizeof(uint64_t), (hipStream_t)s));
+            YL_LAUNCH(dev_pack_xnor_words(reinterpret_cast<const float *>(net.d_pack_src), l.d_weights_bits, M, l.c, l.Cw, s), "pack_xnor_words");
+        } else {
+            std::vector<uint64_t> wb(words, ~0ull);
+            for (int m = 0; m < M; ++m)
+                for (int t = 0; t < 9; ++t)
+                    for (int cw = 0; cw < l.Cw; ++cw) {
+                        uint64_t word = 0;
+                        for (int b = 0; b < 64; ++b) {
+                            const int c = cw * 64 + b;
+                            const bool bit = (c < l.c) ? (l.weights[((size_t)m * l.c + c) * 9 + t] > 0.f) : true;
+                            if (bit) word |= (1ull << b);
+                        }
+                        wb[((size_t)(m / 2) * l.Cw + cw) * 18 + (m % 2) * 9 + t] = word;
                     }
-                    wb[((size_t)(m / 2) * l.Cw + cw) * 18 + (m % 2) * 9 + t] = word;
-                }
-        YL_HIP(hipMalloc((void **)&l.d_weights_bits, wb.size() * sizeof(uint64_t)));
-        YL_STAGE(stage_h2d(net.device, l.d_weights_bits, wb.data(), wb.size() * sizeof(uint64_t)));
+            YL_STAGE(stage_h2d(net.device, l.d_weights_bits, wb.data(), wb.size() * sizeof(uint64_t)));
+        }
         YL_HIP(hipMalloc((void **)&l.d_mean, sizeof(float) * M));
         YL_STAGE(stage_h2d(net.device, l.d_mean, l.mean_arr.data(), sizeof(float) * M));
         size_t bb = (size_t)net.batch * l.h * l.w * l.Cw * sizeof(uint64_t);
@@ -484,6 +552,10 @@ static int to_device(Network &net, int device)
             }
         }
     }
+    // the pack kernels are done with the scratch once the stream is idle
+    YL_HIP(hipStreamSynchronize((hipStream_t)net.stream));
+    if (net.d_pack_src) (void)hipFree(net.d_pack_src);
+    net.d_pack_src = nullptr; net.pack_src_bytes = 0;
     hipEvent_t e0, e1;
     YL_HIP(hipEventCreate(&e0));
     YL_HIP(hipEventCreate(&e1));
@@ -1386,6 +1458,29 @@ int yl_network_set_winograd(yl_network *net, int on)
     if (net->net.on_device) { set_error("set_winograd must precede to_device"); return YL_ERR_STATE; }
     net->net.conv_opts.winograd = on != 0;
     return YL_OK;
+}
+
+int yl_network_set_device_pack(yl_network *net, int on)
+{
+    if (!net) { set_error("null argument"); return YL_ERR_ARG; }
+    if (net->net.on_device) { set_error("set_device_pack must precede to_device"); return YL_ERR_STATE; }
+    net->net.device_pack = on != 0;
+    return YL_OK;
+}
+
+long long yl_debug_layer_packed(yl_network *net, int i, int which, void *dst_host, long long dst_bytes)
+{
+    YL_LAYER_OR(YL_ERR_ARG)
+    if (!net->net.on_device || which < 0 || which > 3) { set_error("bad argument / not on device"); return YL_ERR_STATE; }
+    const void *src = which == 0 ? (const void *)l.d_weights_t : which == 1 ? (const void *)l.d_wino32_u
+                    : which == 2 ? (const void *)l.d_weights_i8 : (const void *)l.d_weights_bits;
+    const long long need = src ? (long long)l.packed_bytes[which] : 0;
+    if (!dst_host || need == 0) return need;
+    if (dst_bytes < need) { set_error("dst too small"); return YL_ERR_ARG; }
+    YL_HIP(hipSetDevice(net->net.device));
+    YL_HIP(hipStreamSynchronize((hipStream_t)net->net.stream));
+    YL_STAGE(stage_d2h(net->net.device, dst_host, src, (size_t)need));
+    return need;
 }
 
 int yl_network_set_nms_mode(yl_network *net, int mode)

@@ -60,6 +60,7 @@ struct Layer {
     int   tapmajor = 0;                  // K order of d_weights_t (see conv_f32_mfma.hip)
     float *d_wino32_u = nullptr;         // FP32 3x3/1/1: Winograd-packed U (conv_f32_wino16.hip / _wino32.hip), else nullptr
     int   wino_tiling = 32;              // which of the two packings d_wino32_u holds
+    size_t packed_bytes[4] = {0, 0, 0, 0};   // bytes of d_weights_t, d_wino32_u, d_weights_i8, d_weights_bits (yl_debug_layer_packed)
     int8_t *d_weights_i8 = nullptr;      // INT8: [K16pad][Mpad][16] int8 units; BF16: [K8pad][Mpad][8] bf16 units
     int   Cpad = 0;                      // channels of the 16-byte-unit activation tensor (INT8: 16 per unit, BF16: 8)
     float bias_abs_max = 0.f;            // INT8: max |bias| and the smallest non-zero |bias| (-1 = a bias is not finite):
@@ -120,6 +121,9 @@ struct Network {
     size_t bitbuf_bytes = 0;
     float *d_binbuf = nullptr;           // XNOR FP32 fallback: +-1 image scratch
     size_t binbuf_bytes = 0;
+    bool device_pack = true;             // kernel-layout weight images are written by pack.hip's kernels (false: host loops)
+    char *d_pack_src = nullptr;          // device scratch: one layer's prepared weights as they are (+ mean_arr)
+    size_t pack_src_bytes = 0;
     void *h_pinned = nullptr;            // pinned staging for the input
     float *h_heads = nullptr;            // pinned: head / last-layer tensors (owned destinations and bounce regions)
     size_t h_heads_floats = 0;
@@ -163,6 +167,12 @@ void select_conv_modes(Network &net);
 float multiplier_from_range_counts(const int *count, int bits_length);
 // prep.hip: the same three passes on the GPU, results bit-identical to the host passes
 int prepare_on_device(Network &net, int device);
+// pack.hip: the kernel-layout packers on the device (bit-identical to the host packers; dst pre-initialised by the caller)
+int dev_pack_kmajor(const float *d_w, const float *d_mean, float *d_dst, int M, int C, int taps, int Mpad, int tapmajor, void *stream);
+int dev_pack_wino(const float *d_w, float *d_dst, int C, int M, int tiling, void *stream);
+int dev_pack_i8_units(const int8_t *d_wq, int8_t *d_dst, int M, int C, int taps, int G, int Mpad, void *stream);
+int dev_pack_bf16_units(const float *d_w, uint16_t *d_dst, int M, int C, int taps, int G, int Mpad, void *stream);
+int dev_pack_xnor_words(const float *d_w, uint64_t *d_dst, int M, int C, int Cw, void *stream);
 // host_calib.cpp
 float entropy_from_counts(const uint32_t *counts, int max_bin, float bin_width);
 }  // namespace yl

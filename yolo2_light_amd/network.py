@@ -63,7 +63,8 @@ class Network:
     @classmethod
     def load(cls, cfg_path: str, weights_path: str, batch: int = 1, quantized: int = 0,
              device: Optional[int] = None, debug: bool = False, fuse: bool = False,
-             quant_rule: int = 0, winograd: bool = True, bf16: bool = False, device_prep: bool = False) -> "Network":
+             quant_rule: int = 0, winograd: bool = True, bf16: bool = False, device_prep: bool = False,
+             variant: Optional[int] = None, device_pack: Optional[bool] = None) -> "Network":
         """The full prep sequence of test_detector_cpu (src/main.c:160-171)."""
         net = cls.from_cfg(cfg_path, batch, quantized)
         if quant_rule:
@@ -72,6 +73,10 @@ class Network:
             check(lib.yl_network_set_winograd(net._h, 0), "yl_network_set_winograd")
         if bf16:
             net.set_precision(1)
+        if variant is not None:
+            net.set_variant(variant)       # before to_device: bit 5 selects the Winograd weight packing
+        if device_pack is not None:
+            check(lib.yl_network_set_device_pack(net._h, 1 if device_pack else 0), "yl_network_set_device_pack")
         net.load_weights(weights_path)
         if device_prep:
             # the same three passes on the GPU, bit-identical results (csrc/prep.hip)
@@ -261,6 +266,19 @@ class Network:
         li = self.layer_info(i)
         out = np.empty(li["outputs"], dtype=np.float32)
         check(lib.yl_network_layer_output_image(self._h, i, image, _fp(out)), "yl_network_layer_output_image")
+        return out
+
+    def layer_packed(self, i: int, which: int) -> Optional[np.ndarray]:
+        """the packed weight image of conv layer i on the device as bytes (which: 0 k-major FP32, 1 Winograd U,
+        2 int8 / bf16 units, 3 XNOR sign words); None if the layer has none"""
+        n = lib.yl_debug_layer_packed(self._h, i, which, None, 0)
+        if n < 0:
+            raise YoloHipError("yl_debug_layer_packed failed: " + _lib.last_error())
+        if n == 0:
+            return None
+        out = np.empty(n, dtype=np.uint8)
+        if lib.yl_debug_layer_packed(self._h, i, which, out.ctypes.data_as(C.c_void_p), n) != n:
+            raise YoloHipError("yl_debug_layer_packed failed: " + _lib.last_error())
         return out
 
     def layer_materialised(self, i: int) -> bool:
