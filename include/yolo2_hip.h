@@ -298,7 +298,8 @@ int yl_network_set_conv_tile(yl_network *net, int cfg);
  * bit 2 float4 B-panel rows in the 1x1 direct kernel, bit 3 LDS-free first-layer kernel, bit 4 Winograd from 32
  * input channels up, bit 5 (takes effect at the next yl_network_to_device: it selects the weight packing) the Winograd
  * kernel with all 16 planes of a block in one wave and the output transform in registers, bit 6 (with bit 5) its
- * warp-specialised form (4 matrix waves that only issue MFMAs + 4 staging waves); -1 = built-in default */
+ * warp-specialised form (4 matrix waves that only issue MFMAs + 4 staging waves), bit 7 (at yl_network_to_device,
+ * without bit 5) the 64-filter x 64-tile 8-wave Winograd kernel for layers with >= 64 filters; -1 = built-in default */
 int yl_network_set_variant(yl_network *net, int bits);
 /* Opt-in BF16 variant of the FP32 path (north_star (a) "FP32/BF16"; BEFORE yl_network_to_device): every FP32
  * convolution whose input has whole 8-channel groups runs on v_mfma_f32_32x32x16_bf16 with both operands rounded
@@ -325,7 +326,8 @@ long long yl_debug_layer_packed(yl_network *net, int i, int which, void *dst_hos
 /* Test hook (host only, no GPU needed): the Winograd weight transform U = G g G^T of a 3x3 layer
  * (weights[m][c][3][3]) packed the way the kernel reads it.  tiling 32 (conv_f32_wino32.hip):
  * [m/32][c/4][xi 16][half 2][m 32][kk 2] with channel = panel*4 + 2*kk + half; tiling 16 (conv_f32_wino16.hip):
- * [m/32][c/4][xi/2][k 4][m%16][(m%32)/16][xi&1] with channel = panel*4 + k.
+ * [m/32][c/4][xi/2][k 4][m%16][(m%32)/16][xi&1] with channel = panel*4 + k; tiling 64 (conv_f32_wino64.hip):
+ * [m/64][c/4][xi 16][half 2][m 64][kk 2] with channel = panel*4 + 2*kk + half.
  * dst == NULL returns the number of floats needed. */
 long long yl_debug_wino_pack(const float *weights, int c, int m, int tiling, float *dst, long long dst_floats);
 

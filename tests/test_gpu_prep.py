@@ -43,8 +43,9 @@ def test_device_prep_equals_host_prep(name, width, height, quantized):
 
 
 @pytest.mark.parametrize("name,width,height,quantized,bf16,variant", [
-    ("yolov3", 64, 64, 0, False, None),            # k-major FP32 panels (both K orders) + Winograd U, all-planes packing
-    ("yolov3", 64, 64, 0, False, 30),              # ... + the round-2 Winograd packing
+    ("yolov3", 64, 64, 0, False, None),            # k-major FP32 panels (both K orders) + Winograd U, default packing
+    ("yolov3", 64, 64, 0, False, 62),              # ... + the all-planes-per-wave Winograd packing
+    ("yolov3", 64, 64, 0, False, 158),             # ... + the 64-filter Winograd packing
     ("yolov3-tiny", 96, 96, 1, False, None),       # int8 units
     ("yolov3", 64, 64, 0, True, None),             # bf16 units
     ("tiny-yolo-xnor", 96, 96, 0, False, None),    # XNOR sign words (c % 64 != 0 included)

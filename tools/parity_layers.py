@@ -63,6 +63,9 @@ def main():
         t = truth.outputs[i]
         print("head %d: fraction of elements within 1e-4 relative of the truth: " % i +
               "  ".join("%s %.5f" % (tg, float(np.mean(np.abs(runs[tg][i] - t) <= 1e-4 * np.abs(t)))) for tg in tags))
+        s = runs["ref_scalar"][i].astype(np.float64)
+        print("head %d: fraction differing from the reference scalar build by more than 1e-4 relative: " % i +
+              "  ".join("%s %.2e" % (tg, float(np.mean(np.abs(runs[tg][i] - s) > 1e-4 * np.abs(s)))) for tg in tags if tg != "ref_scalar"))
 
 
 if __name__ == "__main__":

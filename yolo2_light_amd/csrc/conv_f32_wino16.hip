@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino16_kernel(ConvWino16Dev p
 //                          planes 8-15 while fetching planes 0-7 of panel j+1 (published by barrier j-1) ; barrier j
 //   stage (j+2)%3 last held panel j-1, whose last fragment reads were issued before barrier j-1.
 //
-// A global load issued in iteration j is consumed in iteration j+1: a whole panel (>= 1024 cycles) of latency budget.
+// The staging waves keep two register sets: a load issued at the start of iteration j is consumed in iteration j+1.
 template <bool APF>
 __global__ __launch_bounds__(512) void conv_f32_wino16ws_kernel(ConvWino16Dev p)
 {
@@ -492,51 +492,69 @@ __global__ __launch_bounds__(512) void conv_f32_wino16ws_kernel(ConvWino16Dev p)
         }
         const float *u_tile = p.u + (size_t)tile_m * nkb * YPA;
         const int stid = tid - 256;                    // 0..255 within the staging half
-        float xr[16];
-        float ur[2][4];
-        auto load_panel = [&](int kb) {
-            const int s0 = (kb * YBK + ch) * HW * 4;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const u32x4v q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, pvr[rr], s0, 0);
-                xr[rr * 4 + 0] = __uint_as_float(q0[0]); xr[rr * 4 + 1] = __uint_as_float(q0[1]);
-                xr[rr * 4 + 2] = __uint_as_float(q0[2]); xr[rr * 4 + 3] = __uint_as_float(q0[3]);
-            }
-            const float4 *src = reinterpret_cast<const float4 *>(u_tile + (size_t)kb * YPA);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const float4 t4 = src[stid + e * 256];
-                ur[e][0] = t4.x; ur[e][1] = t4.y; ur[e][2] = t4.z; ur[e][3] = t4.w;
-            }
-        };
-        auto store_panel = [&](int stage) {
-            float *As = smem + stage * STAGE;
-            float *Bs = As + YPA;
-            float4 *adst = reinterpret_cast<float4 *>(As);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) adst[stid + e * 256] = make_float4(ur[e][0], ur[e][1], ur[e][2], ur[e][3]);
-            float va[16];
-            fix_rows16(xr, left_s, inv2_s, inv3_s);
-            input_transform16(xr, va);
-            float *dst = Bs + (ch * 64 + t_s) * 4;
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd)
-                *reinterpret_cast<float4 *>(dst + qd * 1024) = make_float4(va[4 * qd], va[4 * qd + 1], va[4 * qd + 2], va[4 * qd + 3]);
-        };
-        // prologue: panels 0, 1 -> stages 0, 1; panel 2 -> registers   (nkb = C/4 is even and >= 4)
-        load_panel(0);
-        store_panel(0);
-        load_panel(1);
-        store_panel(1);
-        load_panel(2);
+        // two register sets: the loads of panel j+3 are issued at the START of iteration j and consumed in iteration
+        // j+1, so a whole iteration (>= 1024 cycles of the matrix waves) hides their latency.  (First version: one
+        // set, loaded at the end of an iteration and consumed right behind the barrier -- every iteration paid a
+        // full L2 / HBM round trip and the matrix waves waited at the barrier: 0.41 of the MFMA peak.)
+        float xa[16], xb[16];
+        float ua[2][4], ub[2][4];
+#define W_LOAD(KB, XR, UR)                                                                         \
+    {                                                                                              \
+        const int s0 = ((KB) * YBK + ch) * HW * 4;                                                 \
+        _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                         \
+            const u32x4v q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, pvr[rr], s0, 0);         \
+            XR[rr * 4 + 0] = __uint_as_float(q0[0]); XR[rr * 4 + 1] = __uint_as_float(q0[1]);      \
+            XR[rr * 4 + 2] = __uint_as_float(q0[2]); XR[rr * 4 + 3] = __uint_as_float(q0[3]);      \
+        }                                                                                          \
+        const float4 *src = reinterpret_cast<const float4 *>(u_tile + (size_t)(KB) * YPA);         \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                            \
+            const float4 t4 = src[stid + e * 256];                                                 \
+            UR[e][0] = t4.x; UR[e][1] = t4.y; UR[e][2] = t4.z; UR[e][3] = t4.w;                    \
+        }                                                                                          \
+    }
+#define W_STORE(STG, XR, UR)                                                                       \
+    {                                                                                              \
+        float *As_ = smem + (STG) * STAGE;                                                         \
+        float4 *adst = reinterpret_cast<float4 *>(As_);                                            \
+        _Pragma("unroll") for (int e = 0; e < 2; ++e)                                              \
+            adst[stid + e * 256] = make_float4(UR[e][0], UR[e][1], UR[e][2], UR[e][3]);            \
+        float va[16];                                                                              \
+        fix_rows16(XR, left_s, inv2_s, inv3_s);                                                    \
+        input_transform16(XR, va);                                                                 \
+        float *dst = As_ + YPA + (ch * 64 + t_s) * 4;                                              \
+        _Pragma("unroll") for (int qd = 0; qd < 4; ++qd)                                           \
+            *reinterpret_cast<float4 *>(dst + qd * 1024) =                                         \
+                make_float4(va[4 * qd], va[4 * qd + 1], va[4 * qd + 2], va[4 * qd + 3]);           \
+    }
+        // prologue: panels 0, 1 -> stages 0, 1; panel 2 -> set A   (nkb = C/4 is even and >= 4)
+        W_LOAD(0, xa, ua)
+        W_LOAD(1, xb, ub)
+        W_STORE(0, xa, ua)
+        W_STORE(1, xb, ub)
+        W_LOAD(2, xa, ua)
         __syncthreads();                               // barrier -1: panels 0 and 1 are published
         int st = 2;                                    // stage of panel j + 2
-        for (int j = 0; j < nkb; ++j) {
-            if (j + 2 < nkb) store_panel(st);
-            if (j + 3 < nkb) load_panel(j + 3);
+        // Straight-line body, no guards: behind the last panel the loads re-read panel nkb-1 and the stores refill ring
+        // slots nobody reads any more (the slot of panel j+2 is free by construction).  A guard would put a branch join
+        // in front of every s_waitcnt and the compiler then assumes the guarded loads were NOT issued: it waits for
+        // the new loads instead of the old ones (vmcnt(1) where vmcnt(7) is meant) and the prefetch is lost.
+        const int last = nkb - 1;
+        for (int j = 0; j < nkb; j += 2) {
+            // iteration j: set A holds panel j+2
+            { const int kb_ = j + 3 < last ? j + 3 : last; W_LOAD(kb_, xb, ub) }
+            __builtin_amdgcn_sched_barrier(0);         // the loads go out FIRST (the scheduler would sink them below the stores)
+            W_STORE(st, xa, ua)
             st = (st == 2) ? 0 : st + 1;
             __syncthreads();                           // barrier j
+            // iteration j+1: set B holds panel j+3
+            { const int kb_ = j + 4 < last ? j + 4 : last; W_LOAD(kb_, xa, ua) }
+            __builtin_amdgcn_sched_barrier(0);
+            W_STORE(st, xb, ub)
+            st = (st == 2) ? 0 : st + 1;
+            __syncthreads();                           // barrier j+1
         }
+#undef W_STORE
+#undef W_LOAD
         return;
     }
 

@@ -6,7 +6,10 @@
 
 namespace yl {
 
-constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8 | 16 | 32;      // measured on MI355X, profiles/r2_ab_fp32_variants.txt: bit 1 +3.3 %, bit 2 +0.4 %, bit 3 +0.6 %, bit 4 +0.9 %, bit 0 -0.5 %
+// measured on MI355X, profiles/r2_ab_fp32_variants.txt: bit 1 +3.3 %, bit 2 +0.4 %, bit 3 +0.6 %, bit 4 +0.9 %, bit 0 -0.5 %;
+// round 3 (profiles/r3_ab_wino_kernels.txt, yolov3-608 b64 in the network): bit 5 -2.1 %, bits 5+6 -17 %, bit 7 -4.4 % --
+// the three new Winograd kernels are bit-identical alternatives, the round-2 kernel stays the default
+constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8 | 16;
 
 // ---- K1: FP32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 ----
 struct ConvF32Args {
@@ -27,7 +30,8 @@ struct ConvF32Args {
     int act;              // YL_LINEAR / YL_LEAKY
     int tapmajor;         // K order of `wt`: 0 = (c,ky,kx) like im2col_cpu, 1 = (ky,kx,c) (needs C % 16 == 0)
     const float *wino32_u; // Winograd-packed weights (wino16_/wino32_pack_weights) or nullptr: 3x3/1/1 layers only
-    int wino_tiling = 32;  // which packing wino32_u holds: 16 = all-planes-per-wave kernel (conv_f32_wino16.hip), 32 = round-2 kernel
+    int wino_tiling = 32;  // which packing wino32_u holds: 16 = all-planes-per-wave kernel (conv_f32_wino16.hip), 32 = round-2
+                           // kernel, 64 = 64-filter kernel (conv_f32_wino64.hip)
 };
 // per-network kernel-selection knobs (snapshotted in Network: two networks driven from two host
 // threads, one per GPU, share no mutable launch state)
@@ -40,7 +44,8 @@ struct ConvF32Opts {
     // bit 4 Winograd from 32 input channels up (default: from 64), bit 5 (read when the weights are uploaded) the
     // Winograd kernel that keeps all 16 planes of a block in one wave (conv_f32_wino16.hip) instead of round 2's
     // plane-split kernel, bit 6 (with bit 5) its warp-specialised form: 4 matrix + 4 staging waves, one workgroup
-    // per CU.  (An 8-byte-access epilogue for odd map widths was measured and dropped: no gain,
+    // per CU, bit 7 (read at upload, without bit 5, layers with >= 64 filters) the 64-filter x 64-tile 8-wave kernel
+    // (conv_f32_wino64.hip).  (An 8-byte-access epilogue for odd map widths was measured and dropped: no gain,
     // profiles/r2_ab_fp32_variants.txt.)
     int variant = YL_VARIANT_DEFAULT;
 };
@@ -61,6 +66,11 @@ int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, int vari
 size_t wino16_packed_floats(int C, int M);
 void wino16_pack_weights(const float *w, int C, int M, float *dst);
 int launch_conv_f32_wino16(const ConvF32Args &a, const float *u_packed, int variant, void *stream, char *name, size_t name_len);
+// K1w, 64-filter form (conv_f32_wino64.hip): 64 filters x 64 tiles per workgroup of 8 waves, one workgroup per CU:
+// half the patch loads / transforms and a third fewer global -> LDS bytes per MFMA; its own U packing
+size_t wino64_packed_floats(int C, int M);
+void wino64_pack_weights(const float *w, int C, int M, float *dst);
+int launch_conv_f32_wino64(const ConvF32Args &a, const float *u_packed, int variant, void *stream, char *name, size_t name_len);
 
 // ---- K2: INT8 path ----
 // K2a: x_q = clamp_abs((int16)(x*mult), 127), FP32 NCHW -> int8 NHWC(Cpad)   (quantized.c:554-560)

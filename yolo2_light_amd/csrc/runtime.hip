@@ -178,9 +178,10 @@ static int upload_conv(Network &net, Layer &l)
         // specified by the reference as an exact +-1 GEMM.
         const bool wino = net.conv_opts.winograd && !xnor_fallback && wino_applicable(l.c, M, l.size, l.stride, l.pad) &&
                           l.out_h == l.h && l.out_w == l.w && l.h >= 4 && l.w >= 4;
-        l.wino_tiling = (net.conv_opts.variant & 32) ? 16 : 32;
+        l.wino_tiling = (net.conv_opts.variant & 32) ? 16 : (((net.conv_opts.variant & 128) && M >= 64) ? 64 : 32);
         const size_t wt_floats = (size_t)l.Kpad * l.Mpad;
-        const size_t u_floats = !wino ? 0 : (l.wino_tiling == 16 ? wino16_packed_floats(l.c, M) : wino32_packed_floats(l.c, M));
+        const size_t u_floats = !wino ? 0 : (l.wino_tiling == 16 ? wino16_packed_floats(l.c, M)
+                                             : l.wino_tiling == 64 ? wino64_packed_floats(l.c, M) : wino32_packed_floats(l.c, M));
         YL_HIP(hipMalloc((void **)&l.d_weights_t, wt_floats * sizeof(float)));
         l.packed_bytes[0] = wt_floats * sizeof(float);
         if (wino) {
@@ -211,6 +212,7 @@ static int upload_conv(Network &net, Layer &l)
             if (wino) {
                 std::vector<float> u32(u_floats);
                 if (l.wino_tiling == 16) wino16_pack_weights(l.weights.data(), l.c, M, u32.data());
+                else if (l.wino_tiling == 64) wino64_pack_weights(l.weights.data(), l.c, M, u32.data());
                 else wino32_pack_weights(l.weights.data(), l.c, M, u32.data());
                 YL_STAGE(stage_h2d(net.device, l.d_wino32_u, u32.data(), u32.size() * sizeof(float)));
             }
@@ -1526,11 +1528,12 @@ int yl_network_layer_tree(const yl_network *net, int i, int *parent, int *group_
 
 long long yl_debug_wino_pack(const float *weights, int c, int m, int tiling, float *dst, long long dst_floats)
 {
-    if (!weights || c <= 0 || m <= 0 || c % 8 != 0 || (tiling != 32 && tiling != 16)) { set_error("bad argument"); return YL_ERR_ARG; }
-    const size_t need = tiling == 16 ? wino16_packed_floats(c, m) : wino32_packed_floats(c, m);
+    if (!weights || c <= 0 || m <= 0 || c % 8 != 0 || (tiling != 32 && tiling != 16 && tiling != 64)) { set_error("bad argument"); return YL_ERR_ARG; }
+    const size_t need = tiling == 16 ? wino16_packed_floats(c, m) : (tiling == 64 ? wino64_packed_floats(c, m) : wino32_packed_floats(c, m));
     if (!dst) return (long long)need;
     if (dst_floats < (long long)need) { set_error("dst too small"); return YL_ERR_ARG; }
     if (tiling == 16) wino16_pack_weights(weights, c, m, dst);
+    else if (tiling == 64) wino64_pack_weights(weights, c, m, dst);
     else wino32_pack_weights(weights, c, m, dst);
     return (long long)need;
 }
