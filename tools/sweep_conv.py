@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--only", default="", help="comma list of shape indices")
     ap.add_argument("--variant", type=int, default=-1, help="yl_network_set_variant bits, applied before to_device")
+    ap.add_argument("--input", default="rand", choices=["rand", "zeros", "relu"],
+                    help="input data: U(-0.3, 0.7), all zeros (DVFS probe: same instructions, less switching), or a leaky-like mix")
+    ap.add_argument("--weights", default="rand", choices=["rand", "zeros"])
     args = ap.parse_args()
     import torch
     import descs as D
@@ -51,6 +54,8 @@ def main():
         pad = size // 2
         K = Cc * size * size
         wts = rng.normal(0, np.sqrt(2.0 / K), M * K).astype(np.float32)
+        if args.weights == "zeros":
+            wts[:] = 0
         bias = rng.normal(0, 0.1, M).astype(np.float32)
         d = D.conv(B, H, H, Cc, M, size, stride, pad, D.LEAKY, wts, bias)
         net = Network.from_desc([d], B, H, H, Cc)
@@ -58,6 +63,10 @@ def main():
             net.set_variant(args.variant)
         net.to_device(0)
         x = torch.rand((B, Cc, H, H), device="cuda:0", dtype=torch.float32) - 0.3
+        if args.input == "zeros":
+            x.zero_()
+        elif args.input == "relu":
+            x = torch.where(x > 0, x, 0.1 * x)
         flops = 2.0 * M * K * d.out_h * d.out_w * B
         best = None
         for t in tiles:

@@ -102,29 +102,44 @@ __global__ __launch_bounds__(256, 3) void conv_f32_smallk_kernel(ConvSmallKDev p
     __syncthreads();
 
     const int tile0 = (logical * 4 + wave) * SK_TPW;
+    // (image, row, column) of the wave's first pixel: the only divisions; the tiles a wave walks are consecutive, so
+    // the position advances by carries (PMC on the first version: 32 VALU per MFMA, a third of them pixel decode)
+    int b0, oy0, ox0;
+    {
+        const int n0 = tile0 * (32 * TN);
+        b0 = n0 / p.OHW;
+        const int pix0 = n0 - b0 * p.OHW;
+        oy0 = pix0 / p.OW;
+        ox0 = pix0 - oy0 * p.OW;
+    }
 #pragma unroll 1
     for (int it = 0; it < SK_TPW; ++it) {
         const int tile = tile0 + it;
         if (tile >= p.ntiles) break;
         const int n_base = tile * (32 * TN);
         float bfr[TN][KSTEPS];
+        int ob_j[TN], opix_j[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n_base + j * 32 + l31;
             unsigned ntap = 0xFFFFFFFFu;
             int pixoff = 0;
+            int ox = ox0 + j * 32 + l31, oy = oy0, bimg = b0;
+            while (ox >= p.OW) { ox -= p.OW; ++oy; }
+            while (oy >= p.OH) { oy -= p.OH; ++bimg; }
+            ob_j[j] = bimg;
+            opix_j[j] = oy * p.OW + ox;
             if (n < p.Ntotal) {
-                const int bimg = n / p.OHW;
-                const int pix = n - bimg * p.OHW;
-                const int oy = pix / p.OW;
-                const int ox = pix - oy * p.OW;
                 const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+                // taps inside the image = (valid rows) x (valid columns)
+                unsigned rm = 0, cm = 0;
+                for (int k = 0; k < p.size; ++k) {
+                    if ((unsigned)(iy0 + k) < (unsigned)p.H) rm |= 1u << k;
+                    if ((unsigned)(ix0 + k) < (unsigned)p.W) cm |= 1u << k;
+                }
                 unsigned ok = 0;
                 for (int ky = 0; ky < p.size; ++ky)
-                    for (int kx = 0; kx < p.size; ++kx) {
-                        const int iy = iy0 + ky, ix = ix0 + kx;
-                        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ok |= 1u << (ky * p.size + kx);
-                    }
+                    if ((rm >> ky) & 1u) ok |= cm << (ky * p.size);
                 ntap = ~ok | 0x80000000u;
                 pixoff = (int)(((unsigned)bimg * (unsigned)CHW + (unsigned)(oy * p.stride) * (unsigned)p.W +
                                 (unsigned)(ox * p.stride)) * 4u);
@@ -163,12 +178,16 @@ __global__ __launch_bounds__(256, 3) void conv_f32_smallk_kernel(ConvSmallKDev p
                 vals[j][e] = v;
             }
         if (p.q_out && !p.out && !p.add)
-            store_q_from_cd<TN>(vals, 0, p.M, n_base, p.Ntotal, p.OHW, p.q_out, p.q_mult, p.q_G, lane);
+            store_q_from_cd<TN>(vals, 0, p.M, n_base, p.Ntotal, p.OHW, p.q_out, p.q_mult, p.q_G, lane, ob_j, opix_j);
         else if (p.q_out)
             store_rows_via_lds_q<TN>(strip, vals, 0, p.M, n_base, p.Ntotal, p.OHW, p.out, p.add, p.out_add,
                                      p.q_out, p.q_mult, p.q_G, lane);
         else
             store_rows_via_lds<TN>(strip, vals, 0, p.M, n_base, p.Ntotal, p.OHW, p.out, p.add, p.out_add, lane);
+        // next tile of this wave: 32*TN pixels further
+        ox0 += 32 * TN;
+        while (ox0 >= p.OW) { ox0 -= p.OW; ++oy0; }
+        while (oy0 >= p.OH) { oy0 -= p.OH; ++b0; }
     }
 }
 

@@ -123,6 +123,7 @@ template <int PH, bool APF>
 __device__ __forceinline__ void wino32_epilogue(const ConvWino32Dev &p, const f32x16 (&acc)[8], float *smem, int wave,
                                                 int lane, int m0, int t0)
 {
+    typedef unsigned int v2u __attribute__((ext_vector_type(2)));
     const int l31 = lane & 31;
     const int half = lane >> 5;
     const int wt = wave & 1;
@@ -136,44 +137,53 @@ __device__ __forceinline__ void wino32_epilogue(const ConvWino32Dev &p, const f3
     const int oy = 2 * ti_e, ox = 2 * tj_e;
     const bool row1 = oy + 1 < p.H;
     const bool col1 = ox + 1 < p.W;
-    const bool vec2 = col1 && ((p.W & 1) == 0);
+    const bool pairs = (p.W & 1) == 0;          // wave-uniform: even width -> col1 holds everywhere, a 2-pixel row is one 8-byte access
     const unsigned HW4 = (unsigned)(p.H * p.W) * 4u;
     const unsigned W4 = (unsigned)p.W * 4u;
-    // byte offset of (b_e, m0 + 4*half, oy, ox)
+    // byte offset of (b_e, m0 + 4*half, oy, ox); every access goes through a buffer descriptor over the whole
+    // tensor with the offset forced to 0xFFFFFFFF where the row / column / filter / tile does not exist: the range
+    // check drops those lanes, so the epilogue has no divergent branches (the first version spent ~50 mostly
+    // exec-mask instructions per filter row on them)
     const unsigned obase = ((((unsigned)b_e * (unsigned)p.M + (unsigned)(m0 + 4 * half)) * (unsigned)p.H + (unsigned)oy) *
                             (unsigned)p.W + (unsigned)ox) * 4u;
-    const char *addb = reinterpret_cast<const char *>(p.add);
-    char *outb = reinterpret_cast<char *>(p.out);
-    char *oaddb = reinterpret_cast<char *>(p.out_add);
+    const unsigned tbytes = (unsigned)((size_t)p.B * p.M * p.H * p.W * 4);
+    const float *dummy = p.bias;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc((void *)(p.out ? p.out : dummy), 0, p.out ? (int)tbytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc((void *)(p.add ? p.add : dummy), 0, p.add ? (int)tbytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_oadd = __builtin_amdgcn_make_buffer_rsrc((void *)(p.add ? p.out_add : dummy), 0, p.add ? (int)tbytes : 0, 0x00020000);
+    const bool has_out = p.out != nullptr, has_add = p.add != nullptr;
     float *mine = xch + wave * 2048 + lane;
     const float *theirs = xch + (wave ^ 2) * 2048 + lane;
 #pragma unroll
     for (int rnd = 0; rnd < 2; ++rnd) {
+        unsigned off[4][2], off1[4][2];          // row offsets of this round (first / second pixel), 0xFFFFFFFF = absent
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+            const int e = 8 * rnd + (PH ? 4 + ee : ee);
+            const int mrow = (e & 3) + 8 * (e >> 2);                  // + 4*half is in obase
+            const bool ok = t_ok_e && (m0 + mrow + 4 * half < p.M);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool rok = ok && (i == 0 || row1);
+                const unsigned o = obase + (unsigned)mrow * HW4 + (unsigned)i * W4;
+                off[ee][i] = rok ? o : 0xFFFFFFFFu;
+                off1[ee][i] = (rok && col1) ? o + 4u : 0xFFFFFFFFu;
+            }
+        }
         float apf[4][2][2];
-        if constexpr (APF) {
-            if (p.add) {
+        if (APF && has_add) {
 #pragma unroll
-                for (int ee = 0; ee < 4; ++ee) {
-                    const int e = 8 * rnd + (PH ? 4 + ee : ee);
-                    const int mrow = (e & 3) + 8 * (e >> 2);            // + 4*half is in obase
+            for (int ee = 0; ee < 4; ++ee)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) apf[ee][i][0] = apf[ee][i][1] = 0.f;
-                    if (m0 + mrow + 4 * half < p.M && t_ok_e) {
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) {
-                            if (i == 1 && !row1) break;
-                            const unsigned o = obase + (unsigned)mrow * HW4 + (unsigned)i * W4;
-                            if (vec2) {
-                                const float2 a = *reinterpret_cast<const float2 *>(addb + o);
-                                apf[ee][i][0] = a.x; apf[ee][i][1] = a.y;
-                            } else {
-                                apf[ee][i][0] = *reinterpret_cast<const float *>(addb + o);
-                                if (col1) apf[ee][i][1] = *reinterpret_cast<const float *>(addb + o + 4u);
-                            }
-                        }
+                for (int i = 0; i < 2; ++i) {
+                    if (pairs) {
+                        const v2u a = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(rs_add, (int)off[ee][i], 0, 0));
+                        apf[ee][i][0] = __uint_as_float(a[0]); apf[ee][i][1] = __uint_as_float(a[1]);
+                    } else {
+                        apf[ee][i][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_add, (int)off[ee][i], 0, 0));
+                        apf[ee][i][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_add, (int)off1[ee][i], 0, 0));
                     }
                 }
-            }
         }
         // send: PH 1 gives (M2, M2 + M3) of rows e = 8*rnd .. +3; PH 0 gives (M0 + M1, M1) of e = 8*rnd+4 .. +7
 #pragma unroll
@@ -205,43 +215,48 @@ __device__ __forceinline__ void wino32_epilogue(const ConvWino32Dev &p, const f3
                     tmp[1][j] = hi - g1;
                 }
             }
-            if (m < p.M && t_ok_e) {
-                const float bv = p.bias[m];
-                float y[2][2];
+            const float bv = p.bias[m < p.M ? m : 0];
+            float y[2][2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    y[i][0] = ((tmp[i][0] + tmp[i][1]) + tmp[i][2]) + bv;
-                    y[i][1] = ((tmp[i][1] - tmp[i][2]) - tmp[i][3]) + bv;
-                    if (p.act == YL_LEAKY) {
-                        y[i][0] = (y[i][0] > 0.f) ? y[i][0] : (float)(.1 * (double)y[i][0]);
-                        y[i][1] = (y[i][1] > 0.f) ? y[i][1] : (float)(.1 * (double)y[i][1]);
+            for (int i = 0; i < 2; ++i) {
+                y[i][0] = ((tmp[i][0] + tmp[i][1]) + tmp[i][2]) + bv;
+                y[i][1] = ((tmp[i][1] - tmp[i][2]) - tmp[i][3]) + bv;
+                if (p.act == YL_LEAKY) {
+                    y[i][0] = (y[i][0] > 0.f) ? y[i][0] : (float)(.1 * (double)y[i][0]);
+                    y[i][1] = (y[i][1] > 0.f) ? y[i][1] : (float)(.1 * (double)y[i][1]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float a0 = 0.f, a1 = 0.f;
+                if (has_add) {
+                    if (APF) { a0 = apf[ee][i][0]; a1 = apf[ee][i][1]; }
+                    else if (pairs) {
+                        const v2u a = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(rs_add, (int)off[ee][i], 0, 0));
+                        a0 = __uint_as_float(a[0]); a1 = __uint_as_float(a[1]);
+                    } else {
+                        a0 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_add, (int)off[ee][i], 0, 0));
+                        a1 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_add, (int)off1[ee][i], 0, 0));
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    if (i == 1 && !row1) break;
-                    const unsigned o = obase + (unsigned)mrow * HW4 + (unsigned)i * W4;
-                    if (vec2) {
-                        if (p.out) *reinterpret_cast<float2 *>(outb + o) = make_float2(y[i][0], y[i][1]);
-                        if (p.add) {
-                            float2 a;
-                            if constexpr (APF) a = make_float2(apf[ee][i][0], apf[ee][i][1]);
-                            else a = *reinterpret_cast<const float2 *>(addb + o);
-                            *reinterpret_cast<float2 *>(oaddb + o) =
-                                make_float2(__fadd_rn(y[i][0], a.x), __fadd_rn(y[i][1], a.y));
-                        }
-                    } else {
-                        if (p.out) {
-                            *reinterpret_cast<float *>(outb + o) = y[i][0];
-                            if (col1) *reinterpret_cast<float *>(outb + o + 4u) = y[i][1];
-                        }
-                        if (p.add) {
-                            *reinterpret_cast<float *>(oaddb + o) =
-                                __fadd_rn(y[i][0], APF ? apf[ee][i][0] : *reinterpret_cast<const float *>(addb + o));
-                            if (col1)
-                                *reinterpret_cast<float *>(oaddb + o + 4u) =
-                                    __fadd_rn(y[i][1], APF ? apf[ee][i][1] : *reinterpret_cast<const float *>(addb + o + 4u));
-                        }
+                if (pairs) {
+                    const int o2 = (int)off[ee][i];
+                    if (has_out) {
+                        v2u d; d[0] = __float_as_uint(y[i][0]); d[1] = __float_as_uint(y[i][1]);
+                        __builtin_amdgcn_raw_buffer_store_b64(d, rs_out, o2, 0, 0);
+                    }
+                    if (has_add) {
+                        v2u d; d[0] = __float_as_uint(__fadd_rn(y[i][0], a0)); d[1] = __float_as_uint(__fadd_rn(y[i][1], a1));
+                        __builtin_amdgcn_raw_buffer_store_b64(d, rs_oadd, o2, 0, 0);
+                    }
+                } else {
+                    if (has_out) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[i][0]), rs_out, (int)off[ee][i], 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y[i][1]), rs_out, (int)off1[ee][i], 0, 0);
+                    }
+                    if (has_add) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__fadd_rn(y[i][0], a0)), rs_oadd, (int)off[ee][i], 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__fadd_rn(y[i][1], a1)), rs_oadd, (int)off1[ee][i], 0, 0);
                     }
                 }
             }

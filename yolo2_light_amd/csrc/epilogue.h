@@ -100,9 +100,12 @@ __device__ __forceinline__ int quantize_input_i8(float x, float mult)
 // lanes 32-63 bytes 8-15): 512 contiguous bytes per store instruction.  Fast quantisation = trunc + clamp; the
 // `int16_t = float` wrap corner (|x*mult| >= 32768, see quantize_input_i8) is detected per block and redone.
 // Requires m_base % 32 == 0 and M % 16 == 0.
+// ob[j] / opix[j]: image and pixel of column j of this lane when the caller already knows them (no division here),
+// or nullptr
 template <int TN>
 __device__ __forceinline__ void store_q_from_cd(const float (&vals)[TN][16], int m_base, int M, int n_base, int Ntotal,
-                                                int OHW, int8_t *q_out, float q_mult, int q_G, int lane)
+                                                int OHW, int8_t *q_out, float q_mult, int q_G, int lane,
+                                                const int *ob_known = nullptr, const int *opix_known = nullptr)
 {
     const int l31 = lane & 31, half = lane >> 5;
 #pragma unroll
@@ -133,8 +136,8 @@ __device__ __forceinline__ void store_q_from_cd(const float (&vals)[TN][16], int
                 pk[g4] = w;
             }
         }
-        const int ob = n / OHW;
-        const size_t unit0 = (size_t)ob * q_G * OHW + (n - ob * OHW);
+        const int ob = ob_known ? ob_known[j] : n / OHW;
+        const size_t unit0 = (size_t)ob * q_G * OHW + (opix_known ? opix_known[j] : n - ob * OHW);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const auto sw = __builtin_amdgcn_permlane32_swap(pk[2 * u], pk[2 * u + 1], false, false);
