@@ -41,7 +41,10 @@ enum {
     YL_REGION = 21, YL_YOLO = 22, YL_UPSAMPLE = 23, YL_REORG = 24, YL_BLANK = 25
 };
 /* numeric values == reference ACTIVATION (src/additionally.h:68-70) */
-enum { YL_LOGISTIC = 0, YL_LINEAR = 3, YL_LEAKY = 7 };
+enum {
+    YL_LOGISTIC = 0, YL_RELU = 1, YL_RELIE = 2, YL_LINEAR = 3, YL_RAMP = 4, YL_TANH = 5, YL_PLSE = 6, YL_LEAKY = 7,
+    YL_ELU = 8, YL_LOGGY = 9, YL_STAIR = 10, YL_HARDTAN = 11, YL_LHTAN = 12
+};
 
 typedef struct yl_network yl_network;   /* opaque; owns host model + all device memory */
 

@@ -22,17 +22,43 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define ACT_LOGISTIC 0
-#define ACT_LINEAR 3
-#define ACT_LEAKY 7
+/* ACTIVATION  src/additionally.h:68-70 */
+enum { ACT_LOGISTIC = 0, ACT_RELU, ACT_RELIE, ACT_LINEAR, ACT_RAMP, ACT_TANH, ACT_PLSE, ACT_LEAKY, ACT_ELU, ACT_LOGGY,
+       ACT_STAIR, ACT_HARDTAN, ACT_LHTAN };
 
-/* activate()  src/additionally.h:132-165; leaky_activate :91 (.1*x in double),
- * logistic_activate :84 (1./(1.+exp(-x)) in double) */
+/* activate()  src/additionally.h:132-165 and the *_activate bodies :72-105: the same C expressions on a float
+ * argument (literals with a decimal point are doubles, exp() is the double function) */
 static float activate(float x, int a)
 {
-    if (a == ACT_LEAKY) return (x > 0) ? x : .1 * x;
-    if (a == ACT_LOGISTIC) return 1. / (1. + exp(-x));
-    return x;
+    switch (a) {
+    case ACT_LINEAR: return x;
+    case ACT_LOGISTIC: return 1. / (1. + exp(-x));
+    case ACT_LOGGY: return 2. / (1. + exp(-x)) - 1;
+    case ACT_RELU: return x * (x > 0);
+    case ACT_ELU: return (x >= 0) * x + (x < 0) * (exp(x) - 1);
+    case ACT_RELIE: return (x > 0) ? x : .01 * x;
+    case ACT_RAMP: return x * (x > 0) + .1 * x;
+    case ACT_LEAKY: return (x > 0) ? x : .1 * x;
+    case ACT_TANH: return (exp(2 * x) - 1) / (exp(2 * x) + 1);
+    case ACT_PLSE:
+        if (x < -4) return .01 * (x + 4);
+        if (x > 4) return .01 * (x - 4) + 1;
+        return .125 * x + .5;
+    case ACT_STAIR: {
+        int n = floor(x);
+        if (n % 2 == 0) return floor(x / 2.);
+        else return (x - n) + floor(x / 2.);
+    }
+    case ACT_HARDTAN:
+        if (x < -1) return -1;
+        if (x > 1) return 1;
+        return x;
+    case ACT_LHTAN:
+        if (x < 0) return .001 * x;
+        if (x > 1) return .001 * (x - 1) + 1;
+        return x;
+    }
+    return 0;
 }
 
 /* forward_convolutional_layer_cpu, FP32 branch

@@ -121,9 +121,38 @@ def workdir() -> str:
 _MODEL_CACHE = {}
 
 
+ALL_ACTIVATIONS = ("logistic", "loggy", "relu", "elu", "relie", "plse", "hardtan", "lhtan", "linear", "ramp", "leaky",
+                   "tanh", "stair")
+
+
+def all_activations_cfg(width: int, height: int) -> str:
+    """A small trunk that uses every activation of the reference's activate() (src/additionally.h:132-165): in
+    3x3 / 1x1 / stride-2 convolutions (direct and Winograd shapes), in [shortcut] layers and in an xnor convolution."""
+    c = zoo._Cfg()
+    zoo._net(c, width, height, calib=[8.0] * 20)
+    c.conv(16, 3, act="leaky")
+    for i, act in enumerate(ALL_ACTIVATIONS):
+        c.conv(16, 3 if i % 2 == 0 else 1, act=act)
+        if i % 4 == 3:
+            c.section("shortcut", **{"from": -3, "activation": ALL_ACTIVATIONS[(i * 5) % len(ALL_ACTIVATIONS)]})
+    c.conv(32, 3, stride=2, act="elu")
+    c.conv(32, 3, act="ramp", xnor=1)           # bit path + a pass of its own for the activation
+    c.conv(32, 1, act="tanh", xnor=1)           # xnor FP32 fallback
+    c.section("shortcut", **{"from": -2, "activation": "relu"})
+    c.conv(18, 1, bn=False, act="logistic")
+    return c.text()
+
+
 def model_files(name: str, width: int, height: int, seed: int = 1):
     """(cfg_path, weights_path) of a generated cfg + synthetic weights."""
     key = (name, width, height, seed)
+    if key not in _MODEL_CACHE and name == "all-activations":
+        cfg = os.path.join(workdir(), "all-activations-%dx%d.cfg" % (width, height))
+        with open(cfg, "w") as f:
+            f.write(all_activations_cfg(width, height))
+        wpath = cfg[:-4] + "-s%d.weights" % seed
+        weights.write_synthetic_weights(open(cfg).read(), wpath, seed=seed)
+        _MODEL_CACHE[key] = (cfg, wpath)
     if key not in _MODEL_CACHE:
         cfg = zoo.write_cfg(name, workdir(), width, height)
         wpath = os.path.join(workdir(), "%s-%dx%d-s%d.weights" % (name, width, height, seed))

@@ -294,6 +294,7 @@ def test_int8_fusion_with_first_layer_kernel_is_bit_identical(width, height, bat
 @pytest.mark.parametrize("name,width,height,batch,quantized", [
     ("yolov2-voc", 96, 96, 2, 0), ("yolov2-voc", 160, 160, 1, 1), ("tiny-yolo-voc", 96, 64, 2, 0),
     ("yolov3-spp", 64, 64, 2, 0), ("yolov3-spp", 96, 96, 1, 1),
+    ("all-activations", 48, 32, 2, 0), ("all-activations", 64, 48, 1, 1),
 ])
 def test_network_teacher_forced_other_cfgs(olib, name, width, height, batch, quantized):
     """The remaining cfgs of the reference's bin/: reorg, region+softmax, SPP max-pools."""

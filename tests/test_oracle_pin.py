@@ -64,6 +64,8 @@ def test_maxpool_op_pin(olib):
 
 
 MORE_CASES = [
+    ("all-activations", 48, 32, 2, 0),     # every activation of activate() in conv / shortcut / xnor layers
+    ("all-activations", 48, 32, 1, 1),     # -quantized: the INT8 convolution undoes nothing but LEAKY
     ("yolov2-voc", 96, 96, 2, 0),          # reorg + region (softmax) + multi-input route
     ("yolov2-voc", 96, 96, 1, 1),
     ("tiny-yolo-voc", 96, 64, 2, 0),

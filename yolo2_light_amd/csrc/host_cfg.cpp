@@ -104,9 +104,15 @@ std::vector<int> parse_int_list(const std::string &s) {
 
 int activation_from(const std::string &s, bool &ok) {
     ok = true;
-    if (s == "linear") return YL_LINEAR;
-    if (s == "leaky") return YL_LEAKY;
-    if (s == "logistic") return YL_LOGISTIC;
+    // get_activation (src/additionally.h:107-125); an unknown name is an error here (the reference falls back to ReLU
+    // with a message on stderr)
+    static const struct { const char *name; int id; } table[] = {
+        {"logistic", YL_LOGISTIC}, {"loggy", YL_LOGGY}, {"relu", YL_RELU}, {"elu", YL_ELU}, {"relie", YL_RELIE},
+        {"plse", YL_PLSE}, {"hardtan", YL_HARDTAN}, {"lhtan", YL_LHTAN}, {"linear", YL_LINEAR}, {"ramp", YL_RAMP},
+        {"leaky", YL_LEAKY}, {"tanh", YL_TANH}, {"stair", YL_STAIR},
+    };
+    for (const auto &e : table)
+        if (s == e.name) return e.id;
     ok = false;
     return YL_LINEAR;
 }

@@ -158,6 +158,8 @@ int launch_region(const float *in, float *out, int B, int n, int classes, int co
                   const int *tree_group_size = nullptr, int tree_groups = 0);
 // x -> (x > 0 ? 1 : -1)   binarize_cpu, src/additionally.c:128-134
 int launch_binarize(const float *in, float *out, size_t n, void *stream);
+// x = activate(x, act) in place: activate_array_cpu_custom for activations other than LINEAR / LEAKY (activations.h)
+int launch_activate(float *x, size_t n, int act, void *stream);
 int launch_reorg(const float *in, float *out, int B, int out_c, int out_h, int out_w, int stride, void *stream);
 
 // ---- K10: detection compaction ----

@@ -15,6 +15,8 @@
 #include <cfloat>
 
 #include "kernels.h"
+#include "activations.h"
+#include "activations.h"
 #include "../../include/yolo2_hip.h"
 
 namespace yl {
@@ -65,12 +67,7 @@ int launch_maxpool(const float *in, float *out, int B, int C, int H, int W, int 
 }
 
 // ---------------------------------------------------------------- shortcut
-__device__ __forceinline__ float act_apply(float v, int act)
-{
-    if (act == YL_LEAKY) return (v > 0.f) ? v : (float)(.1 * (double)v);
-    if (act == YL_LOGISTIC) return (float)(1. / (1. + exp((double)(-v))));
-    return v;
-}
+__device__ __forceinline__ float act_apply(float v, int act) { return yl_act_epilogue(v, act); }
 
 __global__ __launch_bounds__(256) void shortcut_same_kernel(const float4 *__restrict__ in, const float4 *__restrict__ add,
                                                             float4 *__restrict__ out, size_t n4, int act)
@@ -320,6 +317,23 @@ __global__ __launch_bounds__(256) void binarize_kernel(const float *__restrict__
 int launch_binarize(const float *in, float *out, size_t n, void *stream)
 {
     hipLaunchKernelGGL(binarize_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, in, out, n);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------- activate_array (the rare activations)
+// activate_array_cpu_custom (src/additionally.c:1436-1445) as its own pass, like in the reference: a convolution whose
+// activation is neither LINEAR nor LEAKY runs its kernel with a linear epilogue and this kernel finishes the tensor
+// in place (the same float goes into activate(), so the result is what a fused epilogue would give).  Keeping the
+// 13-way switch with its double exp() out of the MFMA kernels keeps their register allocation where it is.
+__global__ __launch_bounds__(256) void activate_kernel(float *__restrict__ x, size_t n, int act)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        x[i] = yl_activate(x[i], act);
+}
+
+int launch_activate(float *x, size_t n, int act, void *stream)
+{
+    hipLaunchKernelGGL(activate_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, act);
     return (int)hipGetLastError();
 }
 

@@ -51,6 +51,10 @@ void set_error(const std::string &msg) { g_err = msg; }
     } while (0)
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// LINEAR and LEAKY live in the convolution kernels' epilogues; every other activation of activate()
+// (src/additionally.h:132-165) is applied by a pass of its own behind a linear epilogue (layers.hip: activate_kernel)
+static inline bool hot_activation(int a) { return a == YL_LINEAR || a == YL_LEAKY; }
+
 // float -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does to the activations on the device)
 static inline uint16_t f32_to_bf16_rne(float f)
 {
@@ -427,6 +431,7 @@ static int to_device(Network &net, int device)
             Layer &cv = net.layers[i - 1];
             if (sc.type != YL_SHORTCUT || cv.type != YL_CONVOLUTIONAL) continue;
             if (sc.activation != YL_LINEAR) continue;
+            if (!hot_activation(cv.activation)) continue;        // its activation is a pass of its own over the FP32 tensor
             if (!(sc.w == sc.out_w && sc.h == sc.out_h && sc.c == sc.out_c)) continue;   // same-shape add only
             if (sc.index == i - 1) continue;
             bool referenced = (i - 1 == nl - 1);
@@ -493,6 +498,7 @@ static int to_device(Network &net, int device)
             if (in_l.type == YL_SHORTCUT && in_l.fused_into_conv) prod = j - 2;
             Layer &pl = net.layers[prod];
             if (pl.type != YL_CONVOLUTIONAL) continue;
+            if (!hot_activation(pl.activation) && pl.conv_mode != CONV_INT8) continue;      // side outputs are taken in the epilogue
             // producer kernels with a quantise-on-store epilogue: K2, and K1's direct kernel (never a layer
             // Winograd could take, never the xnor FP32 fallback): yolov3's layer 0 stops writing 3 GB of FP32
             const bool f32_direct = cons.conv_mode == CONV_INT8 && pl.conv_mode == CONV_F32 && !pl.xnor &&
@@ -532,14 +538,15 @@ static int to_device(Network &net, int device)
             Layer &cons = net.layers[j];
             if (cons.type != YL_CONVOLUTIONAL || cons.conv_mode != CONV_XNOR) continue;
             Layer &prev = net.layers[j - 1];
-            if (prev.type == YL_CONVOLUTIONAL && prev.conv_mode == CONV_XNOR && prev.fused_shortcut < 0) {
+            // (a producer with a rare activation finishes its FP32 tensor in a pass of its own: no epilogue sign words)
+            if (prev.type == YL_CONVOLUTIONAL && prev.conv_mode == CONV_XNOR && prev.fused_shortcut < 0 && hot_activation(prev.activation)) {
                 prev.bits_out_slot = j;                              // straight into this layer's input slot
                 cons.bits_from_producer = true;
                 prev.skip_f32_out = !referenced_elsewhere(j - 1, j);
             } else if (prev.type == YL_MAXPOOL && j >= 2) {
                 Layer &pp = net.layers[j - 2];
                 const bool pool_private = !referenced_elsewhere(j - 1, j);
-                if (pp.type == YL_CONVOLUTIONAL && pp.conv_mode == CONV_XNOR && pp.fused_shortcut < 0 && pool_private &&
+                if (pp.type == YL_CONVOLUTIONAL && pp.conv_mode == CONV_XNOR && pp.fused_shortcut < 0 && pool_private && hot_activation(pp.activation) &&
                     !referenced_elsewhere(j - 2, j - 1)) {
                     pp.bits_out_slot = j - 1;                        // pre-pool sign words in the pool layer's slot
                     pp.skip_f32_out = true;
@@ -574,6 +581,10 @@ static int forward_layer(Network &net, size_t i, const float *input)
     const int B = net.batch;
     switch (l.type) {
     case YL_CONVOLUTIONAL: {
+        // the -quantized convolution undoes nothing but LEAKY (src/yolov2_forward_network_quantized.c:623-627): there a
+        // rare activation is simply not applied, as in the reference
+        const bool post_act = !hot_activation(l.activation) && l.conv_mode != CONV_INT8;
+        const int kernel_act = post_act ? YL_LINEAR : l.activation;
         if (l.conv_mode == CONV_F32) {
             ConvF32Args a;
             const float *conv_in = input;
@@ -600,7 +611,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
             }
             a.B = B; a.C = l.c; a.H = l.h; a.W = l.w; a.M = l.n; a.OH = l.out_h; a.OW = l.out_w;
             a.K = l.size * l.size * l.c; a.Kpad = l.Kpad; a.Mpad = l.Mpad;
-            a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
+            a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = kernel_act;
             a.tapmajor = l.tapmajor;
             a.wino32_u = l.d_wino32_u;
             a.wino_tiling = l.wino_tiling;
@@ -642,7 +653,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
                 a.q_G = nx.Cpad / 16;
             }
             a.B = B; a.Cpad = l.Cpad; a.H = l.h; a.W = l.w; a.M = l.n; a.Mpad = l.Mpad; a.OH = l.out_h; a.OW = l.out_w;
-            a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
+            a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = kernel_act;
             // float ALPHA1 = R_MULT / (l.input_quant_multipler * l.weights_quant_multipler);  (quantized.c:596)
             a.alpha1 = 32 / (l.input_quant_multipler * l.weights_quant_multipler);
             // corners of the exact epilogue that cannot occur in this layer (see ConvI8Args::no_corner): a non-zero
@@ -683,7 +694,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
                 a.h_G = net.layers[l.q_out_layer].Cpad / 8;
             }
             a.B = B; a.Cpad = l.Cpad; a.H = l.h; a.W = l.w; a.M = l.n; a.Mpad = l.Mpad; a.OH = l.out_h; a.OW = l.out_w;
-            a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
+            a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = kernel_act;
             YL_LAUNCH(launch_conv_bf16(a, net.i8_tile, s, l.kernel_name, sizeof(l.kernel_name)), "conv_bf16");
         } else {
             auto ring = [&](int slot) { return net.d_bitbuf + (size_t)(slot % 3) * (net.bitbuf_bytes / sizeof(uint64_t)); };
@@ -700,10 +711,11 @@ static int forward_layer(Network &net, size_t i, const float *input)
                 a.out_add = sc.d_output;
                 a.out = nullptr;
             }
-            a.B = B; a.C = l.c; a.Cw = l.Cw; a.H = l.h; a.W = l.w; a.M = l.n; a.Mpad = l.Mpad; a.act = l.activation;
+            a.B = B; a.C = l.c; a.Cw = l.Cw; a.H = l.h; a.W = l.w; a.M = l.n; a.Mpad = l.Mpad; a.act = kernel_act;
             YL_LAUNCH(launch_conv_xnor(a, s), "conv_xnor");
             snprintf(l.kernel_name, sizeof(l.kernel_name), "conv_xnor");
         }
+        if (post_act) YL_LAUNCH(launch_activate(l.d_output, (size_t)B * l.outputs, l.activation, s), "activate");
         break;
     }
     case YL_MAXPOOL: {
