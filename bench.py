@@ -125,7 +125,7 @@ def calibrate_head(Network, cfg: str, wts: str, size: int, device: int, thresh: 
     deltas = []
     for i in range(probe.n):
         li = probe.layer_info(i)
-        if li["type"] != 22:        # YL_YOLO
+        if li["type"] not in (21, 22):        # YL_REGION, YL_YOLO: both take logistic(objectness) of channel 4 of an anchor
             continue
         per = 5 + li["classes"]
         o = probe.layer_output(i - 1).reshape(2, li["n"], per, -1)
@@ -133,8 +133,9 @@ def calibrate_head(Network, cfg: str, wts: str, size: int, device: int, thresh: 
         target_obj = float(np.log(thresh / (1.0 - thresh)))
         for a in range(li["n"]):
             d[a, 4] = target_obj - np.quantile(o[:, a, 4, :], 0.997)
-            for c in range(5, per):
-                d[a, c] = 0.0 - np.quantile(o[:, a, c, :], 0.985)
+            if li["type"] == 22:              # [region] classes go through a softmax: their logits stay as they are
+                for c in range(5, per):
+                    d[a, c] = 0.0 - np.quantile(o[:, a, c, :], 0.985)
         deltas.append(d.reshape(-1))
     probe.close()
     return deltas

@@ -34,6 +34,7 @@ struct ConvSmallKDev {
     int8_t *q_out;
     float q_mult;
     int q_G;
+    uint64_t *bits_out;   // sign words of the activated output for an XNOR convolution behind it: bits[B][1][OH][OW]
     int B, C, H, W, M, OH, OW;
     int K, Mpad;
     int size, stride, pad;
@@ -177,7 +178,26 @@ __global__ __launch_bounds__(256, 3) void conv_f32_smallk_kernel(ConvSmallKDev p
                 if (p.act == YL_LEAKY) v = (v > 0.f) ? v : (float)(.1 * (double)v);
                 vals[j][e] = v;
             }
-        if (p.q_out && !p.out && !p.add)
+        if (p.bits_out) {
+            // Sign-domain hand-over (conv_xnor.hip): an XNOR convolution reads only (x > 0) of its input, so this layer
+            // emits ONE 64-bit word per pixel (bit m = filter m, M <= 32; filters beyond M have zero weights and zero
+            // bias: bit 0, as the consumer's channel padding wants) instead of M floats -- the word layout of
+            // pack_sign_bits_kernel.  A pixel's 32 rows sit in two lanes (l31, half): one v_permlane32_swap ORs them.
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                unsigned bits = 0;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) bits |= (vals[j][e] > 0.f ? 1u : 0u) << ((e & 3) + 8 * (e >> 2));
+                bits <<= 4 * half;
+                const auto sw = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+                const unsigned word = sw[0] | sw[1];
+                const int n = n_base + j * 32 + l31;
+                if (half == 0 && n < p.Ntotal) p.bits_out[(size_t)ob_j[j] * p.OHW + opix_j[j]] = (uint64_t)word;
+            }
+        }
+        if (!p.out && !p.add && !p.q_out) {
+            // nothing else wants this tile (its FP32 tensor has no reader under the fusion plan)
+        } else if (p.q_out && !p.out && !p.add)
             store_q_from_cd<TN>(vals, 0, p.M, n_base, p.Ntotal, p.OHW, p.q_out, p.q_mult, p.q_G, lane, ob_j, opix_j);
         else if (p.q_out)
             store_rows_via_lds_q<TN>(strip, vals, 0, p.M, n_base, p.Ntotal, p.OHW, p.out, p.add, p.out_add,
@@ -205,6 +225,7 @@ int launch_conv_f32_smallk(const ConvF32Args &a, void *stream, char *name, size_
     ConvSmallKDev d;
     d.in = a.in; d.wt = a.wt; d.bias = a.bias; d.add = a.add; d.out_add = a.out_add; d.out = a.out;
     d.q_out = a.q_out; d.q_mult = a.q_mult; d.q_G = a.q_G;
+    d.bits_out = a.bits_out;
     d.B = a.B; d.C = a.C; d.H = a.H; d.W = a.W; d.M = a.M; d.OH = a.OH; d.OW = a.OW;
     d.K = a.K; d.Mpad = a.Mpad; d.size = a.size; d.stride = a.stride; d.pad = a.pad; d.act = a.act;
     d.OHW = a.OH * a.OW;

@@ -22,6 +22,8 @@ struct ConvF32Args {
     int8_t *q_out = nullptr;   // optional quantised side output for the next INT8 conv: act_q[B][q_G][OH][OW][16]
     float q_mult = 0.f;   // that layer's input_quant_multipler
     int q_G = 0;          // its channel groups (Cpad/16); direct kernel only, needs M % 16 == 0
+    uint64_t *bits_out = nullptr;   // optional sign words (x > 0) of the activated output, bits[B][1][OH][OW], for an XNOR
+                          // convolution behind this layer; first-layer kernel only (conv_f32_smallk.hip, M <= 32)
     int yolo_entries = 0; // > 0: the [yolo] layer that follows is folded into the epilogue (1x1 direct kernel): rows
                           // m with m % yolo_entries not in {2, 3} get logistic_activate, `out` is the YOLO layer's tensor
     int B, C, H, W, M, OH, OW;

@@ -54,6 +54,11 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // LINEAR and LEAKY live in the convolution kernels' epilogues; every other activation of activate()
 // (src/additionally.h:132-165) is applied by a pass of its own behind a linear epilogue (layers.hip: activate_kernel)
 static inline bool hot_activation(int a) { return a == YL_LINEAR || a == YL_LEAKY; }
+// the shapes conv_f32_smallk.hip accepts (smallk_applicable, minus what only the launch knows)
+static inline bool first_layer_kernel_takes(const Layer &l)
+{
+    return l.size >= 1 && l.size <= 5 && l.size * l.size * l.c <= 32 && l.n <= 32 && !l.tapmajor;
+}
 
 // float -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does to the activations on the device)
 static inline uint16_t f32_to_bf16_rne(float f)
@@ -413,6 +418,16 @@ static int to_device(Network &net, int device)
             l.host_in_heads = true;
         }
     }
+    // an FP32 first layer that hands sign words to an XNOR convolution through a [maxpool] writes PRE-pool words
+    // (one per pixel of its own output) into the ring: make the slots large enough before they are allocated
+    for (size_t i = 0; i + 2 < net.layers.size(); ++i) {
+        const Layer &pp = net.layers[i], &pool = net.layers[i + 1], &cons = net.layers[i + 2];
+        if (pp.type == YL_CONVOLUTIONAL && pp.conv_mode == CONV_F32 && !pp.xnor && first_layer_kernel_takes(pp) &&
+            pool.type == YL_MAXPOOL && cons.type == YL_CONVOLUTIONAL && cons.conv_mode == CONV_XNOR) {
+            const size_t bb = (size_t)net.batch * pp.out_h * pp.out_w * sizeof(uint64_t);
+            if (bb > net.bitbuf_bytes) net.bitbuf_bytes = bb;
+        }
+    }
     // three quantised-activation buffers used round-robin (layer j reads ring[j % 3]): a producer
     // one or two layers earlier can write layer j's input while reading its own
     if (net.qbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_qbuf, 3 * net.qbuf_bytes));
@@ -553,6 +568,16 @@ static int to_device(Network &net, int device)
                     prev.pool_bits_mode = 1;
                     prev.skip_f32_out = true;
                     cons.bits_from_producer = true;
+                } else if (pp.type == YL_CONVOLUTIONAL && pp.conv_mode == CONV_F32 && !pp.xnor && pp.fused_shortcut < 0 && pp.fused_yolo < 0 &&
+                           pp.q_out_layer < 0 && pool_private && hot_activation(pp.activation) && !referenced_elsewhere(j - 2, j - 1) &&
+                           (net.conv_opts.variant & 8) && net.conv_opts.force_tile == 0 && first_layer_kernel_takes(pp)) {
+                    // FP32 first layer -> maxpool -> XNOR conv (tiny-yolo-obj_xnor.cfg layers 0-2: 1.4 GB of FP32 written and
+                    // read back per batch of 128 just to take signs): conv_f32_smallk.hip emits the sign words itself
+                    pp.bits_out_slot = j - 1;
+                    pp.skip_f32_out = true;
+                    prev.pool_bits_mode = 1;
+                    prev.skip_f32_out = true;
+                    cons.bits_from_producer = true;
                 } else if (pool_private) {
                     prev.pool_bits_mode = 2;                         // FP32 in, pooled sign words out
                     prev.skip_f32_out = true;
@@ -620,6 +645,8 @@ static int forward_layer(Network &net, size_t i, const float *input)
                 a.yolo_entries = yo.classes + 5;
                 a.out = yo.d_output;
             }
+            if (l.bits_out_slot >= 0)       // FP32 first layer -> [maxpool] -> XNOR conv: sign words instead of the FP32 tensor
+                a.bits_out = net.d_bitbuf + (size_t)(l.bits_out_slot % 3) * (net.bitbuf_bytes / sizeof(uint64_t));
             YL_LAUNCH(launch_conv_f32(a, net.conv_opts, s, l.kernel_name, sizeof(l.kernel_name)), "conv_f32");
         } else if (l.conv_mode == CONV_INT8) {
             int8_t *q_in = net.d_qbuf + (i % 3) * net.qbuf_bytes;
@@ -1086,6 +1113,7 @@ int yl_network_layer_traffic(const yl_network *net, int i, double *bytes)
         } else {
             rd += 4 * in_el + 4 * wel;
             if (l.binarize_input) { rd += 4 * in_el; wr += 4 * in_el; }
+            if (l.bits_out_slot >= 0) wr += B * (double)l.out_h * l.out_w * 8.0 * ((l.n + 63) / 64);
         }
         if (fused) { rd += 4 * out_el; wr += 4 * out_el; }                // [shortcut] operand in, sum out
         else if (!l.skip_f32_out) wr += 4 * out_el;
