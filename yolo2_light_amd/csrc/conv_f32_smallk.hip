@@ -48,8 +48,10 @@ constexpr int SK_TPW = 4;     // tiles a wave walks
 
 }  // namespace
 
+// three waves per SIMD (<= 168 registers) for the K <= 28 instance every shipped first layer takes; the K = 29..32
+// instance holds two more k-steps of fragments and would spill there (tools/isa_lint.py guards both)
 template <int TN, int KSTEPS>
-__global__ __launch_bounds__(256, 3) void conv_f32_smallk_kernel(ConvSmallKDev p)
+__global__ __launch_bounds__(256, KSTEPS <= 14 ? 3 : 2) void conv_f32_smallk_kernel(ConvSmallKDev p)
 {
     __shared__ __attribute__((aligned(16))) float smem[4 * 16 * TN * 32 + 32];
     const int tid = threadIdx.x;
