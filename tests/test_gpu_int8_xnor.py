@@ -400,7 +400,7 @@ def test_xnor_sign_domain_fusion_is_bit_identical(name, width, height, batch):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "layer %d %r" % (i, plain.layer_info(i))
         checked += 1
     assert skipped >= 12 and checked >= 3          # 6 xnor convs + 6 max-pools + the FP32 first layer and its pool stop writing FP32
-    assert not fused.layer_materialised(0) and "smallk" in fused.layer_kernel(0)      # layer 0 hands over sign words
+    assert not fused.layer_materialised(0) and "conv_f32_first" in fused.layer_kernel(0)      # layer 0 hands over sign words
     for b in range(batch):
         assert np.array_equal(plain.get_boxes(b, width, height, 0.05, nms=0.4), fused.get_boxes(b, width, height, 0.05, nms=0.4))
     plain.close(); fused.close()

@@ -77,6 +77,67 @@ def test_conv_f32_vs_oracle(olib, shape, tile):
     net.close()
 
 
+FIRST_SHAPES = [
+    # B, C, H, W, M, act   (3x3 / stride 1 / pad 1, C <= 3, M <= 16, W % 4 == 0)
+    (2, 3, 32, 48, 16, D.LEAKY),           # tiny-yolo's first layer in small; 12 lanes per row: waves start mid-row
+    (1, 3, 13, 416, 16, D.LEAKY),          # the real row length: 104 lanes per row, lane 0 / 63 neighbours in other waves
+    (3, 3, 9, 8, 7, D.LINEAR),             # M < 16, linear, two lanes per row (every lane is a row end)
+    (2, 1, 20, 20, 16, D.LEAKY),           # one input channel
+    (1, 2, 5, 12, 3, D.LEAKY),             # 15 lanes in total: most of the only wave is dead
+    (5, 3, 7, 64, 16, D.LEAKY),            # 16 lanes per row: rows and waves end together
+]
+FIRST_FALLBACK_SHAPES = [
+    (1, 3, 13, 17, 16, D.LEAKY),           # W % 4 != 0: K1f needs aligned 4-pixel groups -> K1s
+    (1, 2, 5, 4, 3, D.LEAKY),              # W < 8
+    (1, 3, 8, 16, 24, D.LEAKY),            # M > 16
+]
+
+
+@pytest.mark.parametrize("shape", FIRST_SHAPES)
+def test_conv_first_layer_kernel_bit_identical(olib, shape):
+    """K1f (conv_f32_first.hip, VALU, 4 pixels x 16 filters per lane) against K1s (the MFMA first-layer kernel, forced
+    tile 41): an fma chain over k ascending either way => the same bits; and against the oracle within the FP32 bar."""
+    B, Cc, H, W, M, act = shape
+    rng = np.random.default_rng(5 + M + H)
+    K = Cc * 9
+    wts = rng.normal(0, np.sqrt(2.0 / K), M * K).astype(np.float32)
+    bias = rng.normal(0, 0.5, M).astype(np.float32)
+    x = (rng.standard_normal((B, Cc, H, W)) + 0.2).astype(np.float32)
+    d = D.conv(B, W, H, Cc, M, 3, 1, 1, act, wts, bias)
+    net = _net_from([d], B, W, H, Cc)
+    got = net.predict(x).copy()
+    assert "conv_f32_first" in net.layer_kernel(0), net.layer_kernel(0)
+    net.set_conv_tile(41)
+    mfma = net.predict(x)
+    assert "smallk" in net.layer_kernel(0)
+    assert np.array_equal(got.view(np.uint32), mfma.view(np.uint32))
+    ref = np.zeros(B * d.outputs, dtype=np.float32)
+    olib.oracle_conv_f32(fp(x), fp(wts), fp(bias), fp(ref), B, Cc, H, W, M, 3, 1, 1, act)
+    ok, ratio, worst = fp32_close(got, ref)
+    assert ok and ratio < 0.2, "shape %r: err/allowed %.3g" % (shape, ratio)
+    net.close()
+
+
+@pytest.mark.parametrize("shape", FIRST_FALLBACK_SHAPES)
+def test_conv_first_layer_kernel_fallback(olib, shape):
+    """Shapes K1f does not take run on K1s (no silent wrong answer at the applicability edges)."""
+    B, Cc, H, W, M, act = shape
+    rng = np.random.default_rng(11 + W)
+    K = Cc * 9
+    wts = rng.normal(0, np.sqrt(2.0 / K), M * K).astype(np.float32)
+    bias = rng.normal(0, 0.5, M).astype(np.float32)
+    x = (rng.standard_normal((B, Cc, H, W)) + 0.2).astype(np.float32)
+    d = D.conv(B, W, H, Cc, M, 3, 1, 1, act, wts, bias)
+    net = _net_from([d], B, W, H, Cc)
+    got = net.predict(x).copy()
+    assert "conv_f32_first" not in net.layer_kernel(0), net.layer_kernel(0)
+    ref = np.zeros(B * d.outputs, dtype=np.float32)
+    olib.oracle_conv_f32(fp(x), fp(wts), fp(bias), fp(ref), B, Cc, H, W, M, 3, 1, 1, act)
+    ok, ratio, worst = fp32_close(got, ref)
+    assert ok and ratio < 0.2, "shape %r: err/allowed %.3g" % (shape, ratio)
+    net.close()
+
+
 # K1w: Winograd F(2x2,3x3) kernel (forced tile 31), 3x3 / stride 1 / pad 1 only
 WINO_SHAPES = [
     # B, C, H, W, M, act

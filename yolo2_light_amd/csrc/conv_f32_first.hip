@@ -1,0 +1,210 @@
+// conv_f32_first.hip -- K1f: FP32 3x3 / stride 1 / pad 1 convolution of an RGB (C <= 3) image into AT MOST 16 filters
+// on the VALU: the first layer of yolov3-tiny and tiny-yolo-obj_xnor (3 -> 16 channels, K = 27).
+//
+// Same function and the same arithmetic order as conv_f32_smallk.hip / conv_f32_mfma.hip (forward_convolutional_layer_cpu
+// FP32 branch, src/yolov2_forward_network.c:204-261): per output an fma chain over k = (c, ky, kx) ascending, then
+// + bias, then the activation -- v_mfma_f32_32x32x2_f32 is that fmaf chain bit for bit, so this kernel returns the
+// bits of the MFMA kernels (tests/test_gpu_parity.py::test_conv_first_layer_kernel_bit_identical).
+//
+// Why not the MFMA: with 16 filters half of every 32-row MFMA is empty and the work per pixel is only 432 fmas, while
+// the MFMA form pays ~14 VALU per pixel for decode, 27 dword gathers and the epilogue next to 1 792 MFMA cycles per 64
+// pixels (PMC, DESIGN.md K1s: VALU-bound).  Here a lane owns FOUR consecutive output pixels of a row and all 16
+// filters: 64 accumulators, a 3 x 6 input window per channel (18 dword loads instead of 4 x 9), and the weights come
+// out of LDS as broadcast reads (one k-row of 16 weights = 4 ds_read_b128 feeds 64 v_fmac).  ~9 VALU per pixel in
+// total.  Outputs leave without any cross-lane traffic: 16-byte row stores per filter (1 KB contiguous per wave
+// instruction) and / or the sign words of the 16 filters for an XNOR convolution behind the layer (the lane holds
+// every filter of its pixels, so the word is built in registers).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+#include "kernels.h"
+#include "../../include/yolo2_hip.h"
+
+namespace yl {
+
+typedef float s4f __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct ConvFirstDev {
+    const float *in;
+    const float *wt;       // k-major packed [Kpad][Mpad], K order (c, ky, kx); columns >= M are zero
+    const float *bias;
+    float *out;            // [B][M][H][W] or nullptr
+    uint64_t *bits_out;    // [B][1][H][W] sign words or nullptr
+    int B, H, W, M, Mpad, act;
+    int Wq;                // groups of 4 output pixels per row
+    long long total;       // B * H * Wq lanes
+    unsigned rec;          // bytes of the input tensor
+};
+
+}  // namespace
+
+template <int C>
+__global__ __launch_bounds__(256, 4) void conv_f32_first_kernel(ConvFirstDev p)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = idx < p.total;
+    const int q = (int)(idx % p.Wq);
+    const long long t = idx / p.Wq;
+    const int oy = (int)(t % p.H);
+    const int b = live ? (int)(t / p.H) : 0;
+    const int ox0 = 4 * q;
+    const int HW = p.H * p.W;
+
+    // Window addressing.  A lane needs columns ox0-1 .. ox0+4 of three rows: ONE 16-byte load per row brings
+    // ox0 .. ox0+3 (64 lanes x 16 B contiguous), the two outer columns are the neighbour lanes' .w / .x (DPP wave
+    // shifts), zero at the ends of an image row, and a 2-lane load for lanes 0 and 63 whose neighbour is in another
+    // wave.  (First version: 18 dword loads per row triple at a 16-byte lane stride -- 108 quarter-rate texture
+    // instructions per wave, which bounded the kernel: 0.585 ms on 128 x 416 x 416.)  Rows outside the image (and
+    // dead lanes) get voffset -1: the range check of the descriptor returns 0.0 = the zero padding.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)p.rec, 0x00020000);
+    const int lane = threadIdx.x & 63;
+    const bool edge = lane == 0 || lane == 63;
+    const bool has_l = q > 0, has_r = q < p.Wq - 1;
+    int voff[3], eoff[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int iy = oy - 1 + r;
+        const bool rok = live && iy >= 0 && iy < p.H;
+        const unsigned base = (((unsigned)b * C) * (unsigned)HW + (unsigned)(iy * p.W + ox0)) * 4u;
+        voff[r] = rok ? (int)base : -1;
+        // lane 0 fetches its left neighbour, lane 63 its right one (one wave owns >= 2 lanes, so never both)
+        // (every other lane: voffset -1, no memory access.  Unconditional on purpose -- a branch around the load
+        // splits the unrolled body into blocks and hipcc's register allocation falls apart again)
+        eoff[r] = !rok || !edge ? -1 : lane == 0 ? (has_l ? (int)(base - 4u) : -1) : (has_r ? (int)(base + 16u) : -1);
+    }
+
+    // The 27 x 16 weights sit in LDS (1.7 KB per workgroup, filled once) and reach the fmas as VGPR operands through
+    // broadcast ds_read_b128 (every lane reads the same address: no bank conflict, in-order returns).  Scalar
+    // operands (s_load_dwordx16 per k-row) were the first plan: hipcc hoisted all 27 row loads to the top of the
+    // unrolled body -- 432 scalar registers, spilled to VGPR lanes, 7 000-22 000 v_readlane per kernel.
+    __shared__ __attribute__((aligned(16))) float wl[9 * C * 16];
+    for (int i = threadIdx.x; i < 9 * C * 16; i += 256) wl[i] = p.wt[(size_t)(i >> 4) * p.Mpad + (i & 15)];
+    __syncthreads();
+
+    unsigned word[4] = {0u, 0u, 0u, 0u};
+    const size_t pix = (size_t)oy * p.W + ox0;
+    // Two passes of 8 filters: 32 accumulators + the 54 window values + one k-row of 8 weights stay far below the
+    // register budget of four waves per SIMD (all 16 filters at once: 64 accumulators, and hipcc's scheduler ran the
+    // unrolled body into scratch at every register cap tried).  The loop is NOT unrolled: one body, two trips.
+#pragma unroll 1
+    for (int mh = 0; mh < 2; ++mh) {
+        float acc[8][4];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int px = 0; px < 4; ++px) acc[m][px] = 0.f;
+        const float *wh = wl + mh * 8;
+        // row k+1 is read ahead of the 32 fmas of row k, and sched_barriers fence each step: without them the scheduler
+        // lifts all 27 row reads (216 registers) to the top of the unrolled body and the allocator spills them
+        float4 n0 = *reinterpret_cast<const float4 *>(wh), n1 = *reinterpret_cast<const float4 *>(wh + 4);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            // the input window of the lane's four pixels in channel c: 3 rows x 6 columns (re-read per filter half: the
+            // second read hits L1, and 18 live values instead of 54 keep the kernel at four waves per SIMD)
+            float win[3][6];
+            // the channel offset is laundered through an empty asm: otherwise LICM proves the loads invariant in `mh`,
+            // hoists all 54 of them in front of the loop and the allocator spills them (first builds: 0.5-1.2 KB of scratch)
+            int soff = c * HW * 4;
+            asm volatile("" : "+s"(soff));
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const s4f v = __builtin_bit_cast(s4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[r], soff, 0));
+                const float e = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, eoff[r], soff, 0));
+                // wave_shr:1 -- lane i takes lane i-1's .w, lane 0 keeps `e`; wave_shl:1 -- lane i takes lane i+1's .x
+                // (element copies first: __builtin_bit_cast applied directly to `v.w` read element 0 with this hipcc)
+                const float vx = v.x, vw = v.w;
+                const float l = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, e), __builtin_bit_cast(int, vw), 0x138, 0xf, 0xf, false));
+                const float rr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, e), __builtin_bit_cast(int, vx), 0x130, 0xf, 0xf, false));
+                win[r][0] = has_l ? l : 0.f;
+                win[r][1] = v.x; win[r][2] = v.y; win[r][3] = v.z; win[r][4] = v.w;
+                win[r][5] = has_r ? rr : 0.f;
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int k = c * 9 + ky * 3 + kx;
+                    const int kn = k + 1 < 9 * C ? k + 1 : k;
+                    const float w[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+                    {
+                        int wo = kn * 16;                       // laundered as well: keeps row k+1's read HERE
+                        asm volatile("" : "+v"(wo));
+                        n0 = *reinterpret_cast<const float4 *>(wh + wo);
+                        n1 = *reinterpret_cast<const float4 *>(wh + wo + 4);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m)
+#pragma unroll
+                        for (int px = 0; px < 4; ++px) acc[m][px] = __fmaf_rn(w[m], win[ky][kx + px], acc[m][px]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        // Pin the accumulators HERE.  Their only consumers sit under `if (live)` / `if (m < p.M)`, and LLVM's code
+        // sinking moved every fma chain down into the per-filter store block of its consumer -- leaving all 27 weight
+        // rows and 54 window values live across the whole body (0.5-1.2 KB of scratch in every earlier build).
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int px = 0; px < 4; ++px) asm volatile("" : "+v"(acc[m][px]));
+        if (live) {
+#pragma unroll
+            for (int ml = 0; ml < 8; ++ml) {
+                const int m = mh * 8 + ml;
+                if (m < p.M) {                                   // wave-uniform
+                    const float bv = p.bias[m];
+                    float v[4];
+#pragma unroll
+                    for (int px = 0; px < 4; ++px) {
+                        v[px] = acc[ml][px] + bv;
+                        if (p.act == YL_LEAKY) v[px] = (v[px] > 0.f) ? v[px] : (float)(.1 * (double)v[px]);
+                        word[px] |= (v[px] > 0.f ? 1u : 0u) << m;
+                    }
+                    if (p.out) {
+                        float *o = p.out + ((size_t)b * p.M + m) * HW + pix;
+                        *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+            }
+        }
+    }
+    if (live && p.bits_out) {
+        uint64_t *o = p.bits_out + (size_t)b * HW + pix;
+        *reinterpret_cast<ulonglong2 *>(o) = make_ulonglong2((uint64_t)word[0], (uint64_t)word[1]);
+        *reinterpret_cast<ulonglong2 *>(o + 2) = make_ulonglong2((uint64_t)word[2], (uint64_t)word[3]);
+    }
+}
+
+bool first_layer_valu_applicable(const ConvF32Args &a)
+{
+    const long long in_bytes = (long long)a.B * a.C * a.H * a.W * 4;
+    return (a.W & 3) == 0 && a.W >= 8 && !a.tapmajor && a.size == 3 && a.stride == 1 && a.pad == 1 && a.C >= 1 && a.C <= 3 && a.M >= 1 && a.M <= 16 &&
+           a.OH == a.H && a.OW == a.W && a.Mpad >= 16 && a.Kpad >= 9 * a.C && !a.q_out && !a.add && a.yolo_entries == 0 &&
+           in_bytes < 0xFFFFFFFELL && (a.act == YL_LINEAR || a.act == YL_LEAKY);
+}
+
+int launch_conv_f32_first(const ConvF32Args &a, void *stream, char *name, size_t name_len)
+{
+    if (!first_layer_valu_applicable(a)) return (int)hipErrorInvalidValue;
+    ConvFirstDev d;
+    d.in = a.in; d.wt = a.wt; d.bias = a.bias; d.out = a.out; d.bits_out = a.bits_out;
+    d.B = a.B; d.H = a.H; d.W = a.W; d.M = a.M; d.Mpad = a.Mpad; d.act = a.act;
+    d.Wq = (a.W + 3) / 4;
+    d.total = (long long)a.B * a.H * d.Wq;
+    d.rec = (unsigned)((long long)a.B * a.C * a.H * a.W * 4);
+    const long long blocks = (d.total + 255) / 256;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    switch (a.C) {
+    case 1: hipLaunchKernelGGL(conv_f32_first_kernel<1>, grid, block, 0, s, d); break;
+    case 2: hipLaunchKernelGGL(conv_f32_first_kernel<2>, grid, block, 0, s, d); break;
+    default: hipLaunchKernelGGL(conv_f32_first_kernel<3>, grid, block, 0, s, d); break;
+    }
+    if (name) snprintf(name, name_len, "conv_f32_first<valu,4px,m16>");
+    return (int)hipGetLastError();
+}
+
+}  // namespace yl

@@ -522,7 +522,10 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
     // ([64,288,92416]) Winograd wins stand-alone (1.59 vs 2.16 ms) but not in the network, where the
     // layer carries a fused shortcut and is bound by 3 GB of epilogue traffic (2.31 vs 2.2 ms): C >= 64.
     if (a.q_out && a.wino32_u) return (int)hipErrorInvalidValue;      // the planner gives q_out to direct layers only
-    if (a.bits_out)                                                   // sign-word side output: the first-layer kernel has it
+    // RGB first layers with <= 16 filters: the VALU kernel (force_tile 41 keeps the MFMA first-layer kernel for A/B)
+    if (o.force_tile == 0 && (o.variant & 8) && first_layer_valu_applicable(a))
+        return launch_conv_f32_first(a, stream, name, name_len);
+    if (a.bits_out)                                                   // sign-word side output: only the first-layer kernels have it
         return smallk_applicable(a) ? launch_conv_f32_smallk(a, stream, name, name_len) : (int)hipErrorInvalidValue;
     if (a.yolo_entries > 0)                                           // folded [yolo]: 1x1 direct kernel, two tiles
         return launch_conv_f32_direct(a, (o.force_tile == 14 || o.force_tile == 22) ? o.force_tile - 10 :

@@ -62,6 +62,10 @@ void wino32_pack_weights(const float *w, int C, int M, float *dst);
 // K1s (conv_f32_smallk.hip): LDS-free kernel for first layers (C*size^2 <= 32, filters <= 32)
 bool smallk_applicable(const ConvF32Args &a);
 int launch_conv_f32_smallk(const ConvF32Args &a, void *stream, char *name, size_t name_len);
+// K1f (conv_f32_first.hip): RGB 3x3/1/1 first layers with at most 16 filters on the VALU (4 pixels x 16 filters per
+// lane, scalar weights), bit-identical to K1s; FP32 rows and / or sign words out
+bool first_layer_valu_applicable(const ConvF32Args &a);
+int launch_conv_f32_first(const ConvF32Args &a, void *stream, char *name, size_t name_len);
 int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, int variant, void *stream, char *name, size_t name_len);
 // K1w, round 3 (conv_f32_wino16.hip): the same tile on v_mfma_f32_16x16x4_f32, a wave holds all 16 planes of its
 // 32-filter x 16-tile block, output transform in registers; its own U packing

@@ -570,7 +570,8 @@ static int to_device(Network &net, int device)
                     cons.bits_from_producer = true;
                 } else if (pp.type == YL_CONVOLUTIONAL && pp.conv_mode == CONV_F32 && !pp.xnor && pp.fused_shortcut < 0 && pp.fused_yolo < 0 &&
                            pp.q_out_layer < 0 && pool_private && hot_activation(pp.activation) && !referenced_elsewhere(j - 2, j - 1) &&
-                           (net.conv_opts.variant & 8) && net.conv_opts.force_tile == 0 && first_layer_kernel_takes(pp)) {
+                           (net.conv_opts.variant & 8) && (net.conv_opts.force_tile == 0 || net.conv_opts.force_tile == 41) &&
+                           first_layer_kernel_takes(pp)) {
                     // FP32 first layer -> maxpool -> XNOR conv (tiny-yolo-obj_xnor.cfg layers 0-2: 1.4 GB of FP32 written and
                     // read back per batch of 128 just to take signs): conv_f32_smallk.hip emits the sign words itself
                     pp.bits_out_slot = j - 1;
