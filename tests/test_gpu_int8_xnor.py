@@ -266,8 +266,8 @@ def test_int8_fusion_is_bit_identical(width, height, batch, tile):
 
 @pytest.mark.parametrize("width,height,batch", [(96, 96, 2), (160, 96, 3)])
 def test_int8_fusion_with_first_layer_kernel_is_bit_identical(width, height, batch):
-    """-quantized yolov3, fused, layer 0 through the LDS-free first-layer kernel writing ONLY the int8 input of
-    layer 1 (conv_f32_smallk.hip, variant bit 3): same materialised tensors and detections as the unfused run."""
+    """-quantized yolov3, fused, layer 0 through the first-layer kernel (conv_f32_first.hip, variant bit 3) writing ONLY
+    the int8 input of layer 1: same materialised tensors and detections as the unfused run on the generic kernels."""
     cfg, wts = common.model_files("yolov3", width, height)
     x = common.seeded_input(batch, 3, height, width)
     plain = Network.load(cfg, wts, batch, 1, device=0)
@@ -276,7 +276,7 @@ def test_int8_fusion_with_first_layer_kernel_is_bit_identical(width, height, bat
     fused.set_variant(8)
     plain.predict(x)
     fused.predict(x)
-    assert "smallk" in fused.layer_kernel(0), fused.layer_kernel(0)
+    assert "conv_f32_first" in fused.layer_kernel(0) and "qonly" in fused.layer_kernel(0), fused.layer_kernel(0)
     infos = plain.layers()
     checked = 0
     for i, li in enumerate(infos):

@@ -78,18 +78,20 @@ def test_conv_f32_vs_oracle(olib, shape, tile):
 
 
 FIRST_SHAPES = [
-    # B, C, H, W, M, act   (3x3 / stride 1 / pad 1, C <= 3, M <= 16, W % 4 == 0)
+    # B, C, H, W, M, act   (3x3 / stride 1 / pad 1, C <= 3, M <= 32, W % 4 == 0)
     (2, 3, 32, 48, 16, D.LEAKY),           # tiny-yolo's first layer in small; 12 lanes per row: waves start mid-row
     (1, 3, 13, 416, 16, D.LEAKY),          # the real row length: 104 lanes per row, lane 0 / 63 neighbours in other waves
     (3, 3, 9, 8, 7, D.LINEAR),             # M < 16, linear, two lanes per row (every lane is a row end)
     (2, 1, 20, 20, 16, D.LEAKY),           # one input channel
     (1, 2, 5, 12, 3, D.LEAKY),             # 15 lanes in total: most of the only wave is dead
     (5, 3, 7, 64, 16, D.LEAKY),            # 16 lanes per row: rows and waves end together
+    (2, 3, 24, 32, 32, D.LEAKY),           # yolov3's first layer in small: 32 filters = four passes of 8
+    (1, 3, 10, 16, 21, D.LEAKY),           # 17..32 filters, M % 8 != 0: the last pass is partly empty
 ]
 FIRST_FALLBACK_SHAPES = [
     (1, 3, 13, 17, 16, D.LEAKY),           # W % 4 != 0: K1f needs aligned 4-pixel groups -> K1s
     (1, 2, 5, 4, 3, D.LEAKY),              # W < 8
-    (1, 3, 8, 16, 24, D.LEAKY),            # M > 16
+    (1, 3, 8, 16, 40, D.LEAKY),            # M > 32
 ]
 
 

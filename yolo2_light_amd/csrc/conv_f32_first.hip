@@ -1,23 +1,32 @@
-// conv_f32_first.hip -- K1f: FP32 3x3 / stride 1 / pad 1 convolution of an RGB (C <= 3) image into AT MOST 16 filters
-// on the VALU: the first layer of yolov3-tiny and tiny-yolo-obj_xnor (3 -> 16 channels, K = 27).
+// conv_f32_first.hip -- K1f: FP32 3x3 / stride 1 / pad 1 convolution of an RGB (C <= 3) image into AT MOST 32 filters
+// on the VALU: the first layer of yolov3 (3 -> 32), yolov3-tiny and tiny-yolo-obj_xnor (3 -> 16); K = 27.
 //
 // Same function and the same arithmetic order as conv_f32_smallk.hip / conv_f32_mfma.hip (forward_convolutional_layer_cpu
 // FP32 branch, src/yolov2_forward_network.c:204-261): per output an fma chain over k = (c, ky, kx) ascending, then
 // + bias, then the activation -- v_mfma_f32_32x32x2_f32 is that fmaf chain bit for bit, so this kernel returns the
 // bits of the MFMA kernels (tests/test_gpu_parity.py::test_conv_first_layer_kernel_bit_identical).
 //
-// Why not the MFMA: with 16 filters half of every 32-row MFMA is empty and the work per pixel is only 432 fmas, while
-// the MFMA form pays ~14 VALU per pixel for decode, 27 dword gathers and the epilogue next to 1 792 MFMA cycles per 64
-// pixels (PMC, DESIGN.md K1s: VALU-bound).  Here a lane owns FOUR consecutive output pixels of a row and all 16
-// filters: 64 accumulators, a 3 x 6 input window per channel (18 dword loads instead of 4 x 9), and the weights come
-// out of LDS as broadcast reads (one k-row of 16 weights = 4 ds_read_b128 feeds 64 v_fmac).  ~9 VALU per pixel in
-// total.  Outputs leave without any cross-lane traffic: 16-byte row stores per filter (1 KB contiguous per wave
-// instruction) and / or the sign words of the 16 filters for an XNOR convolution behind the layer (the lane holds
-// every filter of its pixels, so the word is built in registers).
+// Why not the MFMA: the work per pixel is only 27 x M fmas, while the MFMA form (K1s) pays ~14 VALU per pixel for
+// decode, 27 dword gathers and a cross-lane epilogue next to the matrix cycles (PMC, DESIGN.md K1s: VALU-bound), and
+// with 16 filters half of every 32-row MFMA is empty.  Here a lane owns FOUR consecutive output pixels of a row and
+// every filter: passes of 8 filters x 4 pixels = 32 accumulators, a 3 x 6 input window per channel (three 16-byte
+// loads + DPP neighbour exchange), weights out of LDS as broadcast reads (one k-row of 8 weights = 2 ds_read_b128 feeds
+// 32 v_fmac).  Outputs leave without any cross-lane traffic, whichever the next layer wants:
+//   * FP32 rows: one 16-byte store per filter (1 KB contiguous per wave instruction),
+//   * the sign words of the filters for an XNOR convolution behind the layer (bit m = filter m, built in registers),
+//   * the int8 units act_q[B][M/16][H][W][16] for an INT8 convolution behind the layer (64 contiguous bytes per lane).
+// Measured (MI355X, profiles/r3_bench_layers_*): tiny-yolo-xnor 128 x 416 x 416 -> sign words 0.75 ms (K1s) -> 0.30 ms;
+// yolov3 64 x 608 x 608 -> int8 only 0.88 -> 0.76 ms; -> FP32 rows 1.07 -> 0.98 ms (3 GB of stores: HBM-write-bound).
+//
+// Three things hipcc had to be talked out of (each cost 0.5-1.2 KB of scratch per lane until found; ISA-checked by
+// tests/test_isa_lint.py): LICM hoisting the window loads out of the pass loop, the scheduler lifting all 27 LDS row
+// reads to the top of the unrolled body, and -- the real one -- code SINKING of every fma chain into the conditional
+// store block of its consumer.  See the comments at the asm("") statements below.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
 #include "kernels.h"
+#include "epilogue.h"
 #include "../../include/yolo2_hip.h"
 
 namespace yl {
@@ -32,6 +41,9 @@ struct ConvFirstDev {
     const float *bias;
     float *out;            // [B][M][H][W] or nullptr
     uint64_t *bits_out;    // [B][1][H][W] sign words or nullptr
+    int8_t *q_out;         // act_q[B][q_G][H][W][16] int8 or nullptr
+    float q_mult;
+    int q_G;
     int B, H, W, M, Mpad, act;
     int Wq;                // groups of 4 output pixels per row
     long long total;       // B * H * Wq lanes
@@ -40,8 +52,8 @@ struct ConvFirstDev {
 
 }  // namespace
 
-template <int C>
-__global__ __launch_bounds__(256, 4) void conv_f32_first_kernel(ConvFirstDev p)
+template <int C, int MP, bool Q>
+__global__ __launch_bounds__(256, Q ? 3 : 4) void conv_f32_first_kernel(ConvFirstDev p)
 {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const bool live = idx < p.total;
@@ -79,17 +91,20 @@ __global__ __launch_bounds__(256, 4) void conv_f32_first_kernel(ConvFirstDev p)
     // broadcast ds_read_b128 (every lane reads the same address: no bank conflict, in-order returns).  Scalar
     // operands (s_load_dwordx16 per k-row) were the first plan: hipcc hoisted all 27 row loads to the top of the
     // unrolled body -- 432 scalar registers, spilled to VGPR lanes, 7 000-22 000 v_readlane per kernel.
-    __shared__ __attribute__((aligned(16))) float wl[9 * C * 16];
-    for (int i = threadIdx.x; i < 9 * C * 16; i += 256) wl[i] = p.wt[(size_t)(i >> 4) * p.Mpad + (i & 15)];
+    __shared__ __attribute__((aligned(16))) float wl[9 * C * MP];
+    for (int i = threadIdx.x; i < 9 * C * MP; i += 256) wl[i] = p.wt[(size_t)(i / MP) * p.Mpad + (i % MP)];
     __syncthreads();
 
     unsigned word[4] = {0u, 0u, 0u, 0u};
     const size_t pix = (size_t)oy * p.W + ox0;
-    // Two passes of 8 filters: 32 accumulators + the 54 window values + one k-row of 8 weights stay far below the
-    // register budget of four waves per SIMD (all 16 filters at once: 64 accumulators, and hipcc's scheduler ran the
-    // unrolled body into scratch at every register cap tried).  The loop is NOT unrolled: one body, two trips.
+    unsigned qheld[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};   // bytes 0-7 of the open 16-channel int8 unit
+    // Passes of 8 filters: 32 accumulators + 18 window values + two k-rows of 8 weights stay far below the register
+    // budget of four waves per SIMD.  The loop is NOT unrolled: one body, MP / 8 trips.
+    const int passes = (p.M + 7) >> 3;
 #pragma unroll 1
-    for (int mh = 0; mh < 2; ++mh) {
+    for (int mh = 0; mh < passes; ++mh) {
+        // (v_pk_fma_f32 over filter pairs -- 432 packed instead of 864 scalar fmas, weight pair x broadcast pixel -- was
+        // built and measured: bit-identical and SLOWER, 0.365 vs 0.304 ms on 128 x 416 x 416; the scalar chain stays)
         float acc[8][4];
 #pragma unroll
         for (int m = 0; m < 8; ++m)
@@ -129,7 +144,7 @@ __global__ __launch_bounds__(256, 4) void conv_f32_first_kernel(ConvFirstDev p)
                     const int kn = k + 1 < 9 * C ? k + 1 : k;
                     const float w[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
                     {
-                        int wo = kn * 16;                       // laundered as well: keeps row k+1's read HERE
+                        int wo = kn * MP;                       // laundered as well: keeps row k+1's read HERE
                         asm volatile("" : "+v"(wo));
                         n0 = *reinterpret_cast<const float4 *>(wh + wo);
                         n1 = *reinterpret_cast<const float4 *>(wh + wo + 4);
@@ -149,24 +164,72 @@ __global__ __launch_bounds__(256, 4) void conv_f32_first_kernel(ConvFirstDev p)
         for (int m = 0; m < 8; ++m)
 #pragma unroll
             for (int px = 0; px < 4; ++px) asm volatile("" : "+v"(acc[m][px]));
-        if (live) {
+        // finish the 32 values in place: + bias, activation (wave-uniform guards)
+#pragma unroll
+        for (int ml = 0; ml < 8; ++ml) {
+            const int m = mh * 8 + ml;
+            const float bv = m < p.M ? p.bias[m] : 0.f;
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                float v = acc[ml][px] + bv;
+                if (p.act == YL_LEAKY) v = (v > 0.f) ? v : (float)(.1 * (double)v);
+                acc[ml][px] = v;
+                if (m < p.M) word[px] |= (v > 0.f ? 1u : 0u) << m;
+            }
+        }
+        if (live && p.out) {
 #pragma unroll
             for (int ml = 0; ml < 8; ++ml) {
                 const int m = mh * 8 + ml;
-                if (m < p.M) {                                   // wave-uniform
-                    const float bv = p.bias[m];
-                    float v[4];
+                if (m < p.M)
+                    *reinterpret_cast<float4 *>(p.out + ((size_t)b * p.M + m) * HW + pix) =
+                        make_float4(acc[ml][0], acc[ml][1], acc[ml][2], acc[ml][3]);
+            }
+        }
+        if (Q) {
+            // int8 side output act_q[B][q_G][H][W][16] for an INT8 convolution behind the layer: a lane holds 8
+            // consecutive channels of 4 consecutive pixels per pass = half a unit each; every second pass writes the
+            // four complete units (64 contiguous bytes per lane).  Fast quantisation = trunc + clamp; the
+            // `int16_t = float` wrap corner is detected per wave and redone exactly (epilogue.h, store_q_from_cd).
+            unsigned qb[4][2];
+            float tmax = 0.f;
 #pragma unroll
-                    for (int px = 0; px < 4; ++px) {
-                        v[px] = acc[ml][px] + bv;
-                        if (p.act == YL_LEAKY) v[px] = (v[px] > 0.f) ? v[px] : (float)(.1 * (double)v[px]);
-                        word[px] |= (v[px] > 0.f ? 1u : 0u) << m;
+            for (int px = 0; px < 4; ++px)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    int c[4];
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const float t = __fmul_rn(acc[h * 4 + r4][px], p.q_mult);
+                        tmax = fmaxf(tmax, fabsf(t));
+                        const int ci = (int)t;
+                        c[r4] = ci < -127 ? -127 : (ci > 127 ? 127 : ci);
                     }
-                    if (p.out) {
-                        float *o = p.out + ((size_t)b * p.M + m) * HW + pix;
-                        *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                    }
+                    qb[px][h] = __builtin_amdgcn_perm((unsigned)c[1], (unsigned)c[0], 0x0C0C0400u) |
+                                __builtin_amdgcn_perm((unsigned)c[3], (unsigned)c[2], 0x04000C0Cu);
                 }
+            if (__builtin_amdgcn_ballot_w64(!(tmax < 32768.f)) != 0ull) {
+#pragma unroll
+                for (int px = 0; px < 4; ++px)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        unsigned w = 0;
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4)
+                            w |= ((unsigned)(quantize_input_i8(acc[h * 4 + r4][px], p.q_mult) & 0xFF)) << (8 * r4);
+                        qb[px][h] = w;
+                    }
+            }
+            if (mh & 1) {
+                if (live) {
+                    int8_t *o = p.q_out + (((size_t)b * p.q_G + (mh >> 1)) * HW + pix) * 16;
+#pragma unroll
+                    for (int px = 0; px < 4; ++px)
+                        *reinterpret_cast<uint4 *>(o + px * 16) = make_uint4(qheld[px][0], qheld[px][1], qb[px][0], qb[px][1]);
+                }
+            } else {
+#pragma unroll
+                for (int px = 0; px < 4; ++px) { qheld[px][0] = qb[px][0]; qheld[px][1] = qb[px][1]; }
             }
         }
     }
@@ -180,8 +243,8 @@ __global__ __launch_bounds__(256, 4) void conv_f32_first_kernel(ConvFirstDev p)
 bool first_layer_valu_applicable(const ConvF32Args &a)
 {
     const long long in_bytes = (long long)a.B * a.C * a.H * a.W * 4;
-    return (a.W & 3) == 0 && a.W >= 8 && !a.tapmajor && a.size == 3 && a.stride == 1 && a.pad == 1 && a.C >= 1 && a.C <= 3 && a.M >= 1 && a.M <= 16 &&
-           a.OH == a.H && a.OW == a.W && a.Mpad >= 16 && a.Kpad >= 9 * a.C && !a.q_out && !a.add && a.yolo_entries == 0 &&
+    return (a.W & 3) == 0 && a.W >= 8 && !a.tapmajor && a.size == 3 && a.stride == 1 && a.pad == 1 && a.C >= 1 && a.C <= 3 && a.M >= 1 && a.M <= 32 &&
+           a.OH == a.H && a.OW == a.W && a.Mpad >= (a.M <= 16 ? 16 : 32) && a.Kpad >= 9 * a.C && (!a.q_out || a.M % 16 == 0) && !a.add && a.yolo_entries == 0 &&
            in_bytes < 0xFFFFFFFELL && (a.act == YL_LINEAR || a.act == YL_LEAKY);
 }
 
@@ -190,6 +253,7 @@ int launch_conv_f32_first(const ConvF32Args &a, void *stream, char *name, size_t
     if (!first_layer_valu_applicable(a)) return (int)hipErrorInvalidValue;
     ConvFirstDev d;
     d.in = a.in; d.wt = a.wt; d.bias = a.bias; d.out = a.out; d.bits_out = a.bits_out;
+    d.q_out = a.q_out; d.q_mult = a.q_mult; d.q_G = a.q_G;
     d.B = a.B; d.H = a.H; d.W = a.W; d.M = a.M; d.Mpad = a.Mpad; d.act = a.act;
     d.Wq = (a.W + 3) / 4;
     d.total = (long long)a.B * a.H * d.Wq;
@@ -198,12 +262,21 @@ int launch_conv_f32_first(const ConvF32Args &a, void *stream, char *name, size_t
     if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks), block(256);
     hipStream_t s = (hipStream_t)stream;
+    const bool wide = a.M > 16;
+#define YL_FIRST_LAUNCH(CC, MPP, QQ) hipLaunchKernelGGL((conv_f32_first_kernel<CC, MPP, QQ>), grid, block, 0, s, d)
+#define YL_FIRST_C(CC)                                                                             \
+    do {                                                                                           \
+        if (a.q_out) { if (wide) YL_FIRST_LAUNCH(CC, 32, true); else YL_FIRST_LAUNCH(CC, 16, true); }   \
+        else { if (wide) YL_FIRST_LAUNCH(CC, 32, false); else YL_FIRST_LAUNCH(CC, 16, false); }        \
+    } while (0)
     switch (a.C) {
-    case 1: hipLaunchKernelGGL(conv_f32_first_kernel<1>, grid, block, 0, s, d); break;
-    case 2: hipLaunchKernelGGL(conv_f32_first_kernel<2>, grid, block, 0, s, d); break;
-    default: hipLaunchKernelGGL(conv_f32_first_kernel<3>, grid, block, 0, s, d); break;
+    case 1: YL_FIRST_C(1); break;
+    case 2: YL_FIRST_C(2); break;
+    default: YL_FIRST_C(3); break;
     }
-    if (name) snprintf(name, name_len, "conv_f32_first<valu,4px,m16>");
+#undef YL_FIRST_C
+#undef YL_FIRST_LAUNCH
+    if (name) snprintf(name, name_len, "conv_f32_first<valu,4px,m%d%s>", wide ? 32 : 16, a.q_out ? (a.out ? ",q" : ",qonly") : "");
     return (int)hipGetLastError();
 }
 
