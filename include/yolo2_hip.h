@@ -302,7 +302,8 @@ int yl_network_set_conv_tile(yl_network *net, int cfg);
  * input channels up, bit 5 (takes effect at the next yl_network_to_device: it selects the weight packing) the Winograd
  * kernel with all 16 planes of a block in one wave and the output transform in registers, bit 6 (with bit 5) its
  * warp-specialised form (4 matrix waves that only issue MFMAs + 4 staging waves), bit 7 (at yl_network_to_device,
- * without bit 5) the 64-filter x 64-tile 8-wave Winograd kernel for layers with >= 64 filters; -1 = built-in default */
+ * without bit 5) the 64-filter x 64-tile 8-wave Winograd kernel for layers with >= 64 filters, bit 8 sign-only XNOR
+ * layers evaluate the float epilogue instead of comparing the match count with its threshold; -1 = built-in default */
 int yl_network_set_variant(yl_network *net, int bits);
 /* Opt-in BF16 variant of the FP32 path (north_star (a) "FP32/BF16"; BEFORE yl_network_to_device): every FP32
  * convolution whose input has whole 8-channel groups runs on v_mfma_f32_32x32x16_bf16 with both operands rounded
@@ -323,7 +324,8 @@ int yl_network_set_nms_mode(yl_network *net, int mode);
  * 0 = packed by host loops and uploaded inflated.  Bit-identical images either way.  BEFORE yl_network_to_device. */
 int yl_network_set_device_pack(yl_network *net, int on);
 /* Test hook: the packed weight image of conv layer i as it sits on the device: which = 0 k-major FP32 panels,
- * 1 Winograd U, 2 int8 / bf16 units, 3 XNOR sign words.  Returns its size in bytes (0 = the layer has none);
+ * 1 Winograd U, 2 int8 / bf16 units, 3 XNOR sign words; XNOR layers also 4 = int32 count thresholds of the sign-only
+ * epilogue [Mpad] + the number of filters without one, 5 = mean[M], 6 = bias[M].  Returns its size in bytes (0 = none);
  * copies it when dst_host != NULL (dst_bytes >= size). */
 long long yl_debug_layer_packed(yl_network *net, int i, int which, void *dst_host, long long dst_bytes);
 /* Test hook (host only, no GPU needed): the Winograd weight transform U = G g G^T of a 3x3 layer

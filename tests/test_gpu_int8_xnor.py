@@ -406,6 +406,39 @@ def test_xnor_sign_domain_fusion_is_bit_identical(name, width, height, batch):
     plain.close(); fused.close()
 
 
+def test_xnor_sign_thresholds_match_the_float_epilogue():
+    """Sign-only XNOR layers compare the match count with a per-filter threshold (conv_xnor.hip).  The thresholds on
+    the device must be exactly where fl(fl((2*count - K) * mean) + bias) > 0 switches on, for every filter of every
+    XNOR layer; and the run with thresholds equals the run with the float epilogue (variant bit 8) bit for bit."""
+    cfg, wts = common.model_files("tiny-yolo-xnor", 96, 96)
+    net = Network.load(cfg, wts, 2, 0, device=0, fuse=True)
+    seen = 0
+    for i, li in enumerate(net.layers()):
+        raw = net.layer_packed(i, 4) if li["type"] == common.CONV else None
+        if raw is None:
+            continue
+        thr = raw.view(np.int32)
+        mean = net.layer_packed(i, 5).view(np.float32)
+        bias = net.layer_packed(i, 6).view(np.float32)
+        M, K = mean.size, 9 * li["c"]
+        assert thr[-1] == 0                                                   # every filter is a step function
+        assert np.all(thr[M:-1] == 0x7fffffff)                                # pad filters never set a bit
+        c = np.arange(K + 1, dtype=np.int64)
+        v = ((2 * c - K).astype(np.float32)[None, :] * mean[:, None]).astype(np.float32) + bias[:, None]
+        pos = v.astype(np.float32) > 0
+        want = np.where(pos.any(axis=1), pos.argmax(axis=1), K + 1)
+        assert np.array_equal(thr[:M], want.astype(np.int32)), i
+        assert np.all(pos == (c[None, :] >= want[:, None]))
+        seen += 1
+    assert seen >= 6
+    x = common.seeded_input(2, 3, 96, 96)
+    a = net.predict(x).copy()
+    net.set_variant(30 | 256)            # YL_VARIANT_DEFAULT | bit 8
+    b = net.predict(x).copy()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    net.close()
+
+
 @pytest.mark.parametrize("width,height,batch", [(64, 48, 2), (96, 96, 3)])
 def test_xnor_conv_shortcut_fusion_is_bit_identical(width, height, batch):
     """conv(xnor, bit path) + [shortcut] folded into one kernel, as the reference GPU path does

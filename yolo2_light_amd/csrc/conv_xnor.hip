@@ -155,6 +155,7 @@ struct ConvXnorDev {
     float *out_add;
     uint64_t *out_bits;       // sign words of the activation for a following XNOR layer, or nullptr
     int32_t *dbg;
+    const int *thr;           // count thresholds (sign-only epilogue) or nullptr
     int B, C, Cw, H, W, M, act;
     int out_Cw;               // words per pixel of out_bits
     int Ntotal, HW;
@@ -312,6 +313,20 @@ __global__ __launch_bounds__(256) void conv_xnor_kernel(ConvXnorDev p)
     const int K = 9 * p.C;
     const size_t obase = (size_t)bimg * p.M * p.HW + pix;
     unsigned sign_lo = 0, sign_hi = 0;
+    // Sign-only epilogue: between two XNOR layers nothing but (result > 0) is consumed, and the result
+    // fl(fl((2*count - K) * mean) + bias) -- leaky keeps the sign -- is a non-decreasing function of the integer
+    // count (mean = mean|w| >= 0, rounding is monotone), i.e. a step at a per-filter threshold that
+    // xnor_threshold_kernel found by evaluating THIS expression for every count (and verified to be a step).  One
+    // compare per filter instead of cvt / mul / add / the double-precision leaky / compare: ~3 VALU instead of ~14
+    // per output, which on the thin layers (K = 144 ... 576 bits) was as much work as the popcounts themselves.
+    if (p.thr && !p.out && !p.add && !p.dbg) {
+#pragma unroll
+        for (int f = 0; f < FT; ++f) {
+            const int t = p.thr[f0 + f];                          // wave-uniform: scalar load; pad filters hold INT_MAX
+            if (f < 32) sign_lo |= (cnt[f] >= t ? 1u : 0u) << f;
+            else sign_hi |= (cnt[f] >= t ? 1u : 0u) << (f - 32);
+        }
+    } else
 #pragma unroll
     for (int f = 0; f < FT; ++f) {
         const int m = f0 + f;
@@ -336,6 +351,33 @@ __global__ __launch_bounds__(256) void conv_xnor_kernel(ConvXnorDev p)
     }
 }
 
+// thresholds of the sign-only epilogue: one lane per filter evaluates the kernel's own expression for every count
+__global__ __launch_bounds__(64) void xnor_threshold_kernel(const float *__restrict__ mean, const float *__restrict__ bias,
+                                                            int *__restrict__ thr, int *__restrict__ bad, int M, int Mpad, int K)
+{
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= Mpad) return;
+    if (m >= M) { thr[m] = 0x7fffffff; return; }
+    const float mu = mean[m], bv = bias[m];
+    int t = K + 1;
+    bool step = true;
+    for (int c = 0; c <= K; ++c) {
+        const float v = __fadd_rn(__fmul_rn((float)(2 * c - K), mu), bv);
+        const bool pos = v > 0.f;
+        if (pos && t == K + 1) t = c;
+        if (!pos && t != K + 1) step = false;                    // positive below, not positive above: no threshold
+    }
+    thr[m] = t;
+    if (!step) atomicAdd(bad, 1);
+}
+
+int launch_xnor_thresholds(const float *mean, const float *bias, int *thr, int *bad, int M, int Mpad, int K, void *stream)
+{
+    hipLaunchKernelGGL(xnor_threshold_kernel, dim3((unsigned)((Mpad + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                       mean, bias, thr, bad, M, Mpad, K);
+    return (int)hipGetLastError();
+}
+
 template <int CWC, int FT, bool W32>
 static int launch_xnor(const ConvXnorDev &d, hipStream_t s)
 {
@@ -348,7 +390,7 @@ int launch_conv_xnor(const ConvXnorArgs &a, void *stream)
 {
     ConvXnorDev d;
     d.in_bits = a.in_bits; d.w_bits = a.w_bits; d.mean = a.mean; d.bias = a.bias; d.out = a.out; d.dbg = a.dbg;
-    d.add = a.add; d.out_add = a.out_add;
+    d.add = a.add; d.out_add = a.out_add; d.thr = a.thr;
     d.out_bits = a.out_bits; d.out_Cw = (a.M + 63) / 64;
     d.B = a.B; d.C = a.C; d.Cw = a.Cw; d.H = a.H; d.W = a.W; d.M = a.M; d.act = a.act;
     d.HW = a.H * a.W;

@@ -47,7 +47,8 @@ struct ConvF32Opts {
     // Winograd kernel that keeps all 16 planes of a block in one wave (conv_f32_wino16.hip) instead of round 2's
     // plane-split kernel, bit 6 (with bit 5) its warp-specialised form: 4 matrix + 4 staging waves, one workgroup
     // per CU, bit 7 (read at upload, without bit 5, layers with >= 64 filters) the 64-filter x 64-tile 8-wave kernel
-    // (conv_f32_wino64.hip).  (An 8-byte-access epilogue for odd map widths was measured and dropped: no gain,
+    // (conv_f32_wino64.hip), bit 8 XNOR layers between XNOR layers keep the float epilogue instead of the count
+    // threshold (conv_xnor.hip; same bits either way).  (An 8-byte-access epilogue for odd map widths was measured and dropped: no gain,
     // profiles/r2_ab_fp32_variants.txt.)
     int variant = YL_VARIANT_DEFAULT;
 };
@@ -139,10 +140,15 @@ struct ConvXnorArgs {
     float *out_add = nullptr;       // the same pair, src/additionally.c:326-339)
     uint64_t *out_bits = nullptr;   // optional sign words of the result for a following XNOR layer: [B][ceil(M/64)][H][W]
     int32_t *dbg;             // optional match counts
+    const int *thr = nullptr; // optional [Mpad] count thresholds (launch_xnor_thresholds): sign of the result = (count >= thr[m])
     int B, C, Cw, H, W, M, Mpad;
     int act;
 };
 int launch_conv_xnor(const ConvXnorArgs &a, void *stream);
+// thr[m] = the smallest match count whose result (2*count - K) * mean[m] + bias[m] is > 0 (K + 1 if none), m < M;
+// INT_MAX for the pad filters; *bad (device int, zeroed by the caller) counts filters whose result is NOT a step
+// function of the count (then thr must not be used)
+int launch_xnor_thresholds(const float *mean, const float *bias, int *thr, int *bad, int M, int Mpad, int K, void *stream);
 // K3c: max-pooling in the sign domain (OR of the window's sign words), and FP32 -> pooled sign words in one pass
 int launch_bit_maxpool(const uint64_t *in, uint64_t *out, int B, int Cw, int H, int W, int OH, int OW,
                        int size, int stride, int pad, void *stream);

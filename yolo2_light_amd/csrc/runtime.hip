@@ -87,6 +87,8 @@ static void free_device(Network &net)
         if (l.d_weights_i8) (void)hipFree(l.d_weights_i8);
         if (l.d_weights_bits) (void)hipFree(l.d_weights_bits);
         if (l.d_mean) (void)hipFree(l.d_mean);
+        if (l.d_thr) (void)hipFree(l.d_thr);
+        l.d_thr = nullptr; l.thr_ok = false;
         if (l.d_debug) (void)hipFree(l.d_debug);
         if (l.d_tree) (void)hipFree(l.d_tree);
         l.d_tree = nullptr;
@@ -324,6 +326,15 @@ static int upload_conv(Network &net, Layer &l)
         }
         YL_HIP(hipMalloc((void **)&l.d_mean, sizeof(float) * M));
         YL_STAGE(stage_h2d(net.device, l.d_mean, l.mean_arr.data(), sizeof(float) * M));
+        {   // thresholds of the sign-only epilogue (conv_xnor.hip), evaluated on the device with the kernel's own expression
+            YL_HIP(hipMalloc((void **)&l.d_thr, sizeof(int) * ((size_t)l.Mpad + 1)));
+            YL_HIP(hipMemsetAsync(l.d_thr + l.Mpad, 0, sizeof(int), (hipStream_t)s));
+            YL_LAUNCH(launch_xnor_thresholds(l.d_mean, l.d_biases, l.d_thr, l.d_thr + l.Mpad, M, l.Mpad, 9 * l.c, s), "xnor_thresholds");
+            YL_HIP(hipStreamSynchronize((hipStream_t)s));
+            int bad = 1;
+            YL_STAGE(stage_d2h(net.device, &bad, l.d_thr + l.Mpad, sizeof(int)));
+            l.thr_ok = bad == 0;
+        }
         size_t bb = (size_t)net.batch * l.h * l.w * l.Cw * sizeof(uint64_t);
         const size_t ob = (size_t)net.batch * l.h * l.w * ((M + 63) / 64) * sizeof(uint64_t);      // sign words of its result
         if (ob > bb) bb = ob;
@@ -732,6 +743,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
             ConvXnorArgs a;
             a.in_bits = in_bits; a.w_bits = l.d_weights_bits; a.mean = l.d_mean; a.bias = l.d_biases;
             a.out = l.skip_f32_out ? nullptr : l.d_output; a.dbg = l.d_debug;
+            a.thr = (l.thr_ok && (net.conv_opts.variant & 256) == 0) ? l.d_thr : nullptr;      // variant bit 8: A/B switch, float epilogue everywhere
             a.out_bits = l.bits_out_slot >= 0 ? ring(l.bits_out_slot) : nullptr;
             if (l.fused_shortcut >= 0) {        // conv_xnor + [shortcut] in one pass (src/additionally.c:326-339)
                 Layer &sc = net.layers[l.fused_shortcut];
@@ -1473,7 +1485,7 @@ int yl_network_set_conv_tile(yl_network *net, int cfg)
 int yl_network_set_variant(yl_network *net, int bits)
 {
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }
-    if (bits < -1 || bits > 255) { set_error("unknown variant bits"); return YL_ERR_ARG; }
+    if (bits < -1 || bits > 511) { set_error("unknown variant bits"); return YL_ERR_ARG; }
     net->net.conv_opts.variant = bits < 0 ? YL_VARIANT_DEFAULT : bits;
     return YL_OK;
 }
@@ -1514,10 +1526,17 @@ int yl_network_set_device_pack(yl_network *net, int on)
 long long yl_debug_layer_packed(yl_network *net, int i, int which, void *dst_host, long long dst_bytes)
 {
     YL_LAYER_OR(YL_ERR_ARG)
-    if (!net->net.on_device || which < 0 || which > 3) { set_error("bad argument / not on device"); return YL_ERR_STATE; }
-    const void *src = which == 0 ? (const void *)l.d_weights_t : which == 1 ? (const void *)l.d_wino32_u
-                    : which == 2 ? (const void *)l.d_weights_i8 : (const void *)l.d_weights_bits;
-    const long long need = src ? (long long)l.packed_bytes[which] : 0;
+    if (!net->net.on_device || which < 0 || which > 6) { set_error("bad argument / not on device"); return YL_ERR_STATE; }
+    const void *src = nullptr;
+    long long need = 0;
+    if (which <= 3) {
+        src = which == 0 ? (const void *)l.d_weights_t : which == 1 ? (const void *)l.d_wino32_u
+            : which == 2 ? (const void *)l.d_weights_i8 : (const void *)l.d_weights_bits;
+        need = src ? (long long)l.packed_bytes[which] : 0;
+    } else if (l.type == YL_CONVOLUTIONAL && l.d_thr) {       // XNOR layers: thresholds (+ the not-a-step count), mean, bias
+        src = which == 4 ? (const void *)l.d_thr : which == 5 ? (const void *)l.d_mean : (const void *)l.d_biases;
+        need = which == 4 ? (long long)sizeof(int) * (l.Mpad + 1) : (long long)sizeof(float) * l.n;
+    }
     if (!dst_host || need == 0) return need;
     if (dst_bytes < need) { set_error("dst too small"); return YL_ERR_ARG; }
     YL_HIP(hipSetDevice(net->net.device));

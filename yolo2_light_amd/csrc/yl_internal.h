@@ -67,6 +67,8 @@ struct Layer {
     float bias_abs_min_nz = 0.f;         //       the host's proof that the exact epilogue's corners cannot occur
     uint64_t *d_weights_bits = nullptr;  // XNOR: [Mpad][taps][Cw] 64-bit words
     float *d_mean = nullptr;
+    int  *d_thr = nullptr;               // XNOR: [Mpad] count thresholds of the sign-only epilogue (+ 1 int: filters without one)
+    bool  thr_ok = false;                //       every filter's result is a step function of the count (else d_thr is not used)
     int   Cw = 0;
     int32_t *d_debug = nullptr;          // xnor counts / int8 acc (debug mode)
     int  *d_tree = nullptr;              // region softmax tree: parent[classes] then group_size[groups]
