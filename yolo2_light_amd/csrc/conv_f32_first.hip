@@ -52,6 +52,25 @@ struct ConvFirstDev {
 
 }  // namespace
 
+// one channel's window of a lane: 3 rows x 6 columns around its four pixels
+__device__ __forceinline__ void first_load_window(float (&win)[3][6], __amdgpu_buffer_rsrc_t rsrc, const int (&voff)[3],
+                                                  const int (&eoff)[3], int soff, bool has_l, bool has_r)
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const s4f v = __builtin_bit_cast(s4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[r], soff, 0));
+        const float e = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, eoff[r], soff, 0));
+        // wave_shr:1 -- lane i takes lane i-1's .w, lane 0 keeps `e`; wave_shl:1 -- lane i takes lane i+1's .x
+        // (element copies first: __builtin_bit_cast applied directly to `v.w` read element 0 with this hipcc)
+        const float vx = v.x, vw = v.w;
+        const float l = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, e), __builtin_bit_cast(int, vw), 0x138, 0xf, 0xf, false));
+        const float rr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, e), __builtin_bit_cast(int, vx), 0x130, 0xf, 0xf, false));
+        win[r][0] = has_l ? l : 0.f;
+        win[r][1] = v.x; win[r][2] = v.y; win[r][3] = v.z; win[r][4] = v.w;
+        win[r][5] = has_r ? rr : 0.f;
+    }
+}
+
 template <int C, int MP, bool Q>
 __global__ __launch_bounds__(256, Q ? 3 : 4) void conv_f32_first_kernel(ConvFirstDev p)
 {
@@ -97,6 +116,16 @@ __global__ __launch_bounds__(256, Q ? 3 : 4) void conv_f32_first_kernel(ConvFirs
 
     unsigned word[4] = {0u, 0u, 0u, 0u};
     const size_t pix = (size_t)oy * p.W + ox0;
+    // The input windows of the lane's four pixels: 3 rows x 6 columns per channel.  RES: loaded ONCE and kept in
+    // registers through all passes (54 values; one exposed memory latency per lane).  The int8-output kernels do not
+    // have the registers for that next to their quantiser (168 + scratch at three waves per SIMD) and re-read 18
+    // values per pass and channel (L1 hits after the first pass).
+    constexpr bool RES = !Q;
+    float wina[RES ? C : 1][3][6];
+    if (RES) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) first_load_window(wina[RES ? c : 0], rsrc, voff, eoff, c * HW * 4, has_l, has_r);
+    }
     unsigned qheld[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};   // bytes 0-7 of the open 16-channel int8 unit
     // Passes of 8 filters: 32 accumulators + 18 window values + two k-rows of 8 weights stay far below the register
     // budget of four waves per SIMD.  The loop is NOT unrolled: one body, MP / 8 trips.
@@ -116,26 +145,14 @@ __global__ __launch_bounds__(256, Q ? 3 : 4) void conv_f32_first_kernel(ConvFirs
         float4 n0 = *reinterpret_cast<const float4 *>(wh), n1 = *reinterpret_cast<const float4 *>(wh + 4);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            // the input window of the lane's four pixels in channel c: 3 rows x 6 columns (re-read per filter half: the
-            // second read hits L1, and 18 live values instead of 54 keep the kernel at four waves per SIMD)
-            float win[3][6];
-            // the channel offset is laundered through an empty asm: otherwise LICM proves the loads invariant in `mh`,
-            // hoists all 54 of them in front of the loop and the allocator spills them (first builds: 0.5-1.2 KB of scratch)
-            int soff = c * HW * 4;
-            asm volatile("" : "+s"(soff));
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const s4f v = __builtin_bit_cast(s4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[r], soff, 0));
-                const float e = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, eoff[r], soff, 0));
-                // wave_shr:1 -- lane i takes lane i-1's .w, lane 0 keeps `e`; wave_shl:1 -- lane i takes lane i+1's .x
-                // (element copies first: __builtin_bit_cast applied directly to `v.w` read element 0 with this hipcc)
-                const float vx = v.x, vw = v.w;
-                const float l = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, e), __builtin_bit_cast(int, vw), 0x138, 0xf, 0xf, false));
-                const float rr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, e), __builtin_bit_cast(int, vx), 0x130, 0xf, 0xf, false));
-                win[r][0] = has_l ? l : 0.f;
-                win[r][1] = v.x; win[r][2] = v.y; win[r][3] = v.z; win[r][4] = v.w;
-                win[r][5] = has_r ? rr : 0.f;
+            if (!RES) {
+                // the channel offset is laundered through an empty asm: otherwise LICM proves the loads invariant in
+                // `mh`, hoists them in front of the pass loop and the kernel is back at 54 resident values
+                int soff = c * HW * 4;
+                asm volatile("" : "+s"(soff));
+                first_load_window(wina[0], rsrc, voff, eoff, soff, has_l, has_r);
             }
+            const float (&win)[3][6] = wina[RES ? c : 0];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
