@@ -303,7 +303,8 @@ int yl_network_set_conv_tile(yl_network *net, int cfg);
  * kernel with all 16 planes of a block in one wave and the output transform in registers, bit 6 (with bit 5) its
  * warp-specialised form (4 matrix waves that only issue MFMAs + 4 staging waves), bit 7 (at yl_network_to_device,
  * without bit 5) the 64-filter x 64-tile 8-wave Winograd kernel for layers with >= 64 filters, bit 8 sign-only XNOR
- * layers evaluate the float epilogue instead of comparing the match count with its threshold; -1 = built-in default */
+ * layers evaluate the float epilogue instead of comparing the match count with its threshold, bit 9 XNOR layers
+ * with >= 64 filters always run 64-filter workgroups (default: 32 on shallow grids); -1 = built-in default */
 int yl_network_set_variant(yl_network *net, int bits);
 /* Opt-in BF16 variant of the FP32 path (north_star (a) "FP32/BF16"; BEFORE yl_network_to_device): every FP32
  * convolution whose input has whole 8-channel groups runs on v_mfma_f32_32x32x16_bf16 with both operands rounded

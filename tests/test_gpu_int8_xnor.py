@@ -43,8 +43,10 @@ XNOR_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("variant", [30, 30 | 512], ids=["ft-by-grid", "ft64"])
 @pytest.mark.parametrize("shape", XNOR_SHAPES)
-def test_conv_xnor_bit_exact(olib, shape):
+def test_conv_xnor_bit_exact(olib, shape, variant):
+    """variant bit 9: 64-filter workgroups wherever the layer has 64 filters (at these sizes the default picks 32)"""
     B, Cc, H, W, M = shape
     rng = np.random.default_rng(77 + Cc + M)
     K = Cc * 9
@@ -57,6 +59,7 @@ def test_conv_xnor_bit_exact(olib, shape):
     x[rng.random(x.shape) < 0.05] = 0.0                       # x == 0 -> bit 0
     d = D.conv(B, W, H, Cc, M, 3, 1, 1, D.LEAKY, wts, bias, xnor=1, mean_arr=mean)
     net = _net_from([d], B, W, H, Cc)
+    net.set_variant(variant)
     got = net.predict(x)
     cnt = net.layer_xnor_counts(0)
     ref = np.zeros_like(got)
@@ -406,6 +409,68 @@ def test_xnor_sign_domain_fusion_is_bit_identical(name, width, height, batch):
     plain.close(); fused.close()
 
 
+XNOR_RAGGED_CFG = """[net]
+batch=1
+subdivisions=1
+width=%d
+height=%d
+channels=3
+[convolutional]
+batch_normalize=1
+filters=16
+size=3
+stride=1
+pad=1
+activation=leaky
+""" + "".join("""[convolutional]
+xnor=1
+batch_normalize=1
+filters=%d
+size=3
+stride=1
+pad=1
+activation=leaky
+""" % m for m in (70, 130, 33, 100, 64)) + """[convolutional]
+size=1
+stride=1
+pad=1
+filters=33
+activation=linear
+[region]
+anchors = 1,1, 2,2, 3,3
+classes=6
+coords=4
+num=3
+softmax=1
+"""
+
+
+@pytest.mark.parametrize("variant", [30, 30 | 512, 30 | 256], ids=["ft-by-grid", "ft64", "float-epilogue"])
+def test_xnor_sign_domain_ragged_filter_counts(variant):
+    """Sign words between XNOR layers whose filter counts are NOT multiples of 64 (70, 130, 33, 100): the bits above
+    the last filter of the last word must be zeros whichever workgroup shape wrote the word (32-filter tiles write
+    half words) -- the next layer counts them against pad weight bits of 1.  Fused == unfused, bit for bit."""
+    import os
+    from yolo2_light_amd import weights as W
+    width, height, batch = 40, 24, 3
+    text = XNOR_RAGGED_CFG % (width, height)
+    cfg = os.path.join(common.workdir(), "xnor-ragged-%dx%d.cfg" % (width, height))
+    open(cfg, "w").write(text)
+    wts = cfg[:-4] + ".weights"
+    W.write_synthetic_weights(text, wts, seed=9)
+    x = common.seeded_input(batch, 3, height, width)
+    plain = Network.load(cfg, wts, batch, 0, device=0)
+    fused = Network.load(cfg, wts, batch, 0, device=0, fuse=True)
+    fused.set_variant(variant)
+    # poison the sign-word ring first: a run of the same network on another image leaves stale words in every slot
+    fused.predict(common.seeded_input(batch, 3, height, width, seed=5))
+    a = plain.predict(x).copy()
+    b = fused.predict(x).copy()
+    assert sum(0 if fused.layer_materialised(i) else 1 for i in range(fused.n)) >= 4
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    plain.close(); fused.close()
+
+
 def test_xnor_sign_thresholds_match_the_float_epilogue():
     """Sign-only XNOR layers compare the match count with a per-filter threshold (conv_xnor.hip).  The thresholds on
     the device must be exactly where fl(fl((2*count - K) * mean) + bias) > 0 switches on, for every filter of every
@@ -433,9 +498,10 @@ def test_xnor_sign_thresholds_match_the_float_epilogue():
     assert seen >= 6
     x = common.seeded_input(2, 3, 96, 96)
     a = net.predict(x).copy()
-    net.set_variant(30 | 256)            # YL_VARIANT_DEFAULT | bit 8
-    b = net.predict(x).copy()
-    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for bits in (256, 512, 256 | 512):   # float epilogue / 64-filter workgroups / both, on top of YL_VARIANT_DEFAULT
+        net.set_variant(30 | bits)
+        b = net.predict(x).copy()
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), bits
     net.close()
 
 

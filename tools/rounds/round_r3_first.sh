@@ -3,7 +3,7 @@
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 O=gpurun_out/r3first; mkdir -p $O
-timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_int8_xnor.py -m gpu -x -q -k "${KSEL:-first or sign_domain}" > $O/pytest_sel.log 2>&1; echo "pytest rc=$?" >> $O/pytest_sel.log
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_int8_xnor.py -m gpu -x -q -k "${KSEL:-xnor}" > $O/pytest_sel.log 2>&1; echo "pytest rc=$?" >> $O/pytest_sel.log
 tail -5 $O/pytest_sel.log
 timeout 300 python bench.py --model tiny-yolo-xnor --size 416 --batch 128 --mode fp32 --no-extras --no-e2e --no-cpu-baseline --layers > $O/bench_xnor.json 2> $O/bench_xnor.err; tail -1 $O/bench_xnor.json | cut -c1-200
 timeout 300 python bench.py --model yolov3-tiny --size 416 --batch 32 --mode fp32 --no-extras --no-e2e --no-cpu-baseline --layers > $O/bench_tiny.json 2> $O/bench_tiny.err; tail -1 $O/bench_tiny.json | cut -c1-200

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void conv_xnor_kernel(ConvXnorDev p)
         uint64_t *dst = p.out_bits + ((size_t)bimg * p.out_Cw + (f0 >> 6)) * p.HW + pix;
         if (FT == 64) *dst = ((uint64_t)sign_hi << 32) | sign_lo;
         else if (p.M <= 32) *dst = (uint64_t)sign_lo;       // the word's only writer: upper half 0, not what an earlier layer left in the ring slot
-        else reinterpret_cast<unsigned *>(dst)[(f0 >> 5) & 1] = sign_lo;      // 32 < M < 64: two filter tiles, half a word each
+        else reinterpret_cast<unsigned *>(dst)[(f0 >> 5) & 1] = sign_lo;      // 32-filter tiles: half a word each
     }
 }
 
@@ -381,7 +381,11 @@ int launch_xnor_thresholds(const float *mean, const float *bias, int *thr, int *
 template <int CWC, int FT, bool W32>
 static int launch_xnor(const ConvXnorDev &d, hipStream_t s)
 {
-    dim3 grid((unsigned)((d.Ntotal + 255) / 256), (unsigned)((d.M + FT - 1) / FT));
+    // 32-filter tiles over more than one tile: always whole output words (both halves of the last sign word are
+    // written -- the upper one as zeros -- whatever an earlier layer left in the ring slot; weights, thresholds
+    // are padded to 64 filters)
+    const int tiles = (FT == 32 && d.M > 32) ? 2 * ((d.M + 63) / 64) : (d.M + FT - 1) / FT;
+    dim3 grid((unsigned)((d.Ntotal + 255) / 256), (unsigned)tiles);
     hipLaunchKernelGGL((conv_xnor_kernel<CWC, FT, W32>), grid, dim3(256), 0, s, d);
     return (int)hipGetLastError();
 }
@@ -398,9 +402,17 @@ int launch_conv_xnor(const ConvXnorArgs &a, void *stream)
     if (nt > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     d.Ntotal = (int)nt;
     hipStream_t s = (hipStream_t)stream;
-    // weights are padded to a multiple of 64 filters (runtime.hip), FT must divide that
-    if (a.C <= 32) return (a.M >= 64) ? launch_xnor<1, 64, true>(d, s) : launch_xnor<1, 32, true>(d, s);
-    return (a.M >= 64) ? launch_xnor<1, 64, false>(d, s) : launch_xnor<1, 32, false>(d, s);
+    // weights are padded to a multiple of 64 filters (runtime.hip), FT must divide that.
+    // Filter tile: 64 where the grid is deep, 32 where it is shallow.  A 64-filter workgroup occupies 5 wave slots per
+    // SIMD (86-95 VGPRs); tiny-yolo's 13 x 13 x 1024 layers at batch 128 are 1 360 such workgroups = 5.3 per CU, so
+    // 80 of the 256 CUs ran a sixth workgroup alone after the other five had finished: 0.70-0.73 of the popcount
+    // roof on the two layers that hold 40 % of the bit work.  Half-size tiles (7-8 slots) balance: the input words
+    // are fetched twice (9 loads per 1 152 VALU instructions instead of per 2 304), two workgroups write one half
+    // of an output sign word each.
+    const long long wg64 = (long long)((d.Ntotal + 255) / 256) * ((a.M + 63) / 64);
+    const bool ft32 = a.M < 64 || (a.ft_mode == 0 && wg64 < 16 * 256) || a.ft_mode == 32;
+    if (a.C <= 32) return !ft32 ? launch_xnor<1, 64, true>(d, s) : launch_xnor<1, 32, true>(d, s);
+    return !ft32 ? launch_xnor<1, 64, false>(d, s) : launch_xnor<1, 32, false>(d, s);
 }
 
 }  // namespace yl

@@ -48,7 +48,8 @@ struct ConvF32Opts {
     // plane-split kernel, bit 6 (with bit 5) its warp-specialised form: 4 matrix + 4 staging waves, one workgroup
     // per CU, bit 7 (read at upload, without bit 5, layers with >= 64 filters) the 64-filter x 64-tile 8-wave kernel
     // (conv_f32_wino64.hip), bit 8 XNOR layers between XNOR layers keep the float epilogue instead of the count
-    // threshold (conv_xnor.hip; same bits either way).  (An 8-byte-access epilogue for odd map widths was measured and dropped: no gain,
+    // threshold (conv_xnor.hip; same bits either way), bit 9 XNOR layers always use 64-filter workgroups where the layer
+    // has 64 filters (default: 32-filter workgroups on shallow grids).  (An 8-byte-access epilogue for odd map widths was measured and dropped: no gain,
     // profiles/r2_ab_fp32_variants.txt.)
     int variant = YL_VARIANT_DEFAULT;
 };
@@ -143,6 +144,7 @@ struct ConvXnorArgs {
     const int *thr = nullptr; // optional [Mpad] count thresholds (launch_xnor_thresholds): sign of the result = (count >= thr[m])
     int B, C, Cw, H, W, M, Mpad;
     int act;
+    int ft_mode = 0;          // filters per workgroup: 0 = by grid depth, 64 / 32 = forced (A/B runs, tests)
 };
 int launch_conv_xnor(const ConvXnorArgs &a, void *stream);
 // thr[m] = the smallest match count whose result (2*count - K) * mean[m] + bias[m] is > 0 (K + 1 if none), m < M;

@@ -752,6 +752,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
                 a.out = nullptr;
             }
             a.B = B; a.C = l.c; a.Cw = l.Cw; a.H = l.h; a.W = l.w; a.M = l.n; a.Mpad = l.Mpad; a.act = kernel_act;
+            a.ft_mode = (net.conv_opts.variant & 512) ? 64 : 0;
             YL_LAUNCH(launch_conv_xnor(a, s), "conv_xnor");
             snprintf(l.kernel_name, sizeof(l.kernel_name), "conv_xnor");
         }
@@ -1485,7 +1486,7 @@ int yl_network_set_conv_tile(yl_network *net, int cfg)
 int yl_network_set_variant(yl_network *net, int bits)
 {
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }
-    if (bits < -1 || bits > 511) { set_error("unknown variant bits"); return YL_ERR_ARG; }
+    if (bits < -1 || bits > 1023) { set_error("unknown variant bits"); return YL_ERR_ARG; }
     net->net.conv_opts.variant = bits < 0 ? YL_VARIANT_DEFAULT : bits;
     return YL_OK;
 }
