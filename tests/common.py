@@ -448,6 +448,26 @@ def oracle_boxes(net_or_heads, image: int, w: int, h: int, thresh: float, nms: f
     return rows[:min(n, max_rows)].copy()
 
 
+def require_ref(fast: bool = False, hip: bool = False) -> None:
+    """GPU tests that compare against the reference-built libraries (oracle/_ref, built in the container where
+    /root/reference exists and shipped with the gpurun snapshot): on a GPU box a missing library is a FAILURE -- the
+    parity gate must not silently turn into a skip -- and a skip only where there is no GPU at all."""
+    import pytest
+    missing = []
+    if not refbind.available():
+        missing.append(refbind.GOLD)
+    if fast and not refbind.available(fast=True):
+        missing.append(refbind.FAST)
+    if hip and not os.path.exists(refbind.HIP):
+        missing.append(refbind.HIP)
+    if not missing:
+        return
+    msg = "reference-built libraries missing: %s (run `make -C oracle` where /root/reference exists)" % ", ".join(missing)
+    if have_gpu():
+        pytest.fail(msg)
+    pytest.skip(msg)
+
+
 def have_gpu() -> bool:
     from yolo2_light_amd._lib import lib
     return lib.yl_device_count() > 0

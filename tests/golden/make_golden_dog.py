@@ -10,6 +10,14 @@ Everything is produced by the REFERENCE ITSELF (oracle/_ref/libyolo2ref.so = its
   fp32 / int8   network_predict_cpu / network_predict_quantized on that tensor with the deterministic
                 synthetic weights (no trained weights exist offline): float64 sum / abs-sum of every layer
                 output, and the detections of src/main.c:228-229 (thresh .24, nms .4)
+
+`python tests/golden/make_golden_dog.py xnor` writes the second fixture, dog_tiny-yolo-xnor_416.npz: the photo through
+bin/tiny-yolo-obj_xnor.cfg's topology (BASELINE config 5's network) on the reference CPU path
+(src/yolov2_forward_network.c:116-203, the XNOR branch).  north_star wants the XNOR work BIT-exact on dog.jpg, and
+the FP32 first layer in front of it is not (summation order), so besides layer sums and detections the fixture holds,
+for each of the 7 XNOR convolutions, the sign bits (x > 0, src/additionally.c:132) of the tensor the REFERENCE fed
+it and the sha256 of the tensor the reference got out: a GPU run of that layer on those bits must reproduce the
+hash (tests/test_gpu_headline.py::test_dog_jpg_xnor_layers_bit_exact_against_the_reference_fixture).
 """
 import ctypes as C
 import hashlib
@@ -69,5 +77,42 @@ def main():
     print(out, os.path.getsize(out), "bytes")
 
 
+def main_xnor():
+    lib = refbind._bind(refbind.GOLD)
+    sized, sw, sh = load_resized(lib, DOG, W, H)
+    name = "tiny-yolo-xnor"
+    cfg, wts = common.model_files(name, W, H)
+    ref = refbind.RefNetwork(cfg, wts, 1, 0)
+    ref.predict(sized[None])
+    keep = {}
+    sums = np.zeros((ref.n, 2), np.float64)
+    xnor_layers = []
+    for i in range(ref.n):
+        o = ref.layer_output(i)
+        sums[i] = (o.astype(np.float64).sum(), np.abs(o.astype(np.float64)).sum())
+        li = ref.layer_info(i)
+        if li["type"] == common.CONV and li["xnor"] and li["size"] == 3 and li["stride"] == 1 and li["pad"] == 1:
+            src = ref.layer_output(i - 1)
+            assert src.size == li["c"] * li["h"] * li["w"]
+            keep["in_bits_%d" % i] = np.packbits(src > 0)              # bit = (x > 0), CHW order
+            keep["out_sha256_%d" % i] = np.array(hashlib.sha256(o.tobytes()).hexdigest())
+            xnor_layers.append(i)
+    keep["xnor_layers"] = np.array(xnor_layers)
+    keep["layer_sums"] = sums
+    for key, thresh in (("dets", 0.24), ("dets_low", LOW_THRESH)):
+        keep[key] = ref.get_detections(0, sw, sh, thresh, nms=0.4, relative=1)
+        print(key, len(keep[key]), "detections at thresh", thresh)
+    out = os.path.join(HERE, "dog", "dog_tiny-yolo-xnor_416.npz")
+    np.savez_compressed(out, src_wh=np.array([sw, sh]),
+                        sized_sha256=np.array(hashlib.sha256(sized.tobytes()).hexdigest()),
+                        low_thresh=np.array(LOW_THRESH),
+                        weights_sha256=np.array(hashlib.sha256(open(wts, "rb").read()).hexdigest()), **keep)
+    print(out, os.path.getsize(out), "bytes; xnor layers", xnor_layers)
+
+
 if __name__ == "__main__":
-    main()
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("tiny", "all"):
+        main()
+    if what in ("xnor", "all"):
+        main_xnor()

@@ -144,3 +144,29 @@ def test_dog_fixture_front_end(olib):
     sized = common.oracle_load_resized(olib, pixels, 416, 416)
     assert hashlib.sha256(sized.tobytes()).hexdigest() == str(z["sized_sha256"])
     assert len(z["fp32_dets_low"]) > 100 and z["fp32_dets_low"].shape[1] == 86
+
+
+def test_oracle_reproduces_the_reference_xnor_layers_on_dog_jpg(olib):
+    """tests/golden/dog/dog_tiny-yolo-xnor_416.npz (make_golden_dog.py xnor): for each of the 7 XNOR convolutions the
+    fixture holds the sign bits of the tensor the REFERENCE CPU path fed it on dog.jpg and the sha256 of what the
+    reference got out.  The oracle restatement on +-1 inputs with those signs reproduces every hash -- the same
+    statement tests/test_gpu_headline.py makes for the HIP kernel."""
+    import ctypes as C
+    z = np.load(os.path.join(common.GOLDEN_DIR, "dog", "dog_tiny-yolo-xnor_416.npz"))
+    cfg, wts = common.model_files("tiny-yolo-xnor", 416, 416)
+    assert hashlib.sha256(open(wts, "rb").read()).hexdigest() == str(z["weights_sha256"])
+    model = Network.load(cfg, wts, 1, 0)
+    layers = [int(i) for i in z["xnor_layers"]]
+    assert layers == [2, 4, 6, 8, 10, 12, 13]
+    for i in layers:
+        li = model.layer_info(i)
+        n_in = li["c"] * li["h"] * li["w"]
+        bits = np.unpackbits(z["in_bits_%d" % i])[:n_in].astype(bool)
+        x = np.where(bits, np.float32(1.0), np.float32(-1.0))
+        ref = np.zeros(li["outputs"], np.float32)
+        cnt = np.zeros(li["outputs"], np.int32)
+        olib.oracle_conv_xnor(common.fp(x), common.fp(model.layer_weights(i)), common.fp(model.layer_mean_arr(i)),
+                              common.fp(model.layer_biases(i)), common.fp(ref), cnt.ctypes.data_as(C.POINTER(C.c_int32)),
+                              1, li["c"], li["h"], li["w"], li["n"], li["activation"])
+        assert hashlib.sha256(ref.tobytes()).hexdigest() == str(z["out_sha256_%d" % i]), "XNOR layer %d" % i
+    model.close()

@@ -13,8 +13,12 @@ import pytest
 import common
 from common import refbind, fp32_close
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.path.exists(refbind.HIP), reason="oracle/_ref/libyolo2ref_hip.so not built")]
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _needs_the_drop_in_library():
+    common.require_ref(hip=True)        # a failure on a GPU box, a skip only without a GPU
 
 
 def _heads(ref):

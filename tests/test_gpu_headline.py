@@ -12,6 +12,11 @@
   * dog.jpg (config 1): the reference's decoded photo -> GPU front end -> yolov3-tiny 416 against the
     fixture the reference CPU path produced (tests/golden/make_golden_dog.py), and through the
     reference's own host code + network_predict_hip when oracle/_ref is present.
+  * yolov3-tiny 416 batch 32 (config 2) and tiny-yolo-xnor 416 batch 128 (config 5), as bench.py's side legs run
+    them, against batch-1 runs, bit for bit; the kernel instances the bench line names are asserted.
+  * dog.jpg through the XNOR network (config 5's topology): detections against the reference CPU path's, every layer
+    teacher-forced against the oracle, and each XNOR convolution on the sign bits the REFERENCE fed it reproduces
+    the sha256 of what the reference got out (bit-exact against the reference itself, no oracle in between).
 """
 import ctypes as C
 import hashlib
@@ -34,8 +39,25 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 
-def _batch64_equals_batch1(quantized):
-    name, size, B = "yolov3", 608, 64
+def _dominant_kernel(net, quantized):
+    """the kernel instance bench.py's roofline block calls dominant (most algorithmic FLOPs; conv_xnor's template
+    instances count as one kernel there)"""
+    flops = {}
+    for i, li in enumerate(net.layers()):
+        if li["type"] == common.CONV:
+            k = net.layer_kernel(i)
+            if quantized and not k.startswith("conv_i8"):
+                continue
+            if k.startswith("conv_xnor"):
+                k = "conv_xnor"
+            flops[k] = flops.get(k, 0.0) + 2.0 * li["n"] * li["size"] ** 2 * li["c"] * li["out_h"] * li["out_w"]
+    return max(flops, key=flops.get)
+
+
+def _big_batch_equals_batch1(name, size, B, quantized, images, min_checked, dets_range=(50, 4096), expect_kernels=None):
+    """the benched configuration (fusion on, batch B) against batch-1 runs of the same images, bit for bit on every
+    materialised tensor and on the detection rows; then fused == unfused at batch 1 (the unfused run is what
+    tests/test_gpu_parity.py / test_gpu_int8_xnor.py pin to the oracle and the reference library)"""
     cfg, wts = common.model_files(name, size, size)
     x = common.seeded_input(B, 3, size, size)
     big = Network.load(cfg, wts, B, quantized, device=0, fuse=True)
@@ -43,20 +65,17 @@ def _batch64_equals_batch1(quantized):
     # the kernel instance bench.py's roofline block will call dominant at this configuration must have its committed
     # PMC traffic entry (profiles/pmc_traffic.json): a renamed or re-tiled kernel fails HERE, not as `traffic: null`
     import json
-    flops = {}
-    for i, li in enumerate(big.layers()):
-        if li["type"] == common.CONV:
-            k = big.layer_kernel(i)
-            if quantized and not k.startswith("conv_i8"):
-                continue
-            flops[k] = flops.get(k, 0.0) + 2.0 * li["n"] * li["size"] ** 2 * li["c"] * li["out_h"] * li["out_w"]
-    dominant = max(flops, key=flops.get)
+    dominant = _dominant_kernel(big, quantized)
+    key = dominant if (name == "yolov3" and size == 608) else "%s@%s-%d" % (dominant, name, size)
     with open(os.path.join(common.ROOT, "profiles", "pmc_traffic.json")) as f:
-        assert dominant in json.load(f), "no PMC traffic entry for the dominant kernel %r" % dominant
+        assert key in json.load(f), "no PMC traffic entry for the dominant kernel %r" % key
+    for i, want in (expect_kernels or {}).items():
+        assert big.layer_kernel(i) == want, "layer %d runs %r at batch %d, the bench line is quoted on %r" % (
+            i, big.layer_kernel(i), B, want)
     one = Network.load(cfg, wts, 1, quantized, device=0, fuse=True)
     plain = Network.load(cfg, wts, 1, quantized, device=0, fuse=False)
     n_checked = 0
-    for b in IMAGES:
+    for b in images:
         one.predict(x[b:b + 1])
         for i in range(one.n):
             if not one.layer_materialised(i):
@@ -64,29 +83,64 @@ def _batch64_equals_batch1(quantized):
                 continue
             a = big.layer_output_image(i, b)
             r = one.layer_output(i)
-            assert np.array_equal(_bits(a), _bits(r)), "image %d layer %d %r: batch-64 != batch-1" % (b, i, one.layer_info(i))
+            assert np.array_equal(_bits(a), _bits(r)), "image %d layer %d %r: batch-%d != batch-1" % (b, i, one.layer_info(i), B)
             n_checked += 1
-        rows64 = big.get_boxes(b, size, size, 0.24, nms=0.4)
+        rows_big = big.get_boxes(b, size, size, 0.24, nms=0.4)
         rows1 = one.get_boxes(0, size, size, 0.24, nms=0.4)
-        assert rows64.shape == rows1.shape and np.array_equal(_bits(rows64), _bits(rows1)), "image %d detection rows" % b
+        assert rows_big.shape == rows1.shape and np.array_equal(_bits(rows_big), _bits(rows1)), "image %d detection rows" % b
         # the untrained head passes thousands of cells at .24 (a dense set): it must stay below the device
         # path's capacity for the order to be defined
-        assert 50 < len(rows1) < 4096
-    # fused == unfused at batch 1 (the unfused FP32 run is what is pinned to the reference library)
-    plain.predict(x[IMAGES[-1]:IMAGES[-1] + 1])
+        assert dets_range[0] < len(rows1) < dets_range[1], len(rows1)
+    # fused == unfused at batch 1 (the unfused run is what is pinned to the reference library)
+    plain.predict(x[images[-1]:images[-1] + 1])
+    n_fused = 0
     for i in range(one.n):
         if one.layer_materialised(i):
             assert np.array_equal(_bits(plain.layer_output(i)), _bits(one.layer_output(i))), "fused != unfused, layer %d" % i
-    assert n_checked > 3 * (40 if quantized else 60)
+        else:
+            n_fused += 1
+    assert n_checked >= min_checked, n_checked
     big.close(); one.close(); plain.close()
+    return n_fused
 
 
 def test_yolov3_608_batch64_fp32_fused_equals_batch1():
-    _batch64_equals_batch1(0)
+    _big_batch_equals_batch1("yolov3", 608, 64, 0, IMAGES, 3 * 60 + 1)
 
 
 def test_yolov3_608_batch64_int8_fused_equals_batch1():
-    _batch64_equals_batch1(1)
+    _big_batch_equals_batch1("yolov3", 608, 64, 1, IMAGES, 3 * 40 + 1)
+
+
+def test_yolov3_tiny_416_batch32_fp32_fused_equals_batch1():
+    """BASELINE config 2 as bench.py's side leg runs it (yolov3-tiny 416, batch 32, fusion on): images 0 / 15 / 31."""
+    _big_batch_equals_batch1("yolov3-tiny", 416, 32, 0, (0, 15, 31), 3 * 12)
+
+
+def test_tiny_yolo_xnor_416_batch128_fused_equals_batch1():
+    """BASELINE config 5 as bench.py's side leg runs it (tiny-yolo-obj_xnor 416, batch 128, sign-domain fusion on):
+    images 0 / 64 / 127.  conv_xnor's filter tile is chosen by GRID depth (conv_xnor.hip, launch_conv_xnor): at batch
+    128 the 208 x 208 and 104 x 104 layers run 64-filter workgroups where the layer has 64 filters and the
+    13 x 13 layers 32-filter ones; at batch 1 everything runs 32-filter tiles -- so this is also 64-filter == 32-filter
+    tiles on the whole network.  XNOR arithmetic is integer: bit for bit, no tolerance (north_star)."""
+    cfg, _ = common.model_files("tiny-yolo-xnor", 416, 416)
+    probe = Network.from_cfg(cfg, 1, 0)
+    xnor_layers = [i for i, li in enumerate(probe.layers()) if li["type"] == common.CONV and li["xnor"]]
+    infos = probe.layers()
+    probe.close()
+    assert len(xnor_layers) == 7
+    expect = {}
+    for i in xnor_layers:
+        li = infos[i]
+        wg64 = -(-128 * li["h"] * li["w"] // 256) * -(-li["n"] // 64)
+        ft = 32 if (li["n"] < 64 or wg64 < 16 * 256) else 64
+        expect[i] = "conv_xnor<ft%d,%s,thr>" % (ft, "w32" if li["c"] <= 32 else "w64")
+    # the layer in front of the region head's linear conv feeds an FP32 conv: float epilogue, no thresholds
+    expect[xnor_layers[-1]] = expect[xnor_layers[-1]].replace(",thr", "")
+    assert any("ft64" in v for v in expect.values()) and any("ft32" in v for v in expect.values())
+    n_fused = _big_batch_equals_batch1("tiny-yolo-xnor", 416, 128, 0, (0, 64, 127), 3 * 3, dets_range=(0, 4096),
+                                       expect_kernels=expect)
+    assert n_fused >= 8          # the sign domain really was on: FP32 tensors between the bit layers never existed
 
 
 def test_yolov3_608_int8_every_layer_teacher_forced(olib):
@@ -201,12 +255,12 @@ def test_dog_jpg_fp32_against_the_reference_cpu_fixture():
     net.close()
 
 
-@pytest.mark.skipif(not os.path.exists(refbind.HIP), reason="oracle/_ref/libyolo2ref_hip.so not built")
 @pytest.mark.parametrize("quantized", [0, 1])
 def test_dog_jpg_reference_host_code_cpu_vs_hip(quantized):
     """src/main.c:187-229 on the photo: load_image + resize_image (fixture pixels through the pinned
     oracle front end = the reference's sized.data), then network_predict_cpu / _quantized vs
     network_predict_hip on the SAME network object, then the reference's own get_network_boxes + do_nms_sort."""
+    common.require_ref(hip=True)
     z = np.load(DOG)
     sw, sh = (int(v) for v in z["src_wh"])
     name, W, H = "yolov3-tiny", 416, 416
@@ -239,3 +293,102 @@ def test_dog_jpg_reference_host_code_cpu_vs_hip(quantized):
         frac, _ = _match_rows(cpu_dets, hip_dets)
         assert frac > 0.98
     ref.lib.ref_free_hip()
+
+
+# ---------------------------------------------------------------------------- dog.jpg through the XNOR network
+DOG_XNOR = os.path.join(common.GOLDEN_DIR, "dog", "dog_tiny-yolo-xnor_416.npz")
+
+
+def _dog_sized_on_gpu(net):
+    z = np.load(DOG)
+    net.set_input_u8(0, z["pixels"])
+    sized = net.input_download()
+    assert hashlib.sha256(sized.tobytes()).hexdigest() == str(z["sized_sha256"])
+    return sized
+
+
+def test_dog_jpg_xnor_network_against_the_reference_cpu_fixture():
+    """src/main.c:187-229 with bin/tiny-yolo-obj_xnor.cfg's topology: photo -> GPU front end -> FP32 first layer ->
+    7 XNOR convolutions -> region head, against what the reference CPU path produced for the same photo and weights.
+    End to end the comparison is tolerant (a last-bit difference of the FP32 first layer can flip a sign bit); the
+    bit-exact statements are the two tests below."""
+    z = np.load(DOG_XNOR)
+    sw, sh = (int(v) for v in z["src_wh"])
+    name, W, H = "tiny-yolo-xnor", 416, 416
+    cfg, wts = common.model_files(name, W, H)
+    assert hashlib.sha256(open(wts, "rb").read()).hexdigest() == str(z["weights_sha256"]), "synthetic weights changed"
+    net = Network.load(cfg, wts, 1, 0, device=0)
+    _dog_sized_on_gpu(net)
+    net.forward_staged()
+    net.synchronize()
+    sums = z["layer_sums"]
+    worst = 0.0
+    for i in range(net.n):
+        o = net.layer_output(i).astype(np.float64)
+        worst = max(worst, abs(o.sum() - sums[i, 0]) / (sums[i, 1] + 1e-6), abs(np.abs(o).sum() - sums[i, 1]) / (sums[i, 1] + 1e-6))
+        assert abs(o.sum() - sums[i, 0]) <= 1e-3 * sums[i, 1] + 1e-6, "layer %d sum" % i
+        assert abs(np.abs(o).sum() - sums[i, 1]) <= 1e-3 * sums[i, 1] + 1e-6, "layer %d abs-sum" % i
+    print("dog.jpg xnor: worst layer-sum deviation / abs-sum = %.3g" % worst)
+    rows = {}
+    for key, thresh in (("dets", 0.24), ("dets_low", float(z["low_thresh"]))):
+        r = z[key]
+        g = net.get_boxes(0, sw, sh, thresh, nms=0.4)
+        rows[key] = g
+        assert abs(len(r) - len(g)) <= max(2, len(r) // 50), (key, len(r), len(g))
+        frac, m = _match_rows(r, g)
+        assert frac > 0.98, (key, frac)
+        if m is not None:
+            ok, j = m
+            np.testing.assert_allclose(g[j[ok]][:, 4], r[ok][:, 4], rtol=1e-3, atol=1e-5)
+    assert len(z["dets"]) > 100
+    net.close()
+    # the benched form (sign-domain fusion on) returns the same rows, bit for bit
+    fused = Network.load(cfg, wts, 1, 0, device=0, fuse=True)
+    _dog_sized_on_gpu(fused)
+    fused.forward_staged()
+    fused.synchronize()
+    g = fused.get_boxes(0, sw, sh, 0.24, nms=0.4)
+    assert g.shape == rows["dets"].shape and np.array_equal(_bits(g), _bits(rows["dets"]))
+    fused.close()
+
+
+def test_dog_jpg_xnor_every_layer_teacher_forced(olib):
+    """every layer of the XNOR network on the photo against the oracle applied to the GPU's own input of that layer:
+    match counts and outputs of the 7 XNOR convolutions, max-pools and the region layout bit-exact"""
+    from test_gpu_int8_xnor import _teacher_forced
+    z = np.load(DOG)
+    sized = common.oracle_load_resized(olib, z["pixels"], 416, 416)
+    assert hashlib.sha256(sized.tobytes()).hexdigest() == str(z["sized_sha256"])
+    stats = _teacher_forced(olib, "tiny-yolo-xnor", 416, 416, 1, 0, x=sized[None])
+    assert stats["exact"] >= 7 + 6, stats
+
+
+def test_dog_jpg_xnor_layers_bit_exact_against_the_reference_fixture():
+    """Each XNOR convolution of the network, alone, on the sign bits the REFERENCE CPU path fed it for dog.jpg
+    (fixture, tests/golden/make_golden_dog.py xnor): the output tensor's sha256 equals the reference's.  The bit path
+    reads nothing but signs (src/yolov2_forward_network.c:116-203), so +-1 stands for the reference's tensor."""
+    import descs as D
+    z = np.load(DOG_XNOR)
+    name, W, H = "tiny-yolo-xnor", 416, 416
+    cfg, wts = common.model_files(name, W, H)
+    assert hashlib.sha256(open(wts, "rb").read()).hexdigest() == str(z["weights_sha256"]), "synthetic weights changed"
+    model = Network.load(cfg, wts, 1, 0)            # host side only: fused weights, biases, mean_arr
+    layers = [int(i) for i in z["xnor_layers"]]
+    assert len(layers) == 7
+    for i in layers:
+        li = model.layer_info(i)
+        n_in = li["c"] * li["h"] * li["w"]
+        bits = np.unpackbits(z["in_bits_%d" % i])[:n_in].astype(bool)
+        x = np.where(bits, np.float32(1.0), np.float32(-1.0)).reshape(1, li["c"], li["h"], li["w"])
+        d = D.conv(1, li["w"], li["h"], li["c"], li["n"], 3, 1, 1, li["activation"], model.layer_weights(i),
+                   model.layer_biases(i), xnor=1, mean_arr=model.layer_mean_arr(i))
+        for variant in (30, 30 | 512):            # filter tile by grid depth (32 at batch 1) / 64-filter workgroups
+            net = Network.from_desc([d], 1, li["w"], li["h"], li["c"], 0)
+            net.set_variant(variant)
+            net.to_device(0)
+            got = net.predict(x)
+            assert hashlib.sha256(np.ascontiguousarray(got, dtype=np.float32).tobytes()).hexdigest() == str(z["out_sha256_%d" % i]), \
+                "XNOR layer %d (%dx%d, %d -> %d) differs from the reference CPU path on dog.jpg (variant %d)" % (
+                    i, li["w"], li["h"], li["c"], li["n"], variant)
+            net.close()
+    model.close()

@@ -121,10 +121,12 @@ def test_conv_int8_bit_exact(olib, shape, tile):
 # ----------------------------------------------------------------------------
 # teacher-forced whole networks
 # ----------------------------------------------------------------------------
-def _teacher_forced(olib, name, width, height, batch, quantized):
+def _teacher_forced(olib, name, width, height, batch, quantized, x=None):
     cfg, wts = common.model_files(name, width, height)
     net = Network.load(cfg, wts, batch, quantized, device=0, debug=True)
-    x = common.seeded_input(batch, 3, height, width)
+    if x is None:
+        x = common.seeded_input(batch, 3, height, width)
+    x = np.ascontiguousarray(x, dtype=np.float32)
     net.predict(x)
     infos = net.layers()
     outs = [net.layer_output(i) for i in range(net.n)]
@@ -207,10 +209,10 @@ def test_network_teacher_forced(olib, name, width, height, batch, quantized):
     assert stats["exact"] > 0
 
 
-@pytest.mark.skipif(not common.refbind.available(), reason="oracle/_ref not built")
 def test_int8_network_vs_reference_library_batch1():
     """-quantized yolov3-tiny 416 against network_predict_quantized of the reference itself
     (which handles batch item 0 only): final detections agree."""
+    common.require_ref()
     name, width, height = "yolov3-tiny", 416, 416
     cfg, wts = common.model_files(name, width, height)
     ref = common.refbind.RefNetwork(cfg, wts, 1, 1)

@@ -188,7 +188,7 @@ def test_conv_winograd_vs_oracle(olib, shape, kernel):
 
 def test_winograd_switch_off_keeps_direct_kernel():
     rng = np.random.default_rng(1)
-    B, Cc, H, W, M = 1, 64, 12, 12, 64          # the heuristic takes Winograd from 64 input channels up
+    B, Cc, H, W, M = 1, 64, 12, 12, 64          # the heuristic takes Winograd from 32 input channels up
     wts = rng.normal(0, 0.05, M * Cc * 9).astype(np.float32)
     d = D.conv(B, W, H, Cc, M, 3, 1, 1, D.LEAKY, wts, np.zeros(M, np.float32))
     x = rng.standard_normal((B, Cc, H, W)).astype(np.float32)
@@ -351,10 +351,10 @@ def test_network_every_layer_vs_oracle(olib, name, width, height, batch):
     net.close()
 
 
-@pytest.mark.skipif(not refbind.available(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("name,width,height,batch", [("yolov3-tiny", 416, 416, 2), ("yolov3", 608, 608, 1)])
 def test_full_size_vs_reference_library(name, width, height, batch):
     """BASELINE configs at full resolution against the unmodified reference CPU path."""
+    common.require_ref()
     cfg, wts = common.model_files(name, width, height)
     ref = refbind.RefNetwork(cfg, wts, batch, 0)
     net = Network.load(cfg, wts, batch, 0, device=0)
@@ -368,9 +368,13 @@ def test_full_size_vs_reference_library(name, width, height, batch):
         ok, ratio, worst = fp32_close(got, want)
         assert ok, "layer %d %r: err/allowed %.3g at %d (got %r ref %r)" % (
             i, net.layer_info(i), ratio, worst, got[worst], want[worst])
-        # the pure relative error (no RMS-tied floor) over everything above 1 % of the layer RMS: reported only --
-        # what bounds it is measured against a float64 ground truth in test_fp32_error_vs_float64_truth below
-        worst_strict = max(worst_strict, common.strict_max_rel(got, want))
+        # the pure relative error (no RMS-tied floor) over everything above 1 % of the layer RMS: a hard per-layer
+        # bound against the reference (measured 3.6e-3 at 608, 1.3e-3 at 416: cancellation results just above the 1 %
+        # floor); the tight statement is measured against a float64 ground truth in
+        # test_fp32_error_vs_float64_truth below -- an addition to this bound, not a replacement
+        strict = common.strict_max_rel(got, want)
+        assert strict <= 2e-2, "layer %d %r: strict max relative error %.3g vs the reference" % (i, net.layer_info(i), strict)
+        worst_strict = max(worst_strict, strict)
         worst_ratio = max(worst_ratio, ratio)
     print("%s %dx%d: worst fp32_close ratio %.3g, worst strict max-rel %.3g over %d layers" % (
         name, width, height, worst_ratio, worst_strict, net.n))
@@ -397,7 +401,6 @@ def test_full_size_vs_reference_library(name, width, height, batch):
     net.close()
 
 
-@pytest.mark.skipif(not (refbind.available() and refbind.available(fast=True)), reason="oracle/_ref not built")
 @pytest.mark.parametrize("name,width,height", [("yolov3-tiny", 416, 416), ("yolov3", 608, 608)])
 def test_fp32_error_vs_float64_truth(name, width, height):
     """The FP32 contract on measured footing.  Summation order is the only freedom an FP32
@@ -407,6 +410,7 @@ def test_fp32_error_vs_float64_truth(name, width, height):
     reference's two builds, per layer, in relative RMS error and in the largest error (in units of the layer RMS).
     At the heads, element by element under north_star's 1e-4 relative tolerance: the HIP path is within it at least
     as often as the reference's worse build.  (Measured: profiles/r3_parity_layers_yolov3_608_b1_vs_float64_truth.txt.)"""
+    common.require_ref(fast=True)
     batch = 1
     cfg, wts = common.model_files(name, width, height)
     x = common.seeded_input(batch, 3, height, width)

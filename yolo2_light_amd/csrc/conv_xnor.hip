@@ -23,6 +23,7 @@
 // filters are accumulated; count = #matching bits is integer-exact.
 //   out = act( (2*count - K) * mean[f] + bias[f] ),  K = 9*C   (src/additionally.c:1531)
 #include <hip/hip_runtime.h>
+#include <cstdio>
 
 #include "kernels.h"
 #include "../../include/yolo2_hip.h"
@@ -390,7 +391,7 @@ static int launch_xnor(const ConvXnorDev &d, hipStream_t s)
     return (int)hipGetLastError();
 }
 
-int launch_conv_xnor(const ConvXnorArgs &a, void *stream)
+int launch_conv_xnor(const ConvXnorArgs &a, void *stream, char *name, size_t name_len)
 {
     ConvXnorDev d;
     d.in_bits = a.in_bits; d.w_bits = a.w_bits; d.mean = a.mean; d.bias = a.bias; d.out = a.out; d.dbg = a.dbg;
@@ -411,6 +412,8 @@ int launch_conv_xnor(const ConvXnorArgs &a, void *stream)
     // of an output sign word each.
     const long long wg64 = (long long)((d.Ntotal + 255) / 256) * ((a.M + 63) / 64);
     const bool ft32 = a.M < 64 || (a.ft_mode == 0 && wg64 < 16 * 256) || a.ft_mode == 32;
+    if (name) snprintf(name, name_len, "conv_xnor<ft%d,%s%s>", ft32 ? 32 : 64, a.C <= 32 ? "w32" : "w64",
+                       (a.thr && !a.out && !a.add && !a.dbg) ? ",thr" : "");      // ",thr": the count-threshold epilogue really runs
     if (a.C <= 32) return !ft32 ? launch_xnor<1, 64, true>(d, s) : launch_xnor<1, 32, true>(d, s);
     return !ft32 ? launch_xnor<1, 64, false>(d, s) : launch_xnor<1, 32, false>(d, s);
 }

@@ -146,7 +146,8 @@ struct ConvXnorArgs {
     int act;
     int ft_mode = 0;          // filters per workgroup: 0 = by grid depth, 64 / 32 = forced (A/B runs, tests)
 };
-int launch_conv_xnor(const ConvXnorArgs &a, void *stream);
+// writes the kernel instance name (filter tile, word width, threshold epilogue) into name[name_len] when name != nullptr
+int launch_conv_xnor(const ConvXnorArgs &a, void *stream, char *name = nullptr, size_t name_len = 0);
 // thr[m] = the smallest match count whose result (2*count - K) * mean[m] + bias[m] is > 0 (K + 1 if none), m < M;
 // INT_MAX for the pad filters; *bad (device int, zeroed by the caller) counts filters whose result is NOT a step
 // function of the count (then thr must not be used)

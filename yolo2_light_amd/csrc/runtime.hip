@@ -753,8 +753,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
             }
             a.B = B; a.C = l.c; a.Cw = l.Cw; a.H = l.h; a.W = l.w; a.M = l.n; a.Mpad = l.Mpad; a.act = kernel_act;
             a.ft_mode = (net.conv_opts.variant & 512) ? 64 : 0;
-            YL_LAUNCH(launch_conv_xnor(a, s), "conv_xnor");
-            snprintf(l.kernel_name, sizeof(l.kernel_name), "conv_xnor");
+            YL_LAUNCH(launch_conv_xnor(a, s, l.kernel_name, sizeof(l.kernel_name)), "conv_xnor");
         }
         if (post_act) YL_LAUNCH(launch_activate(l.d_output, (size_t)B * l.outputs, l.activation, s), "activate");
         break;
