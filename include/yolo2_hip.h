@@ -87,6 +87,14 @@ typedef struct yl_layer_desc {
     const int *tree_parent, *tree_group_size;
 } yl_layer_desc;
 
+/* ABI version of this header.  Bumped whenever the signature or meaning of an existing entry point changes (a
+ * caller built against an older header would still LINK against the same symbol name and pass garbage): 4 = round 4,
+ * the first numbered one (round 3 had inserted mask_cap / anchors_cap into yl_network_layer_head without a marker).
+ * Bindings compare yl_abi_version() with the YL_ABI_VERSION they were written against at load time
+ * (integration/network_predict_hip.c, yolo2_light_amd/_lib.py) and refuse to run on a mismatch. */
+#define YL_ABI_VERSION 4
+int yl_abi_version(void);
+
 /* thread-local human-readable message of the last failure */
 const char *yl_last_error(void);
 
@@ -330,11 +338,9 @@ int yl_network_set_device_pack(yl_network *net, int on);
  * copies it when dst_host != NULL (dst_bytes >= size). */
 long long yl_debug_layer_packed(yl_network *net, int i, int which, void *dst_host, long long dst_bytes);
 /* Test hook (host only, no GPU needed): the Winograd weight transform U = G g G^T of a 3x3 layer
- * (weights[m][c][3][3]) packed the way the kernel reads it.  tiling 32 (conv_f32_wino32.hip):
- * [m/32][c/4][xi 16][half 2][m 32][kk 2] with channel = panel*4 + 2*kk + half; tiling 16 (conv_f32_wino16.hip):
- * [m/32][c/4][xi/2][k 4][m%16][(m%32)/16][xi&1] with channel = panel*4 + k; tiling 64 (conv_f32_wino64.hip):
- * [m/64][c/4][xi 16][half 2][m 64][kk 2] with channel = panel*4 + 2*kk + half.
- * dst == NULL returns the number of floats needed. */
+ * (weights[m][c][3][3]) packed the way the kernel reads it.  tiling must be 32 (conv_f32_wino32.hip):
+ * [m/32][c/4][xi 16][half 2][m 32][kk 2] with channel = panel*4 + 2*kk + half.  (16 / 64 selected round 3's
+ * alternative kernels, removed in round 4: YL_ERR_ARG.)  dst == NULL returns the number of floats needed. */
 long long yl_debug_wino_pack(const float *weights, int c, int m, int tiling, float *dst, long long dst_floats);
 
 /* On-device detection compaction (new): threshold test

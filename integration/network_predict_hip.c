@@ -50,6 +50,11 @@ static yl_network *hip_build(network *net)
 {
     int i;
     yl_network *h = NULL;
+    if (yl_abi_version() != YL_ABI_VERSION) {       /* an older / newer libyolo2hip.so behind the same symbol names */
+        fprintf(stderr, "libyolo2hip.so implements C-ABI version %d, this adaptor was built against %d\n",
+                yl_abi_version(), YL_ABI_VERSION);
+        error("network_predict_hip: ABI version mismatch");
+    }
     yl_layer_desc *d = (yl_layer_desc *)calloc(net->n, sizeof(yl_layer_desc));
     for (i = 0; i < net->n; ++i) {
         layer *l = &net->layers[i];

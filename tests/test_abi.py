@@ -27,6 +27,13 @@ def test_binding_table_matches_header():
     assert sorted(_lib.EXPORTED) == header_functions()
 
 
+def test_abi_version_marker():
+    """header, library and binding agree on YL_ABI_VERSION (a changed signature behind an unchanged symbol name is
+    caught at load time)"""
+    m = re.search(r"#define\s+YL_ABI_VERSION\s+(\d+)", open(HEADER).read())
+    assert m and int(m.group(1)) == _lib.ABI_VERSION == _lib.lib.yl_abi_version()
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     """Device entry points must fail with an error (never compute on the CPU)."""
     import numpy as np

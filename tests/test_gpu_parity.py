@@ -155,11 +155,9 @@ WINO_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("kernel", ["p16", "r2", "64x64t"])
 @pytest.mark.parametrize("shape", WINO_SHAPES)
-def test_conv_winograd_vs_oracle(olib, shape, kernel):
-    """kernel p16 = conv_f32_wino16.hip (all 16 planes per wave), r2 = conv_f32_wino32.hip (variant bits 5 and 7 off),
-    64x64t = conv_f32_wino64.hip (bit 7; layers below 64 filters keep the 32-filter kernel)"""
+def test_conv_winograd_vs_oracle(olib, shape):
+    """K1w = conv_f32_wino32.hip (round 3's two alternative Winograd kernels left the library in round 4)"""
     B, Cc, H, W, M, act = shape
     rng = np.random.default_rng(99 + M + H)
     K = Cc * 9
@@ -167,11 +165,10 @@ def test_conv_winograd_vs_oracle(olib, shape, kernel):
     bias = rng.normal(0, 0.5, M).astype(np.float32)
     x = (rng.standard_normal((B, Cc, H, W)) + 0.3).astype(np.float32)
     d = D.conv(B, W, H, Cc, M, 3, 1, 1, act, wts, bias)
-    net = _net_from([d], B, W, H, Cc, variant={"p16": 62, "r2": 30, "64x64t": 30 | 128}[kernel])
+    net = _net_from([d], B, W, H, Cc, variant=30)
     net.set_conv_tile(31)
     got = net.predict(x)
-    assert "wino" in net.layer_kernel(0) and ("p16" in net.layer_kernel(0)) == (kernel == "p16")
-    assert ("64x64t" in net.layer_kernel(0)) == (kernel == "64x64t" and M >= 64)
+    assert "wino<32x64t" in net.layer_kernel(0)
     ref = np.zeros(B * d.outputs, dtype=np.float32)
     olib.oracle_conv_f32(fp(x), fp(wts), fp(bias), fp(ref), B, Cc, H, W, M, 3, 1, 1, act)
     ok, ratio, worst = fp32_close(got, ref)
@@ -570,7 +567,7 @@ def test_winograd_variants_bit_identical(shape):
     net = _net_from([d], B, W, H, Cc, variant=0)              # round-2 kernel and packing
     net.set_conv_tile(31)
     base = net.predict(x).copy()
-    assert "wino" in net.layer_kernel(0) and "udma" not in net.layer_kernel(0) and "p16" not in net.layer_kernel(0)
+    assert "wino" in net.layer_kernel(0) and "udma" not in net.layer_kernel(0)
     for v in (1, 2, 3):
         net.set_variant(v)
         got = net.predict(x)
@@ -578,39 +575,16 @@ def test_winograd_variants_bit_identical(shape):
             assert "udma" in net.layer_kernel(0)
         assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), "variant %d shape %r" % (v, shape)
     net.close()
-    # the 64-filter x 64-tile 8-wave kernel: the same per-element arithmetic, staged by half-patch threads
-    if M >= 64:
-        net = _net_from([d], B, W, H, Cc, variant=128)
-        net.set_conv_tile(31)
-        for v in (128, 130):
-            net.set_variant(v)
-            got = net.predict(x)
-            assert "64x64t" in net.layer_kernel(0) and ("apf" in net.layer_kernel(0)) == bool(v & 2)
-            assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), "variant %d shape %r" % (v, shape)
-        net.close()
-    # the 16x16x4 kernel (all planes in one wave): the fma chain of every accumulator visits the channels in the
-    # same order and the output transform associates the same way => the same bits as the round-2 kernel
-    net = _net_from([d], B, W, H, Cc, variant=32)
-    net.set_conv_tile(31)
-    for v in (32, 34, 96, 98):          # bit 6: the warp-specialised form (4 matrix + 4 staging waves)
-        net.set_variant(v)
-        got = net.predict(x)
-        assert "p16" in net.layer_kernel(0) and ("apf" in net.layer_kernel(0)) == bool(v & 2)
-        assert (",ws" in net.layer_kernel(0)) == bool(v & 64)
-        assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), "variant %d shape %r" % (v, shape)
-    net.close()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 15, 30, 31, 34, 62, 126, 158])
+@pytest.mark.parametrize("variant", [1, 2, 3, 15, 30, 31])
 def test_variants_whole_network_fused_bit_identical(variant):
     """yolov3 with conv+[shortcut] fusion (the benched setup): every materialised tensor and the detections of
     a run with the schedule variants equal the plain schedule's bit for bit (odd and even map sizes)."""
     name, width, height, batch = "yolov3", 160, 96, 2
     cfg, wts = common.model_files(name, width, height)
     x = common.seeded_input(batch, 3, height, width)
-    # bit 4 changes WHICH kernel a layer takes (Winograd from C = 32), not a schedule; bit 5 the Winograd kernel /
-    # weight packing (read at to_device) -- the reference run keeps the round-2 kernel, so variants 34 / 62 also
-    # check the 16x16x4 kernel against it, whole network, fused [shortcut] included
+    # bit 4 changes WHICH kernel a layer takes (Winograd from C = 32), not a schedule
     a = Network.load(cfg, wts, batch, 0, device=0, fuse=True, variant=variant & 16)
     b = Network.load(cfg, wts, batch, 0, device=0, fuse=True, variant=variant)
     a.predict(x)
@@ -621,11 +595,7 @@ def test_variants_whole_network_fused_bit_identical(variant):
             continue
         assert np.array_equal(a.layer_output(i).view(np.uint32), b.layer_output(i).view(np.uint32)), "layer %d" % i
     kernels = [b.layer_kernel(i) for i in range(b.n)]
-    if variant & 128 and not variant & 32:
-        assert any("64x64t" in k for k in kernels)
-    if variant & 32:
-        assert any("p16" in k for k in kernels)
-    elif variant & 1:
+    if variant & 1:
         assert any("udma" in k for k in kernels)
     if variant & 8:
         assert "conv_f32_first" in kernels[0]          # 160 wide: K1f (K1s only where W % 4 != 0)

@@ -44,15 +44,13 @@ def test_device_prep_equals_host_prep(name, width, height, quantized):
 
 @pytest.mark.parametrize("name,width,height,quantized,bf16,variant", [
     ("yolov3", 64, 64, 0, False, None),            # k-major FP32 panels (both K orders) + Winograd U, default packing
-    ("yolov3", 64, 64, 0, False, 62),              # ... + the all-planes-per-wave Winograd packing
-    ("yolov3", 64, 64, 0, False, 158),             # ... + the 64-filter Winograd packing
     ("yolov3-tiny", 96, 96, 1, False, None),       # int8 units
     ("yolov3", 64, 64, 0, True, None),             # bf16 units
     ("tiny-yolo-xnor", 96, 96, 0, False, None),    # XNOR sign words (c % 64 != 0 included)
     ("yolov2-voc", 96, 96, 1, False, None),
 ])
 def test_device_packers_equal_host_packers(name, width, height, quantized, bf16, variant):
-    """csrc/pack.hip against the host loops of runtime.hip / conv_f32_wino*.hip: every packed weight image a network
+    """csrc/pack.hip against the host loops of runtime.hip / conv_f32_wino32.hip: every packed weight image a network
     uploads (k-major FP32 panels, Winograd U, int8 / bf16 16-byte units, XNOR sign words) identical byte for byte,
     and the same forward pass."""
     cfg, wts = common.model_files(name, width, height)

@@ -57,7 +57,10 @@ class LayerDesc(C.Structure):
 
 _vp = C.c_void_p
 
+ABI_VERSION = 4          # YL_ABI_VERSION of the include/yolo2_hip.h this table was written against
+
 _SIGS = {
+    "yl_abi_version": (C.c_int, []),
     "yl_last_error": (C.c_char_p, []),
     "yl_device_count": (C.c_int, []),
     "yl_device_synchronize": (C.c_int, [C.c_int]),
@@ -145,6 +148,11 @@ for _name, (_res, _args) in _SIGS.items():
     _fn = getattr(lib, _name)          # AttributeError here == missing export == hard failure
     _fn.restype = _res
     _fn.argtypes = _args
+
+
+if lib.yl_abi_version() != ABI_VERSION:
+    raise ImportError("%s implements C-ABI version %d, this binding was written against %d (include/yolo2_hip.h)"
+                      % (LIB_PATH, lib.yl_abi_version(), ABI_VERSION))
 
 
 def last_error() -> str:

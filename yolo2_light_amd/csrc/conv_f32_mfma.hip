@@ -533,9 +533,7 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
                                       o.variant, stream, name, name_len);
     if (a.wino32_u && (o.force_tile == 31 || (o.force_tile == 0 && o.winograd && a.C >= ((o.variant & 16) ? 32 : 64) &&
                                              wino32_fits(a.B, a.M, a.H, a.W))))
-        return a.wino_tiling == 16 ? launch_conv_f32_wino16(a, a.wino32_u, o.variant, stream, name, name_len)
-             : a.wino_tiling == 64 ? launch_conv_f32_wino64(a, a.wino32_u, o.variant, stream, name, name_len)
-                                   : launch_conv_f32_wino32(a, a.wino32_u, o.variant, stream, name, name_len);
+        return launch_conv_f32_wino32(a, a.wino32_u, o.variant, stream, name, name_len);
     if (o.force_tile == 31) return (int)hipErrorInvalidValue;   // forced on a layer without packed U
     if (o.force_tile == 41 || (o.force_tile == 0 && (o.variant & 8) && smallk_applicable(a)))
         return launch_conv_f32_smallk(a, stream, name, name_len);

@@ -6,9 +6,10 @@
 
 namespace yl {
 
-// measured on MI355X, profiles/r2_ab_fp32_variants.txt: bit 1 +3.3 %, bit 2 +0.4 %, bit 3 +0.6 %, bit 4 +0.9 %, bit 0 -0.5 %;
-// round 3 (profiles/r3_ab_wino_kernels.txt, yolov3-608 b64 in the network): bit 5 -2.1 %, bits 5+6 -17 %, bit 7 -4.4 % --
-// the three new Winograd kernels are bit-identical alternatives, the round-2 kernel stays the default
+// measured on MI355X, profiles/r2_ab_fp32_variants.txt: bit 1 +3.3 %, bit 2 +0.4 %, bit 3 +0.6 %, bit 4 +0.9 %, bit 0 -0.5 %.
+// (Bits 5-7 selected round 3's three alternative Winograd kernels -- all-planes-per-wave on 16x16x4, its warp-specialised
+// form, the 64-filter 8-wave tile: bit-identical, -2.1 / -17 / -4.4 % in the network, profiles/r3_ab_wino_kernels.txt --
+// removed from the library in round 4; the bits are ignored.)
 constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8 | 16;
 
 // ---- K1: FP32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 ----
@@ -31,9 +32,7 @@ struct ConvF32Args {
     int size, stride, pad;
     int act;              // YL_LINEAR / YL_LEAKY
     int tapmajor;         // K order of `wt`: 0 = (c,ky,kx) like im2col_cpu, 1 = (ky,kx,c) (needs C % 16 == 0)
-    const float *wino32_u; // Winograd-packed weights (wino16_/wino32_pack_weights) or nullptr: 3x3/1/1 layers only
-    int wino_tiling = 32;  // which packing wino32_u holds: 16 = all-planes-per-wave kernel (conv_f32_wino16.hip), 32 = round-2
-                           // kernel, 64 = 64-filter kernel (conv_f32_wino64.hip)
+    const float *wino32_u; // Winograd-packed weights (wino32_pack_weights) or nullptr: 3x3/1/1 layers only
 };
 // per-network kernel-selection knobs (snapshotted in Network: two networks driven from two host
 // threads, one per GPU, share no mutable launch state)
@@ -43,11 +42,8 @@ struct ConvF32Opts {
     // schedule variants kept switchable for same-box A/B runs (yl_network_set_variant): bit 0 Winograd U panels by
     // LDS-DMA, bit 1 Winograd epilogue requests the [shortcut] operand ahead of its LDS exchange, bit 2 1x1 direct
     // kernel loads the B panel as float4 rows, bit 3 LDS-free small-K kernel for the first layer (C*size^2 <= 32),
-    // bit 4 Winograd from 32 input channels up (default: from 64), bit 5 (read when the weights are uploaded) the
-    // Winograd kernel that keeps all 16 planes of a block in one wave (conv_f32_wino16.hip) instead of round 2's
-    // plane-split kernel, bit 6 (with bit 5) its warp-specialised form: 4 matrix + 4 staging waves, one workgroup
-    // per CU, bit 7 (read at upload, without bit 5, layers with >= 64 filters) the 64-filter x 64-tile 8-wave kernel
-    // (conv_f32_wino64.hip), bit 8 XNOR layers between XNOR layers keep the float epilogue instead of the count
+    // bit 4 Winograd from 32 input channels up (default: from 64), bits 5-7 unused (round 3's alternative Winograd
+    // kernels, removed), bit 8 XNOR layers between XNOR layers keep the float epilogue instead of the count
     // threshold (conv_xnor.hip; same bits either way), bit 9 XNOR layers always use 64-filter workgroups where the layer
     // has 64 filters (default: 32-filter workgroups on shallow grids).  (An 8-byte-access epilogue for odd map widths was measured and dropped: no gain,
     // profiles/r2_ab_fp32_variants.txt.)
@@ -69,16 +65,6 @@ int launch_conv_f32_smallk(const ConvF32Args &a, void *stream, char *name, size_
 bool first_layer_valu_applicable(const ConvF32Args &a);
 int launch_conv_f32_first(const ConvF32Args &a, void *stream, char *name, size_t name_len);
 int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, int variant, void *stream, char *name, size_t name_len);
-// K1w, round 3 (conv_f32_wino16.hip): the same tile on v_mfma_f32_16x16x4_f32, a wave holds all 16 planes of its
-// 32-filter x 16-tile block, output transform in registers; its own U packing
-size_t wino16_packed_floats(int C, int M);
-void wino16_pack_weights(const float *w, int C, int M, float *dst);
-int launch_conv_f32_wino16(const ConvF32Args &a, const float *u_packed, int variant, void *stream, char *name, size_t name_len);
-// K1w, 64-filter form (conv_f32_wino64.hip): 64 filters x 64 tiles per workgroup of 8 waves, one workgroup per CU:
-// half the patch loads / transforms and a third fewer global -> LDS bytes per MFMA; its own U packing
-size_t wino64_packed_floats(int C, int M);
-void wino64_pack_weights(const float *w, int C, int M, float *dst);
-int launch_conv_f32_wino64(const ConvF32Args &a, const float *u_packed, int variant, void *stream, char *name, size_t name_len);
 
 // ---- K2: INT8 path ----
 // K2a: x_q = clamp_abs((int16)(x*mult), 127), FP32 NCHW -> int8 NHWC(Cpad)   (quantized.c:554-560)

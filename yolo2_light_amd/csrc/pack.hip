@@ -37,12 +37,11 @@ __global__ __launch_bounds__(256) void pack_kmajor_kernel(const float *__restric
     }
 }
 
-// U = G g G^T in double, rounded once to float (wino16_ / wino32_ / wino64_pack_weights): one lane per (tile_m,
+// U = G g G^T in double, rounded once to float (wino32_pack_weights): one lane per (tile_m,
 // m in tile, channel); filters beyond M give zeros
-template <int TILING>
 __global__ __launch_bounds__(256) void pack_wino_kernel(const float *__restrict__ w, float *__restrict__ dst, int C, int M, int tiles_m)
 {
-    constexpr int BMT = TILING == 64 ? 64 : 32;          // filters per workgroup tile
+    constexpr int BMT = 32;          // filters per workgroup tile
     const double G[4][3] = {{1., 0., 0.}, {.5, .5, .5}, {.5, -.5, .5}, {0., 0., 1.}};
     const int nkb = C / 4;
     const size_t total = (size_t)tiles_m * BMT * C;
@@ -77,9 +76,7 @@ __global__ __launch_bounds__(256) void pack_wino_kernel(const float *__restrict_
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) {
             const float v = (float)u[xi >> 2][xi & 3];
-            if (TILING == 32) panel[xi * 128 + (kl & 1) * 64 + ml * 2 + (kl >> 1)] = v;                       // [xi][half][m 32][kk]
-            else if (TILING == 64) panel[xi * 256 + (kl & 1) * 128 + ml * 2 + (kl >> 1)] = v;                 // [xi][half][m 64][kk]
-            else panel[(((xi >> 1) * 4 + kl) * 16 + (ml & 15)) * 4 + (ml >> 4) * 2 + (xi & 1)] = v;            // [xi/2][k][m16][fb][xi&1]
+            panel[xi * 128 + (kl & 1) * 64 + ml * 2 + (kl >> 1)] = v;                       // [xi][half][m 32][kk]
         }
     }
 }
@@ -144,14 +141,12 @@ int dev_pack_kmajor(const float *d_w, const float *d_mean, float *d_dst, int M, 
     return (int)hipGetLastError();
 }
 
-int dev_pack_wino(const float *d_w, float *d_dst, int C, int M, int tiling, void *stream)
+int dev_pack_wino(const float *d_w, float *d_dst, int C, int M, void *stream)
 {
-    const int bm = tiling == 64 ? 64 : 32;
+    const int bm = 32;
     const int tiles_m = (M + bm - 1) / bm;
     const unsigned g = pack_blocks((size_t)tiles_m * bm * C);
-    if (tiling == 16) hipLaunchKernelGGL(pack_wino_kernel<16>, dim3(g), dim3(256), 0, (hipStream_t)stream, d_w, d_dst, C, M, tiles_m);
-    else if (tiling == 64) hipLaunchKernelGGL(pack_wino_kernel<64>, dim3(g), dim3(256), 0, (hipStream_t)stream, d_w, d_dst, C, M, tiles_m);
-    else hipLaunchKernelGGL(pack_wino_kernel<32>, dim3(g), dim3(256), 0, (hipStream_t)stream, d_w, d_dst, C, M, tiles_m);
+    hipLaunchKernelGGL(pack_wino_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, d_w, d_dst, C, M, tiles_m);
     return (int)hipGetLastError();
 }
 

@@ -55,9 +55,19 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // (src/additionally.h:132-165) is applied by a pass of its own behind a linear epilogue (layers.hip: activate_kernel)
 static inline bool hot_activation(int a) { return a == YL_LINEAR || a == YL_LEAKY; }
 // the shapes conv_f32_smallk.hip accepts (smallk_applicable, minus what only the launch knows)
-static inline bool first_layer_kernel_takes(const Layer &l)
+// `batch`: both first-layer kernels address the input with 32-bit byte offsets (input tensor < 4 GiB) -- a batch
+// beyond that must not get the sign-word plan, whose only producers they are (launch_conv_f32 would fail instead of
+// falling back to the FP32 path)
+static inline bool first_layer_kernel_takes(const Layer &l, int batch)
 {
-    return l.size >= 1 && l.size <= 5 && l.size * l.size * l.c <= 32 && l.n <= 32 && !l.tapmajor;
+    const unsigned long long in_bytes = (unsigned long long)batch * l.c * l.h * l.w * sizeof(float);
+    return l.size >= 1 && l.size <= 5 && l.size * l.size * l.c <= 32 && l.n <= 32 && !l.tapmajor && in_bytes < 0xFFFFFFFEull;
+}
+// the plan of the fusion pass below: FP32 first layer -> [maxpool] -> XNOR conv hands over sign words
+static inline bool first_layer_sign_plan(const Network &net, const Layer &pp)
+{
+    return net.fuse && !net.debug && (net.conv_opts.variant & 8) && (net.conv_opts.force_tile == 0 || net.conv_opts.force_tile == 41) &&
+           first_layer_kernel_takes(pp, net.batch);
 }
 
 // float -> bf16, round to nearest even (what v_cvt_pk_bf16_f32 does to the activations on the device)
@@ -103,11 +113,7 @@ static void free_device(Network &net)
     if (net.d_binbuf) (void)hipFree(net.d_binbuf);
     net.d_binbuf = nullptr;
     if (net.h_pinned) (void)hipHostFree(net.h_pinned);
-#ifdef YL_REPRO_REGISTER
-    if (net.h_heads) { (void)hipHostUnregister(net.h_heads); free(net.h_heads); }
-#else
     if (net.h_heads) (void)hipHostFree(net.h_heads);
-#endif
     net.h_heads = nullptr; net.h_heads_floats = 0;
     if (net.h_u8) (void)hipHostFree(net.h_u8);
     if (net.d_u8) (void)hipFree(net.d_u8);
@@ -189,10 +195,8 @@ static int upload_conv(Network &net, Layer &l)
         // specified by the reference as an exact +-1 GEMM.
         const bool wino = net.conv_opts.winograd && !xnor_fallback && wino_applicable(l.c, M, l.size, l.stride, l.pad) &&
                           l.out_h == l.h && l.out_w == l.w && l.h >= 4 && l.w >= 4;
-        l.wino_tiling = (net.conv_opts.variant & 32) ? 16 : (((net.conv_opts.variant & 128) && M >= 64) ? 64 : 32);
         const size_t wt_floats = (size_t)l.Kpad * l.Mpad;
-        const size_t u_floats = !wino ? 0 : (l.wino_tiling == 16 ? wino16_packed_floats(l.c, M)
-                                             : l.wino_tiling == 64 ? wino64_packed_floats(l.c, M) : wino32_packed_floats(l.c, M));
+        const size_t u_floats = !wino ? 0 : wino32_packed_floats(l.c, M);
         YL_HIP(hipMalloc((void **)&l.d_weights_t, wt_floats * sizeof(float)));
         l.packed_bytes[0] = wt_floats * sizeof(float);
         if (wino) {
@@ -206,7 +210,7 @@ static int upload_conv(Network &net, Layer &l)
             const float *d_mean = xnor_fallback ? reinterpret_cast<const float *>(net.d_pack_src + ((sizeof(float) * (size_t)M * K + 255) & ~(size_t)255)) : nullptr;
             YL_HIP(hipMemsetAsync(l.d_weights_t, 0, wt_floats * sizeof(float), (hipStream_t)s));
             YL_LAUNCH(dev_pack_kmajor(d_src, d_mean, l.d_weights_t, M, l.c, taps, l.Mpad, l.tapmajor, s), "pack_kmajor");
-            if (wino) YL_LAUNCH(dev_pack_wino(d_src, l.d_wino32_u, l.c, M, l.wino_tiling, s), "pack_wino");
+            if (wino) YL_LAUNCH(dev_pack_wino(d_src, l.d_wino32_u, l.c, M, s), "pack_wino");
         } else {
             std::vector<float> wt(wt_floats, 0.f);
             for (int m = 0; m < M; ++m)
@@ -222,9 +226,7 @@ static int upload_conv(Network &net, Layer &l)
             YL_STAGE(stage_h2d(net.device, l.d_weights_t, wt.data(), wt.size() * sizeof(float)));
             if (wino) {
                 std::vector<float> u32(u_floats);
-                if (l.wino_tiling == 16) wino16_pack_weights(l.weights.data(), l.c, M, u32.data());
-                else if (l.wino_tiling == 64) wino64_pack_weights(l.weights.data(), l.c, M, u32.data());
-                else wino32_pack_weights(l.weights.data(), l.c, M, u32.data());
+                wino32_pack_weights(l.weights.data(), l.c, M, u32.data());
                 YL_STAGE(stage_h2d(net.device, l.d_wino32_u, u32.data(), u32.size() * sizeof(float)));
             }
         }
@@ -410,13 +412,7 @@ static int to_device(Network &net, int device)
             total += ((size_t)net.batch * l.outputs + 63) & ~(size_t)63;
         }
         if (total) {
-#ifdef YL_REPRO_REGISTER        // repro builds only (staging.hip): round 2's registered heap block instead of pinned memory
-            net.h_heads = static_cast<float *>(malloc(total * sizeof(float)));
-            if (!net.h_heads) { set_error("malloc failed"); return YL_ERR_DEVICE; }
-            (void)hipHostRegister(net.h_heads, total * sizeof(float), hipHostRegisterDefault);
-#else
             YL_HIP(hipHostMalloc((void **)&net.h_heads, total * sizeof(float), hipHostMallocDefault));
-#endif
             net.h_heads_floats = total;
             memset(net.h_heads, 0, total * sizeof(float));
         }
@@ -433,7 +429,7 @@ static int to_device(Network &net, int device)
     // (one per pixel of its own output) into the ring: make the slots large enough before they are allocated
     for (size_t i = 0; i + 2 < net.layers.size(); ++i) {
         const Layer &pp = net.layers[i], &pool = net.layers[i + 1], &cons = net.layers[i + 2];
-        if (pp.type == YL_CONVOLUTIONAL && pp.conv_mode == CONV_F32 && !pp.xnor && first_layer_kernel_takes(pp) &&
+        if (pp.type == YL_CONVOLUTIONAL && pp.conv_mode == CONV_F32 && !pp.xnor && first_layer_sign_plan(net, pp) &&
             pool.type == YL_MAXPOOL && cons.type == YL_CONVOLUTIONAL && cons.conv_mode == CONV_XNOR) {
             const size_t bb = (size_t)net.batch * pp.out_h * pp.out_w * sizeof(uint64_t);
             if (bb > net.bitbuf_bytes) net.bitbuf_bytes = bb;
@@ -581,8 +577,7 @@ static int to_device(Network &net, int device)
                     cons.bits_from_producer = true;
                 } else if (pp.type == YL_CONVOLUTIONAL && pp.conv_mode == CONV_F32 && !pp.xnor && pp.fused_shortcut < 0 && pp.fused_yolo < 0 &&
                            pp.q_out_layer < 0 && pool_private && hot_activation(pp.activation) && !referenced_elsewhere(j - 2, j - 1) &&
-                           (net.conv_opts.variant & 8) && (net.conv_opts.force_tile == 0 || net.conv_opts.force_tile == 41) &&
-                           first_layer_kernel_takes(pp)) {
+                           first_layer_sign_plan(net, pp)) {
                     // FP32 first layer -> maxpool -> XNOR conv (tiny-yolo-obj_xnor.cfg layers 0-2: 1.4 GB of FP32 written and
                     // read back per batch of 128 just to take signs): conv_f32_smallk.hip emits the sign words itself
                     pp.bits_out_slot = j - 1;
@@ -651,7 +646,6 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = kernel_act;
             a.tapmajor = l.tapmajor;
             a.wino32_u = l.d_wino32_u;
-            a.wino_tiling = l.wino_tiling;
             if (l.fused_yolo >= 0) {
                 const Layer &yo = net.layers[l.fused_yolo];
                 a.yolo_entries = yo.classes + 5;
@@ -885,6 +879,8 @@ using namespace yl;
 extern "C" {
 
 const char *yl_last_error(void) { return g_err.c_str(); }
+
+int yl_abi_version(void) { return YL_ABI_VERSION; }
 
 int yl_device_count(void)
 {
@@ -1588,13 +1584,11 @@ int yl_network_layer_tree(const yl_network *net, int i, int *parent, int *group_
 
 long long yl_debug_wino_pack(const float *weights, int c, int m, int tiling, float *dst, long long dst_floats)
 {
-    if (!weights || c <= 0 || m <= 0 || c % 8 != 0 || (tiling != 32 && tiling != 16 && tiling != 64)) { set_error("bad argument"); return YL_ERR_ARG; }
-    const size_t need = tiling == 16 ? wino16_packed_floats(c, m) : (tiling == 64 ? wino64_packed_floats(c, m) : wino32_packed_floats(c, m));
+    if (!weights || c <= 0 || m <= 0 || c % 8 != 0 || tiling != 32) { set_error("bad argument"); return YL_ERR_ARG; }
+    const size_t need = wino32_packed_floats(c, m);
     if (!dst) return (long long)need;
     if (dst_floats < (long long)need) { set_error("dst too small"); return YL_ERR_ARG; }
-    if (tiling == 16) wino16_pack_weights(weights, c, m, dst);
-    else if (tiling == 64) wino64_pack_weights(weights, c, m, dst);
-    else wino32_pack_weights(weights, c, m, dst);
+    wino32_pack_weights(weights, c, m, dst);
     return (long long)need;
 }
 

@@ -6,12 +6,18 @@
 // by the host address; when the allocator returns that range to the kernel (heap trim / munmap) and later hands
 // the same address out for a shorter block, a later copy hits the cached lock and the copy engine walks a
 // user-pointer mapping whose tail is gone: "Memory access fault by GPU node-N ... on address <host heap>".
-// tools/repro_pin_cache.hip reproduces exactly this without any product code.
+// (Root-caused in round 3 with instrumented builds on fresh GPU boxes: DESIGN.md section 9, profiles/r3_repro_fault.txt.)
 //
 // Here every transfer is bounced through library-owned hipHostMalloc memory (two 8 MB chunks per device, the
 // memcpy of chunk k+1 overlaps the DMA of chunk k), so the runtime never sees a pointer it did not allocate
 // itself and never has to lock / unlock / cache anything.  The reference's device runtime has the same shape of
 // entry points (cuda_push_array / cuda_pull_array, src/gpu.cu:236-266), on pageable memory.
+//
+// Concurrency: ONE stager (two bounce chunks, one copy stream, one mutex) per DEVICE.  Uploads / downloads of two
+// networks on the same GPU are therefore serialised against each other; networks on different GPUs (the group path:
+// one replica and one host thread per device) do not contend.  These are set-up and debug transfers (weight images,
+// layer downloads): the per-step paths -- input staging, head block, detection rows -- use per-network pinned
+// buffers and the network's own stream, not this stager.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -60,17 +66,9 @@ int ensure(Stager &st)
 
 }  // namespace
 
-// YL_REPRO_PAGEABLE / YL_REPRO_REGISTER: build switches of tools/build_repro_variants.sh ONLY -- they put ONE of
-// round 2's two habits back (pageable hipMemcpy here; a malloc'd + hipHostRegister'ed head block in runtime.hip) so
-// that tools/repro_fault.py can tell which of them the GPU memory fault needs.  Never defined in the product build.
 int stage_h2d(int device, void *dst_dev, const void *src_host, size_t bytes)
 {
     if (bytes == 0) return YL_OK;
-#ifdef YL_REPRO_PAGEABLE
-    ST_HIP(hipSetDevice(device));
-    ST_HIP(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
-    return YL_OK;
-#endif
     if (device < 0 || device >= MAX_DEV || !dst_dev || !src_host) { set_error("staging: bad argument"); return YL_ERR_ARG; }
     Stager &st = g_stagers[device];
     std::lock_guard<std::mutex> lock(st.m);
@@ -95,11 +93,6 @@ int stage_h2d(int device, void *dst_dev, const void *src_host, size_t bytes)
 int stage_d2h(int device, void *dst_host, const void *src_dev, size_t bytes)
 {
     if (bytes == 0) return YL_OK;
-#ifdef YL_REPRO_PAGEABLE
-    ST_HIP(hipSetDevice(device));
-    ST_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
-    return YL_OK;
-#endif
     if (device < 0 || device >= MAX_DEV || !dst_host || !src_dev) { set_error("staging: bad argument"); return YL_ERR_ARG; }
     Stager &st = g_stagers[device];
     std::lock_guard<std::mutex> lock(st.m);

@@ -58,8 +58,7 @@ struct Layer {
     float *d_biases = nullptr;
     int   Kpad = 0, Mpad = 0;
     int   tapmajor = 0;                  // K order of d_weights_t (see conv_f32_mfma.hip)
-    float *d_wino32_u = nullptr;         // FP32 3x3/1/1: Winograd-packed U (conv_f32_wino16.hip / _wino32.hip), else nullptr
-    int   wino_tiling = 32;              // which of the two packings d_wino32_u holds
+    float *d_wino32_u = nullptr;         // FP32 3x3/1/1: Winograd-packed U (conv_f32_wino32.hip), else nullptr
     size_t packed_bytes[4] = {0, 0, 0, 0};   // bytes of d_weights_t, d_wino32_u, d_weights_i8, d_weights_bits (yl_debug_layer_packed)
     int8_t *d_weights_i8 = nullptr;      // INT8: [K16pad][Mpad][16] int8 units; BF16: [K8pad][Mpad][8] bf16 units
     int   Cpad = 0;                      // channels of the 16-byte-unit activation tensor (INT8: 16 per unit, BF16: 8)
@@ -171,7 +170,7 @@ float multiplier_from_range_counts(const int *count, int bits_length);
 int prepare_on_device(Network &net, int device);
 // pack.hip: the kernel-layout packers on the device (bit-identical to the host packers; dst pre-initialised by the caller)
 int dev_pack_kmajor(const float *d_w, const float *d_mean, float *d_dst, int M, int C, int taps, int Mpad, int tapmajor, void *stream);
-int dev_pack_wino(const float *d_w, float *d_dst, int C, int M, int tiling, void *stream);
+int dev_pack_wino(const float *d_w, float *d_dst, int C, int M, void *stream);
 int dev_pack_i8_units(const int8_t *d_wq, int8_t *d_dst, int M, int C, int taps, int G, int Mpad, void *stream);
 int dev_pack_bf16_units(const float *d_w, uint16_t *d_dst, int M, int C, int taps, int G, int Mpad, void *stream);
 int dev_pack_xnor_words(const float *d_w, uint64_t *d_dst, int M, int C, int Cw, void *stream);
