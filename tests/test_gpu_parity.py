@@ -552,6 +552,81 @@ def test_shortcut_fusion_is_bit_identical(width, height, batch):
     plain.close(); fused.close()
 
 
+POOL_FUSION_SHAPES = [
+    # B, C, H, W, M, act, tag of the kernel that must take it
+    (2, 3, 16, 24, 16, D.LEAKY, "conv_f32_first"),        # K1f: a lane owns a 2 x 4 patch
+    (3, 3, 10, 8, 32, D.LEAKY, "conv_f32_first"),         # two 16-filter halves, one lane group per row
+    (1, 3, 64, 96, 12, D.LINEAR, "conv_f32_first"),       # ragged filter count, linear
+    (5, 1, 6, 12, 7, D.LEAKY, "conv_f32_first"),          # one input channel
+    (2, 32, 12, 20, 64, D.LEAKY, "conv_f32_wino"),        # K1w: an F(2x2) tile is a pooling window
+    (1, 64, 26, 26, 33, D.LEAKY, "conv_f32_wino"),        # ragged filter tile
+    (3, 128, 6, 10, 40, D.LINEAR, "conv_f32_wino"),       # a workgroup's tiles span images
+]
+
+
+@pytest.mark.parametrize("keep_full", [False, True], ids=["pool-only", "pool+full"])
+@pytest.mark.parametrize("shape", POOL_FUSION_SHAPES)
+def test_maxpool_fusion_is_bit_identical(shape, keep_full):
+    """conv -> [maxpool 2x2/2] with the pooling folded into the convolution's epilogue (yl_network_set_fusion; K1f and
+    K1w) against the two kernels run one after the other: the pooled tensor -- and, where a [route] also reads it, the
+    full-resolution tensor -- bit for bit.  forward_maxpool_layer_cpu, src/additionally.c:1448-1482."""
+    B, Cc, H, W, M, act, tag = shape
+    rng = np.random.default_rng(5 + M + H + Cc)
+    K = Cc * 9
+    wts = rng.normal(0, np.sqrt(2.0 / K), M * K).astype(np.float32)
+    bias = rng.normal(0, 0.5, M).astype(np.float32)
+    x = (rng.standard_normal((B, Cc, H, W)) + 0.1).astype(np.float32)
+    layers = [D.conv(B, W, H, Cc, M, 3, 1, 1, act, wts, bias), D.maxpool(B, W, H, M, 2, 2)]
+    if keep_full:       # a [route] back to the convolution: its own tensor must exist as well
+        layers.append(D.route(B, [0], [M * H * W], (W, H, M)))
+    outs = {}
+    for fuse in (False, True):
+        net = Network.from_desc(layers, B, W, H, Cc, 0)
+        net.set_variant(30)
+        net.set_fusion(fuse)
+        net.to_device(0)
+        net.predict(x)
+        k = net.layer_kernel(0)
+        assert tag in k, k
+        assert ("pool" in k) == fuse, k
+        if fuse:
+            assert ("pool+" in k) == keep_full, k
+            assert net.layer_materialised(0) == keep_full
+        outs[fuse] = [net.layer_output(i) if net.layer_materialised(i) else None for i in range(net.n)]
+        net.close()
+    for i in range(len(layers)):
+        if outs[True][i] is None:
+            continue
+        assert np.array_equal(outs[True][i].view(np.uint32), outs[False][i].view(np.uint32)), "layer %d" % i
+    assert outs[True][1] is not None
+
+
+def test_maxpool_fusion_whole_network_yolov3_tiny():
+    """yolov3-tiny 416 (BASELINE config 2): with fusion on, the first layer (K1f) and the Winograd layers in front of a
+    2x2 / stride-2 [maxpool] write the pooled tensors themselves; every materialised tensor and the detections equal
+    the unfused run's bit for bit; layer 8 also feeds a [route] and keeps its full tensor."""
+    name, width, height, batch = "yolov3-tiny", 416, 416, 2
+    cfg, wts = common.model_files(name, width, height)
+    x = common.seeded_input(batch, 3, height, width)
+    plain = Network.load(cfg, wts, batch, 0, device=0)
+    fused = Network.load(cfg, wts, batch, 0, device=0, fuse=True)
+    plain.predict(x)
+    fused.predict(x)
+    kernels = [fused.layer_kernel(i) for i in range(fused.n)]
+    pooled = [i for i, k in enumerate(kernels) if "pool" in k]
+    assert 0 in pooled and 8 in pooled and len(pooled) >= 4, kernels
+    assert "pool+" in kernels[8] and fused.layer_materialised(8)          # [route] -1, 8 reads layer 8
+    assert not fused.layer_materialised(0)
+    assert all("pool" not in plain.layer_kernel(i) for i in range(plain.n))
+    for i in range(plain.n):
+        if not fused.layer_materialised(i):
+            continue
+        assert np.array_equal(plain.layer_output(i).view(np.uint32), fused.layer_output(i).view(np.uint32)), "layer %d" % i
+    for b in range(batch):
+        assert np.array_equal(plain.get_boxes(b, width, height, 0.24, nms=0.4), fused.get_boxes(b, width, height, 0.24, nms=0.4))
+    plain.close(); fused.close()
+
+
 # ----------------------------------------------------------------------------
 # schedule variants (yl_network_set_variant): same arithmetic in the same order => bit-identical results
 # ----------------------------------------------------------------------------

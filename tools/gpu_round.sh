@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun invocation: parity tests, smoke, bench (+ per-layer table), rocprofv3 kernel stats
 # and PMC counter passes.  Usage (repo root on the GPU box):  bash tools/gpu_round.sh <tag> [steps...]
-# steps: tests smoke bench sweep prof pmc int8 xnor   (default: tests smoke bench prof)
+# steps: tests newtests smoke bench sweep prof pmc int8 xnor valu stats4 pmclegs ...   (default: tests smoke bench prof)
 TAG=${1:-r1}
 shift
 STEPS=${@:-tests smoke bench prof}
@@ -21,9 +21,54 @@ if has tests; then
 fi
 if has newtests; then
   echo "== pytest new files: $NEWTESTS" | tee -a $OUT/summary.txt
-  timeout 900 python -m pytest ${NEWTESTS:-tests/test_gpu_detect.py tests/test_gpu_input.py} -m gpu -q --maxfail=20 --durations=8 > $OUT/pytest_new.log 2>&1
+  timeout 900 python -m pytest ${NEWTESTS:-tests/test_gpu_detect.py tests/test_gpu_input.py} -m gpu -q -s ${NEWK:+-k "$NEWK"} --maxfail=20 --durations=8 > $OUT/pytest_new.log 2>&1
   echo "pytest new exit $?" | tee -a $OUT/summary.txt
   tail -40 $OUT/pytest_new.log
+fi
+if has valu; then
+  # VALU issue rate (wave-instructions per SIMD clock) of the instruction mixes the XNOR / first-layer roofs are quoted on
+  echo "== VALU issue-rate microbenchmark" | tee -a $OUT/summary.txt
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/valu_issue_bench tools/valu_issue_bench.hip 2> $OUT/valu_build.log
+  timeout 120 /tmp/valu_issue_bench > $OUT/valu_issue_bench.txt 2>&1
+  echo "valu exit $?" | tee -a $OUT/summary.txt
+  cat $OUT/valu_issue_bench.txt
+fi
+if has stats4; then
+  # single-configuration rocprofv3 kernel stats of the shipped tree: BASELINE configs 3 (FP32), 4 (INT8), 2, 5
+  echo "== rocprofv3 --kernel-trace --stats, one configuration per run (--no-extras)" | tee -a $OUT/summary.txt
+  C1="--no-cpu-baseline --no-e2e --no-extras"
+  for leg in "c3_yolov3_608_b64_fp32|--mode fp32 --steps 5 --warmup 2" "c4_yolov3_608_b64_int8|--mode int8 --steps 10 --warmup 2" \
+             "c2_yolov3_tiny_416_b32_fp32|--model yolov3-tiny --size 416 --batch 32 --mode fp32 --steps 20 --warmup 3" \
+             "c5_tiny_yolo_xnor_416_b128|--model tiny-yolo-xnor --size 416 --batch 128 --mode fp32 --steps 20 --warmup 3" \
+             "bf16_yolov3_608_b64|--mode bf16 --steps 10 --warmup 2"; do
+    T=${leg%%|*}; A=${leg#*|}
+    ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/stats_$T -o s -- python $R/bench.py $A $C1 > $R/$OUT/stats_$T.json 2> $R/$OUT/stats_$T.err )
+    echo "stats $T exit $?" | tee -a $OUT/summary.txt
+    F=$(find $OUT/stats_$T -name "*kernel_stats.csv" | head -1)
+    [ -n "$F" ] && cp "$F" $OUT/kernel_stats_$T.csv && head -8 "$F" | cut -c1-180
+    tail -1 $OUT/stats_$T.json | cut -c1-300
+  done
+  find $OUT -name "*kernel_trace.csv" -delete
+fi
+if has pmclegs; then
+  # FETCH_SIZE / WRITE_SIZE in their own runs (kernel-trace only), one configuration per run, batch of the bench line
+  echo "== rocprofv3 PMC FETCH_SIZE / WRITE_SIZE passes per leg (--no-extras)" | tee -a $OUT/summary.txt
+  C1="--steps 1 --warmup 0 --no-cpu-baseline --no-e2e --no-extras --raw-head --nms 0"
+  for leg in ${PMCLEGS:-fp32 bf16}; do
+    case $leg in
+      fp32) A="--mode fp32";; int8) A="--mode int8";; bf16) A="--mode bf16";;
+      tiny) A="--model yolov3-tiny --size 416 --batch 32 --mode fp32";;
+      xnor) A="--model tiny-yolo-xnor --size 416 --batch 128 --mode fp32";;
+    esac
+    for C in FETCH_SIZE WRITE_SIZE; do
+      ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmcleg_${leg}/$C -o pmc -- python $R/bench.py $A $C1 > $R/$OUT/pmcleg_${leg}_$C.log 2>&1 )
+      echo "pmcleg $leg $C exit $?" | tee -a $OUT/summary.txt
+    done
+    python tools/pmc_summary.py $OUT/pmcleg_${leg} > $OUT/pmcleg_${leg}_summary.txt 2>&1
+    cat $OUT/pmcleg_${leg}_summary.txt | head -40
+  done
+  find $OUT -name "*counter_collection.csv" -size +30M -delete
+  find $OUT -name "*kernel_trace.csv" -delete
 fi
 if has smoke; then
   echo "== smoke" | tee -a $OUT/summary.txt

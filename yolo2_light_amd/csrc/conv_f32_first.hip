@@ -41,6 +41,7 @@ struct ConvFirstDev {
     const float *bias;
     float *out;            // [B][M][H][W] or nullptr
     uint64_t *bits_out;    // [B][1][H][W] sign words or nullptr
+    float *pool_out;       // fused [maxpool] 2x2 / stride 2 behind the layer: [B][M][H/2][W/2] or nullptr (pool kernel only)
     int8_t *q_out;         // act_q[B][q_G][H][W][16] int8 or nullptr
     float q_mult;
     int q_G;
@@ -52,12 +53,14 @@ struct ConvFirstDev {
 
 }  // namespace
 
-// one channel's window of a lane: 3 rows x 6 columns around its four pixels
-__device__ __forceinline__ void first_load_window(float (&win)[3][6], __amdgpu_buffer_rsrc_t rsrc, const int (&voff)[3],
-                                                  const int (&eoff)[3], int soff, bool has_l, bool has_r)
+// one channel's window of a lane: R rows x 6 columns around its four pixels (R = 3; 4 in the pooling kernel, whose
+// lanes own two output rows)
+template <int R>
+__device__ __forceinline__ void first_load_window(float (&win)[R][6], __amdgpu_buffer_rsrc_t rsrc, const int (&voff)[R],
+                                                  const int (&eoff)[R], int soff, bool has_l, bool has_r)
 {
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < R; ++r) {
         const s4f v = __builtin_bit_cast(s4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[r], soff, 0));
         const float e = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, eoff[r], soff, 0));
         // wave_shr:1 -- lane i takes lane i-1's .w, lane 0 keeps `e`; wave_shl:1 -- lane i takes lane i+1's .x
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256, Q ? 3 : 4) void conv_f32_first_kernel(ConvFirs
     float wina[RES ? C : 1][3][6];
     if (RES) {
 #pragma unroll
-        for (int c = 0; c < C; ++c) first_load_window(wina[RES ? c : 0], rsrc, voff, eoff, c * HW * 4, has_l, has_r);
+        for (int c = 0; c < C; ++c) first_load_window<3>(wina[RES ? c : 0], rsrc, voff, eoff, c * HW * 4, has_l, has_r);
     }
     unsigned qheld[4][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};   // bytes 0-7 of the open 16-channel int8 unit
     // Passes of 8 filters: 32 accumulators + 18 window values + two k-rows of 8 weights stay far below the register
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256, Q ? 3 : 4) void conv_f32_first_kernel(ConvFirs
                 // `mh`, hoists them in front of the pass loop and the kernel is back at 54 resident values
                 int soff = c * HW * 4;
                 asm volatile("" : "+s"(soff));
-                first_load_window(wina[0], rsrc, voff, eoff, soff, has_l, has_r);
+                first_load_window<3>(wina[0], rsrc, voff, eoff, soff, has_l, has_r);
             }
             const float (&win)[3][6] = wina[RES ? c : 0];
 #pragma unroll
@@ -257,29 +260,174 @@ __global__ __launch_bounds__(256, Q ? 3 : 4) void conv_f32_first_kernel(ConvFirs
     }
 }
 
+
+// K1f with the 2x2 / stride-2 [maxpool] behind the layer folded in (forward_maxpool_layer_cpu,
+// src/additionally.c:1448-1482; H, W even: window origin 0 and no out-of-range taps).  yolov3-tiny's first layer
+// wrote 354 MB of FP32 per batch of 32 that the pooling kernel read straight back (0.14 of the 1.84 ms step).  Here a
+// lane owns a 2-row x 4-column patch of the convolution output = two pooling windows: the two rows are computed one
+// after the other from a resident 4-row window (the same fma chains in the same order as the kernel above => the same
+// bits), the pooled pair leaves as one 8-byte store per filter (64 lanes x 8 B contiguous), and the full-resolution
+// rows are written only when something else reads them (p.out != nullptr).
+template <int C, int MP>
+__global__ __launch_bounds__(256, 3) void conv_f32_first_pool_kernel(ConvFirstDev p)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = idx < p.total;
+    const int PH = p.H >> 1, PW = p.W >> 1;
+    const int q = (int)(idx % p.Wq);
+    const long long t = idx / p.Wq;
+    const int oyp = (int)(t % PH);
+    const int b = live ? (int)(t / PH) : 0;
+    const int oy0 = 2 * oyp, ox0 = 4 * q;
+    const int HW = p.H * p.W;
+
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)p.in, 0, (int)p.rec, 0x00020000);
+    const int lane = threadIdx.x & 63;
+    const bool edge = lane == 0 || lane == 63;
+    const bool has_l = q > 0, has_r = q < p.Wq - 1;
+    int voff[4], eoff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int iy = oy0 - 1 + r;
+        const bool rok = live && iy >= 0 && iy < p.H;
+        const unsigned base = (((unsigned)b * C) * (unsigned)HW + (unsigned)(iy * p.W + ox0)) * 4u;
+        voff[r] = rok ? (int)base : -1;
+        eoff[r] = !rok || !edge ? -1 : lane == 0 ? (has_l ? (int)(base - 4u) : -1) : (has_r ? (int)(base + 16u) : -1);
+    }
+
+    __shared__ __attribute__((aligned(16))) float wl[9 * C * MP];
+    for (int i = threadIdx.x; i < 9 * C * MP; i += 256) wl[i] = p.wt[(size_t)(i / MP) * p.Mpad + (i % MP)];
+    __syncthreads();
+
+    float wina[C][4][6];
+#pragma unroll
+    for (int c = 0; c < C; ++c) first_load_window<4>(wina[c], rsrc, voff, eoff, c * HW * 4, has_l, has_r);
+
+    const size_t pix = (size_t)oy0 * p.W + ox0;
+    const size_t ppix = (size_t)oyp * PW + 2 * q;
+    // passes of FOUR filters (the kernel above: eight): 72 resident window values + 16 accumulators + 8 running maxima
+    // stay below the 168 registers of three waves per SIMD
+    constexpr int FP = 4;
+    const int passes = (p.M + FP - 1) / FP;
+#pragma unroll 1
+    for (int mh = 0; mh < passes; ++mh) {
+        float hp[FP][2];                                  // running max of the two windows, per filter of the pass
+        const float *wh = wl + mh * FP;
+#pragma unroll
+        for (int ry = 0; ry < 2; ++ry) {
+            float acc[FP][4];
+#pragma unroll
+            for (int m = 0; m < FP; ++m)
+#pragma unroll
+                for (int px = 0; px < 4; ++px) acc[m][px] = 0.f;
+            int w0 = 0;
+            asm volatile("" : "+v"(w0));                  // keeps the first row's read inside this ry block
+            float4 n0 = *reinterpret_cast<const float4 *>(wh + w0);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int k = c * 9 + ky * 3 + kx;
+                        const int kn = k + 1 < 9 * C ? k + 1 : k;
+                        const float w[FP] = {n0.x, n0.y, n0.z, n0.w};
+                        {
+                            int wo = kn * MP;
+                            asm volatile("" : "+v"(wo));
+                            n0 = *reinterpret_cast<const float4 *>(wh + wo);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int m = 0; m < FP; ++m)
+#pragma unroll
+                            for (int px = 0; px < 4; ++px) acc[m][px] = __fmaf_rn(w[m], wina[c][ry + ky][kx + px], acc[m][px]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
+#pragma unroll
+            for (int m = 0; m < FP; ++m)
+#pragma unroll
+                for (int px = 0; px < 4; ++px) asm volatile("" : "+v"(acc[m][px]));      // no sinking of the chains (see above)
+#pragma unroll
+            for (int ml = 0; ml < FP; ++ml) {
+                const int m = mh * FP + ml;
+                const float bv = m < p.M ? p.bias[m] : 0.f;
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    float v = acc[ml][px] + bv;
+                    if (p.act == YL_LEAKY) v = (v > 0.f) ? v : (float)(.1 * (double)v);
+                    acc[ml][px] = v;
+                }
+                // the reference's scan order: rows, then columns, `if (val > max) max = val` from -FLT_MAX
+#pragma unroll
+                for (int w2 = 0; w2 < 2; ++w2) {
+                    float mx = ry == 0 ? -3.402823466e+38f : hp[ml][w2];
+                    mx = (acc[ml][2 * w2] > mx) ? acc[ml][2 * w2] : mx;
+                    mx = (acc[ml][2 * w2 + 1] > mx) ? acc[ml][2 * w2 + 1] : mx;
+                    hp[ml][w2] = mx;
+                }
+            }
+            if (live && p.out) {
+#pragma unroll
+                for (int ml = 0; ml < FP; ++ml) {
+                    const int m = mh * FP + ml;
+                    if (m < p.M)
+                        *reinterpret_cast<float4 *>(p.out + ((size_t)b * p.M + m) * HW + pix + (size_t)ry * p.W) =
+                            make_float4(acc[ml][0], acc[ml][1], acc[ml][2], acc[ml][3]);
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int ml = 0; ml < FP; ++ml) {
+                const int m = mh * FP + ml;
+                if (m < p.M)
+                    *reinterpret_cast<float2 *>(p.pool_out + ((size_t)b * p.M + m) * (size_t)(PH * PW) + ppix) = make_float2(hp[ml][0], hp[ml][1]);
+            }
+        }
+    }
+}
+
 bool first_layer_valu_applicable(const ConvF32Args &a)
 {
     const long long in_bytes = (long long)a.B * a.C * a.H * a.W * 4;
     return (a.W & 3) == 0 && a.W >= 8 && !a.tapmajor && a.size == 3 && a.stride == 1 && a.pad == 1 && a.C >= 1 && a.C <= 3 && a.M >= 1 && a.M <= 32 &&
            a.OH == a.H && a.OW == a.W && a.Mpad >= (a.M <= 16 ? 16 : 32) && a.Kpad >= 9 * a.C && (!a.q_out || a.M % 16 == 0) && !a.add && a.yolo_entries == 0 &&
-           in_bytes < 0xFFFFFFFELL && (a.act == YL_LINEAR || a.act == YL_LEAKY);
+           in_bytes < 0xFFFFFFFELL && (a.act == YL_LINEAR || a.act == YL_LEAKY) &&
+           (!a.pool_out || (!a.q_out && !a.bits_out && (a.H & 1) == 0));          // fused [maxpool]: FP32 outputs, whole windows
 }
 
 int launch_conv_f32_first(const ConvF32Args &a, void *stream, char *name, size_t name_len)
 {
     if (!first_layer_valu_applicable(a)) return (int)hipErrorInvalidValue;
     ConvFirstDev d;
-    d.in = a.in; d.wt = a.wt; d.bias = a.bias; d.out = a.out; d.bits_out = a.bits_out;
+    d.in = a.in; d.wt = a.wt; d.bias = a.bias; d.out = a.out; d.bits_out = a.bits_out; d.pool_out = a.pool_out;
     d.q_out = a.q_out; d.q_mult = a.q_mult; d.q_G = a.q_G;
     d.B = a.B; d.H = a.H; d.W = a.W; d.M = a.M; d.Mpad = a.Mpad; d.act = a.act;
     d.Wq = (a.W + 3) / 4;
-    d.total = (long long)a.B * a.H * d.Wq;
+    d.total = (long long)a.B * (a.pool_out ? a.H / 2 : a.H) * d.Wq;          // pool kernel: a lane owns two output rows
     d.rec = (unsigned)((long long)a.B * a.C * a.H * a.W * 4);
     const long long blocks = (d.total + 255) / 256;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks), block(256);
     hipStream_t s = (hipStream_t)stream;
     const bool wide = a.M > 16;
+    if (a.pool_out) {
+#define YL_FIRST_POOL(CC)                                                                                   \
+    do {                                                                                                    \
+        if (wide) hipLaunchKernelGGL((conv_f32_first_pool_kernel<CC, 32>), grid, block, 0, s, d);           \
+        else hipLaunchKernelGGL((conv_f32_first_pool_kernel<CC, 16>), grid, block, 0, s, d);                \
+    } while (0)
+        switch (a.C) {
+        case 1: YL_FIRST_POOL(1); break;
+        case 2: YL_FIRST_POOL(2); break;
+        default: YL_FIRST_POOL(3); break;
+        }
+#undef YL_FIRST_POOL
+        if (name) snprintf(name, name_len, "conv_f32_first<valu,2x4px,m%d,%s>", wide ? 32 : 16, a.out ? "pool+" : "pool");
+        return (int)hipGetLastError();
+    }
 #define YL_FIRST_LAUNCH(CC, MPP, QQ) hipLaunchKernelGGL((conv_f32_first_kernel<CC, MPP, QQ>), grid, block, 0, s, d)
 #define YL_FIRST_C(CC)                                                                             \
     do {                                                                                           \

@@ -514,6 +514,18 @@ static int launch_conv_f32_direct(const ConvF32Args &a, int cfg, int variant, vo
     return rc;
 }
 
+// The two branches of launch_conv_f32 below whose kernels have a pooled output (kept next to it on purpose).
+bool conv_f32_pool_fusable(const ConvF32Args &a0, const ConvF32Opts &o)
+{
+    ConvF32Args a = a0;
+    a.pool_out = nullptr;
+    if (a.q_out || a.bits_out || a.add || a.yolo_entries > 0 || ((a.H | a.W) & 1) || a.OH != a.H || a.OW != a.W) return false;
+    if (o.force_tile == 0 && (o.variant & 8) && first_layer_valu_applicable(a)) return true;
+    return a.wino32_u && (o.force_tile == 31 || (o.force_tile == 0 && o.winograd && a.C >= ((o.variant & 32) ? 16 : ((o.variant & 16) ? 32 : 64)) &&
+                                                wino32_fits(a.B, a.M, a.H, a.W))) &&
+           wino_applicable(a.C, a.M, a.size, a.stride, a.pad) && a.H >= 4 && a.W >= 4 && a.C / 4 >= 4 && ((a.C / 4) & 1) == 0;
+}
+
 // Kernel choice for one FP32 convolution.  o.force_tile: 0 = heuristic, 11..22 = direct tile
 // 1..12 of launch_conv_f32_direct, 31 = Winograd (error if the layer has no packed U).
 int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, char *name, size_t name_len)
@@ -522,6 +534,9 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
     // ([64,288,92416]) Winograd wins stand-alone (1.59 vs 2.16 ms) but not in the network, where the
     // layer carries a fused shortcut and is bound by 3 GB of epilogue traffic (2.31 vs 2.2 ms): C >= 64.
     if (a.q_out && a.wino32_u) return (int)hipErrorInvalidValue;      // the planner gives q_out to direct layers only
+    // a fused [maxpool] was planned for a kernel that has the pooled output: a later change of the kernel-selection
+    // knobs must fail loudly, not drop the pooling layer's tensor
+    if (a.pool_out && !conv_f32_pool_fusable(a, o)) return (int)hipErrorInvalidValue;
     // RGB first layers with <= 16 filters: the VALU kernel (force_tile 41 keeps the MFMA first-layer kernel for A/B)
     if (o.force_tile == 0 && (o.variant & 8) && first_layer_valu_applicable(a))
         return launch_conv_f32_first(a, stream, name, name_len);
@@ -531,7 +546,7 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
         return launch_conv_f32_direct(a, (o.force_tile == 14 || o.force_tile == 22) ? o.force_tile - 10 :
                                       (((long long)((a.M + 127) / 128) * (((long long)a.B * a.OH * a.OW + 127) / 128) >= 512) ? 12 : 4),
                                       o.variant, stream, name, name_len);
-    if (a.wino32_u && (o.force_tile == 31 || (o.force_tile == 0 && o.winograd && a.C >= ((o.variant & 16) ? 32 : 64) &&
+    if (a.wino32_u && (o.force_tile == 31 || (o.force_tile == 0 && o.winograd && a.C >= ((o.variant & 32) ? 16 : ((o.variant & 16) ? 32 : 64)) &&
                                              wino32_fits(a.B, a.M, a.H, a.W))))
         return launch_conv_f32_wino32(a, a.wino32_u, o.variant, stream, name, name_len);
     if (o.force_tile == 31) return (int)hipErrorInvalidValue;   // forced on a layer without packed U

@@ -73,6 +73,7 @@ struct ConvWino32Dev {
     const float *add;
     float *out_add;
     float *out;
+    float *pool_out;       // fused [maxpool] 2x2 / stride 2 behind the layer (H, W even): [B][M][H/2][W/2], or nullptr
     int B, C, H, W, M;
     int th, tw, tpi, T;
     int tiles_m, tiles_t, nkb;
@@ -152,6 +153,15 @@ __device__ __forceinline__ void wino32_epilogue(const ConvWino32Dev &p, const f3
     const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc((void *)(p.add ? p.add : dummy), 0, p.add ? (int)tbytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_oadd = __builtin_amdgcn_make_buffer_rsrc((void *)(p.add ? p.out_add : dummy), 0, p.add ? (int)tbytes : 0, 0x00020000);
     const bool has_out = p.out != nullptr, has_add = p.add != nullptr;
+    // fused 2x2 / stride-2 [maxpool] (forward_maxpool_layer_cpu, src/additionally.c:1448-1482): an F(2x2) output tile IS
+    // one pooling window (H, W even: window origin 0, no out-of-range taps), so the lane that finishes a tile's four
+    // outputs also owns its pooled value -- one dword per lane, 32 consecutive tiles of a row = 128 contiguous bytes
+    const bool has_pool = p.pool_out != nullptr;
+    const unsigned PHW4 = (unsigned)((p.H >> 1) * (p.W >> 1)) * 4u;
+    const unsigned pbase = ((((unsigned)b_e * (unsigned)p.M + (unsigned)(m0 + 4 * half)) * (unsigned)(p.H >> 1) + (unsigned)ti_e) *
+                            (unsigned)(p.W >> 1) + (unsigned)tj_e) * 4u;
+    const __amdgpu_buffer_rsrc_t rs_pool = __builtin_amdgcn_make_buffer_rsrc((void *)(has_pool ? p.pool_out : dummy), 0,
+                                                                              has_pool ? (int)(tbytes >> 2) : 0, 0x00020000);
     float *mine = xch + wave * 2048 + lane;
     const float *theirs = xch + (wave ^ 2) * 2048 + lane;
 #pragma unroll
@@ -225,6 +235,16 @@ __device__ __forceinline__ void wino32_epilogue(const ConvWino32Dev &p, const f3
                     y[i][0] = (y[i][0] > 0.f) ? y[i][0] : (float)(.1 * (double)y[i][0]);
                     y[i][1] = (y[i][1] > 0.f) ? y[i][1] : (float)(.1 * (double)y[i][1]);
                 }
+            }
+            if (has_pool) {
+                // the reference's scan: max = -FLT_MAX; rows then columns; `if (val > max) max = val`
+                float mx = -3.402823466e+38f;
+                mx = (y[0][0] > mx) ? y[0][0] : mx;
+                mx = (y[0][1] > mx) ? y[0][1] : mx;
+                mx = (y[1][0] > mx) ? y[1][0] : mx;
+                mx = (y[1][1] > mx) ? y[1][1] : mx;
+                const bool okp = t_ok_e && (m < p.M);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mx), rs_pool, okp ? (int)(pbase + (unsigned)mrow * PHW4) : -1, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -573,6 +593,8 @@ int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, int vari
         return (int)hipErrorInvalidValue;
     ConvWino32Dev d;
     d.in = a.in; d.u = u_packed; d.bias = a.bias; d.add = a.add; d.out_add = a.out_add; d.out = a.out;
+    d.pool_out = a.pool_out;
+    if (a.pool_out && ((a.H | a.W) & 1)) return (int)hipErrorInvalidValue;      // a tile must be a whole pooling window
     d.B = a.B; d.C = a.C; d.H = a.H; d.W = a.W; d.M = a.M;
     d.th = (a.H + 1) / 2; d.tw = (a.W + 1) / 2; d.tpi = d.th * d.tw;
     const long long T = (long long)a.B * d.tpi;
@@ -594,7 +616,8 @@ int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, int vari
     case 2: hipLaunchKernelGGL(conv_f32_wino32_kernel<2>, grid, block, 0, s, d); break;
     default: hipLaunchKernelGGL(conv_f32_wino32_kernel<3>, grid, block, 0, s, d); break;
     }
-    if (name) snprintf(name, name_len, "conv_f32_wino<32x64t,f2x2%s%s>", (variant & 1) ? ",udma" : "", (variant & 2) ? ",apf" : "");
+    if (name) snprintf(name, name_len, "conv_f32_wino<32x64t,f2x2%s%s%s>", (variant & 1) ? ",udma" : "", (variant & 2) ? ",apf" : "",
+                       a.pool_out ? (a.out ? ",pool+" : ",pool") : "");
     return (int)hipGetLastError();
 }
 

@@ -9,8 +9,10 @@ namespace yl {
 // measured on MI355X, profiles/r2_ab_fp32_variants.txt: bit 1 +3.3 %, bit 2 +0.4 %, bit 3 +0.6 %, bit 4 +0.9 %, bit 0 -0.5 %.
 // (Bits 5-7 selected round 3's three alternative Winograd kernels -- all-planes-per-wave on 16x16x4, its warp-specialised
 // form, the 64-filter 8-wave tile: bit-identical, -2.1 / -17 / -4.4 % in the network, profiles/r3_ab_wino_kernels.txt --
-// removed from the library in round 4; the bits are ignored.)
-constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8 | 16;
+// removed from the library in round 4; bit 5 has a new meaning since, bits 6-7 are ignored.)
+// round 4: bit 5 (Winograd from 16 input channels: yolov3-tiny's 16 -> 32 layer at 208 x 208, 0.175 ms on the direct 32x256
+// tile + 0.063 ms of [maxpool] -> 0.119 ms with the pooling folded into the Winograd epilogue; config 2 +7.8 %)
+constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8 | 16 | 32;
 
 // ---- K1: FP32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 ----
 struct ConvF32Args {
@@ -25,6 +27,9 @@ struct ConvF32Args {
     int q_G = 0;          // its channel groups (Cpad/16); direct kernel only, needs M % 16 == 0
     uint64_t *bits_out = nullptr;   // optional sign words (x > 0) of the activated output, bits[B][1][OH][OW], for an XNOR
                           // convolution behind this layer; first-layer kernel only (conv_f32_smallk.hip, M <= 32)
+    float *pool_out = nullptr; // optional fused [maxpool] 2x2 / stride 2 / pad 1 behind the layer (H, W even): [B][M][H/2][W/2],
+                          // written by the epilogue next to (or instead of, out == nullptr) the full tensor; only the kernels
+                          // conv_f32_pool_fusable() names have it (K1f: a lane owns a 2 x 4 patch; K1w: an F(2x2) tile is a window)
     int yolo_entries = 0; // > 0: the [yolo] layer that follows is folded into the epilogue (1x1 direct kernel): rows
                           // m with m % yolo_entries not in {2, 3} get logistic_activate, `out` is the YOLO layer's tensor
     int B, C, H, W, M, OH, OW;
@@ -42,13 +47,15 @@ struct ConvF32Opts {
     // schedule variants kept switchable for same-box A/B runs (yl_network_set_variant): bit 0 Winograd U panels by
     // LDS-DMA, bit 1 Winograd epilogue requests the [shortcut] operand ahead of its LDS exchange, bit 2 1x1 direct
     // kernel loads the B panel as float4 rows, bit 3 LDS-free small-K kernel for the first layer (C*size^2 <= 32),
-    // bit 4 Winograd from 32 input channels up (default: from 64), bits 5-7 unused (round 3's alternative Winograd
-    // kernels, removed), bit 8 XNOR layers between XNOR layers keep the float epilogue instead of the count
+    // bit 4 Winograd from 32 input channels up (without it: from 64), bit 5 Winograd from 16 input channels up,
+    // bits 6-7 unused (round 3's alternative Winograd kernels, removed), bit 8 XNOR layers between XNOR layers keep the float epilogue instead of the count
     // threshold (conv_xnor.hip; same bits either way), bit 9 XNOR layers always use 64-filter workgroups where the layer
     // has 64 filters (default: 32-filter workgroups on shallow grids).  (An 8-byte-access epilogue for odd map widths was measured and dropped: no gain,
     // profiles/r2_ab_fp32_variants.txt.)
     int variant = YL_VARIANT_DEFAULT;
 };
+// would launch_conv_f32 send this layer (a.pool_out ignored) to a kernel that can fold a 2x2 / stride-2 [maxpool]?
+bool conv_f32_pool_fusable(const ConvF32Args &a, const ConvF32Opts &o);
 // writes the name of the kernel instance it launched into name[name_len]
 int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, char *name, size_t name_len);
 // K1w (conv_f32_wino32.hip): Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 layers,

@@ -445,7 +445,7 @@ static int to_device(Network &net, int device)
     }
     if (net.binbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_binbuf, net.binbuf_bytes));
     // ---- optional conv+shortcut fusion plan ----
-    for (Layer &l : net.layers) { l.fused_shortcut = -1; l.fused_yolo = -1; l.fused_into_conv = false; }
+    for (Layer &l : net.layers) { l.fused_shortcut = -1; l.fused_yolo = -1; l.fused_pool = -1; l.fused_into_conv = false; }
     if (net.fuse && !net.debug) {
         const int nl = (int)net.layers.size();
         for (int i = 1; i < nl; ++i) {
@@ -592,6 +592,29 @@ static int to_device(Network &net, int device)
                 }
             }
         }
+        // ---- 2x2 / stride-2 [maxpool] folded into the FP32 convolution in front of it (round 4): the kernels whose
+        //      lanes finish whole pooling windows (K1f: a 2 x 4 patch per lane; K1w: an F(2x2) output tile) write the
+        //      pooled tensor themselves; the full-resolution tensor is written only where something else reads it
+        //      (yolov3-tiny: layer 8 also feeds a [route]).  forward_maxpool_layer_cpu, src/additionally.c:1448-1482:
+        //      even H and W => window origin 0, no out-of-range taps, max is exact => the same bits as the two kernels.
+        for (int j = 1; j < nl; ++j) {
+            Layer &pl = net.layers[j];
+            Layer &cv = net.layers[j - 1];
+            if (pl.type != YL_MAXPOOL || pl.size != 2 || pl.stride != 2 || pl.pad < 0 || pl.pad > 1 || pl.pool_bits_mode != 0 || pl.skip_f32_out) continue;
+            if ((pl.h | pl.w) & 1 || pl.out_h != pl.h / 2 || pl.out_w != pl.w / 2) continue;
+            if (cv.type != YL_CONVOLUTIONAL || cv.conv_mode != CONV_F32 || cv.xnor || cv.binarize_input || !hot_activation(cv.activation)) continue;
+            if (cv.fused_shortcut >= 0 || cv.fused_yolo >= 0 || cv.q_out_layer >= 0 || cv.bits_out_slot >= 0 || cv.skip_f32_out) continue;
+            ConvF32Args a;
+            a.in = nullptr; a.wt = cv.d_weights_t; a.bias = cv.d_biases; a.add = nullptr; a.out_add = nullptr; a.out = nullptr;
+            a.B = net.batch; a.C = cv.c; a.H = cv.h; a.W = cv.w; a.M = cv.n; a.OH = cv.out_h; a.OW = cv.out_w;
+            a.K = cv.size * cv.size * cv.c; a.Kpad = cv.Kpad; a.Mpad = cv.Mpad;
+            a.size = cv.size; a.stride = cv.stride; a.pad = cv.pad; a.act = cv.activation; a.tapmajor = cv.tapmajor;
+            a.wino32_u = cv.d_wino32_u;
+            if (!conv_f32_pool_fusable(a, net.conv_opts)) continue;
+            cv.fused_pool = j;
+            pl.fused_into_conv = true;
+            cv.skip_f32_out = !referenced_elsewhere(j - 1, j);
+        }
     }
     // the pack kernels are done with the scratch once the stream is idle
     YL_HIP(hipStreamSynchronize((hipStream_t)net.stream));
@@ -651,6 +674,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
                 a.yolo_entries = yo.classes + 5;
                 a.out = yo.d_output;
             }
+            if (l.fused_pool >= 0) a.pool_out = net.layers[l.fused_pool].d_output;      // 2x2 / stride-2 [maxpool] written by this epilogue
             if (l.bits_out_slot >= 0)       // FP32 first layer -> [maxpool] -> XNOR conv: sign words instead of the FP32 tensor
                 a.bits_out = net.d_bitbuf + (size_t)(l.bits_out_slot % 3) * (net.bitbuf_bytes / sizeof(uint64_t));
             YL_LAUNCH(launch_conv_f32(a, net.conv_opts, s, l.kernel_name, sizeof(l.kernel_name)), "conv_f32");
@@ -753,6 +777,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
         break;
     }
     case YL_MAXPOOL: {
+        if (l.fused_into_conv) break;          // written by the epilogue of the convolution in front of it
         auto ring = [&](int slot) { return net.d_bitbuf + (size_t)(slot % 3) * (net.bitbuf_bytes / sizeof(uint64_t)); };
         if (l.pool_bits_mode == 1)
             YL_LAUNCH(launch_bit_maxpool(ring((int)i), ring((int)i + 1), B, (l.c + 63) / 64, l.h, l.w, l.out_h, l.out_w,
@@ -1126,6 +1151,7 @@ int yl_network_layer_traffic(const yl_network *net, int i, double *bytes)
         }
         if (fused) { rd += 4 * out_el; wr += 4 * out_el; }                // [shortcut] operand in, sum out
         else if (!l.skip_f32_out) wr += 4 * out_el;
+        if (l.fused_pool >= 0) wr += out_el;                              // the pooled tensor of the fused [maxpool]: a quarter of the elements
         if (l.q_out_layer >= 0) wr += (l.conv_mode == CONV_BF16 ? 2 : 1) * out_el;   // int8 / bf16 side output
         break;
     }
@@ -1139,7 +1165,7 @@ int yl_network_layer_traffic(const yl_network *net, int i, double *bytes)
         const double wi = B * (double)l.h * l.w * 8.0 * ((l.c + 63) / 64), wo = B * (double)l.out_h * l.out_w * 8.0 * ((l.c + 63) / 64);
         if (l.pool_bits_mode == 1) { rd += wi; wr += wo; }
         else if (l.pool_bits_mode == 2) { rd += 4 * in_el; wr += wo; }
-        if (!l.skip_f32_out) { rd += 4 * in_el; wr += 4 * out_el; }
+        if (!l.skip_f32_out && !l.fused_into_conv) { rd += 4 * in_el; wr += 4 * out_el; }
         break;
     }
     case YL_ROUTE:

@@ -74,6 +74,7 @@ struct Layer {
     char kernel_name[64] = "";           // kernel instance of this layer's last launch
     int   fused_shortcut = -1;           // conv: index of the [shortcut] layer folded into its epilogue
     int   fused_yolo = -1;               // FP32 1x1 head conv: index of the [yolo] layer folded into its epilogue
+    int   fused_pool = -1;               // FP32 conv (K1f / K1w): index of the 2x2 / stride-2 [maxpool] layer its epilogue also writes
     bool  fused_into_conv = false;       // shortcut: produced by the preceding conv's epilogue
     bool  q_from_producer = false;       // INT8 conv: its quantised input is written by the producing conv
     bool  q_from_route = false;          // INT8 conv: its input is a multi-input [route], quantised source by source
