@@ -643,16 +643,17 @@ def test_winograd_variants_bit_identical(shape):
     net.set_conv_tile(31)
     base = net.predict(x).copy()
     assert "wino" in net.layer_kernel(0) and "udma" not in net.layer_kernel(0)
-    for v in (1, 2, 3):
+    for v in (1, 2, 3, 64, 66, 66):           # 64: persistent workgroups (twice: the work counters must be back at zero)
         net.set_variant(v)
         got = net.predict(x)
         if v & 1:
             assert "udma" in net.layer_kernel(0)
+        assert (",pers" in net.layer_kernel(0)) == bool(v & 64)
         assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), "variant %d shape %r" % (v, shape)
     net.close()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 15, 30, 31])
+@pytest.mark.parametrize("variant", [1, 2, 3, 15, 30, 31, 62, 126])
 def test_variants_whole_network_fused_bit_identical(variant):
     """yolov3 with conv+[shortcut] fusion (the benched setup): every materialised tensor and the detections of
     a run with the schedule variants equal the plain schedule's bit for bit (odd and even map sizes)."""
@@ -660,7 +661,7 @@ def test_variants_whole_network_fused_bit_identical(variant):
     cfg, wts = common.model_files(name, width, height)
     x = common.seeded_input(batch, 3, height, width)
     # bit 4 changes WHICH kernel a layer takes (Winograd from C = 32), not a schedule
-    a = Network.load(cfg, wts, batch, 0, device=0, fuse=True, variant=variant & 16)
+    a = Network.load(cfg, wts, batch, 0, device=0, fuse=True, variant=variant & 48)
     b = Network.load(cfg, wts, batch, 0, device=0, fuse=True, variant=variant)
     a.predict(x)
     b.predict(x)
@@ -670,7 +671,9 @@ def test_variants_whole_network_fused_bit_identical(variant):
             continue
         assert np.array_equal(a.layer_output(i).view(np.uint32), b.layer_output(i).view(np.uint32)), "layer %d" % i
     kernels = [b.layer_kernel(i) for i in range(b.n)]
-    if variant & 1:
+    if variant & 64:
+        assert any(",pers" in k for k in kernels)           # persistent Winograd workgroups, fused [shortcut] included
+    elif variant & 1:
         assert any("udma" in k for k in kernels)
     if variant & 8:
         assert "conv_f32_first" in kernels[0]          # 160 wide: K1f (K1s only where W % 4 != 0)

@@ -4,6 +4,7 @@
 # GPU box on the Winograd shapes of yolov3-608 at batch 64.  Results of X_DBG != 0 builds are garbage by design.
 #   bash tools/ab_builds.sh build "0 7 64 128 256"       (here, cross-compiles)
 #   bash tools/ab_builds.sh run   "0 7 64 128 256" [variant]   (on the GPU box)
+# A value that is not a number is a tag whose compiler flags come from the environment: ABFLAGS_<tag>="-DXGT=4 ..."
 set -e
 cd "$(dirname "$0")/.."
 MODE=$1; VALS=${2:-0}; VARIANT=${3:-30}
@@ -11,14 +12,15 @@ if [ "$MODE" = build ]; then
   mkdir -p tools/ab yolo2_light_amd/csrc/build_repro
   for v in $VALS; do
     ( cd yolo2_light_amd/csrc
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -DX_DBG=$v -c conv_f32_wino32.hip -o build_repro/wino32_x$v.o
+      case $v in ''|*[!0-9]*) fl_var=ABFLAGS_$v; FL=${!fl_var};; *) FL="-DX_DBG=$v";; esac
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize $FL -c conv_f32_wino32.hip -o build_repro/wino32_x$v.o
       objs=$(ls build/*.o | grep -v "build/conv_f32_wino32.o")
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ab/libyolo2hip_x$v.so $objs build_repro/wino32_x$v.o -ldl -lpthread )
     echo "built tools/ab/libyolo2hip_x$v.so"
   done
 else
   for v in $VALS; do
-    echo "== X_DBG=$v variant=$VARIANT"
+    echo "== build $v variant=$VARIANT"
     YOLO2HIP_LIB=$PWD/tools/ab/libyolo2hip_x$v.so timeout 300 python tools/sweep_conv.py --batch 64 --tiles 31 --only ${SHAPES:-6,9,12,15} --iters 5 --variant $VARIANT 2>&1 | grep -E "^\{" | python -c "
 import sys, json
 for l in sys.stdin:

@@ -78,6 +78,8 @@ struct ConvWino32Dev {
     int th, tw, tpi, T;
     int tiles_m, tiles_t, nkb;
     int act;
+    unsigned *tile_ctr;    // persistent form (VAR bit 2): 8 per-XCD work counters, all zero between launches
+    int total;             // workgroup tiles of the launch = tiles_m * tiles_t
 };
 
 __device__ __forceinline__ void fix_rows32(float (&d)[16], bool left, bool inv2, bool inv3)
@@ -291,12 +293,22 @@ __device__ __forceinline__ void wino32_epilogue(const ConvWino32Dev &p, const f3
 //   (vmcnt(0)) in front of the next barrier, which publishes them.
 // VAR bit 1 (APF): the fused [shortcut] operand of an epilogue round is requested BEFORE the round's LDS exchange
 //   and barrier instead of after them (its HBM latency hides behind the exchange).
+// VAR bit 2 (PERSIST, round 4): persistent workgroups.  The launch has two workgroups per CU; each draws its tiles from
+//   the work counter of ITS XCD (block b runs on XCD b % 8 -- an observation used for L2 locality only: the eight
+//   contiguous tile ranges are what the non-persistent form's XCD remap gives the same XCD, and a workgroup that lands
+//   elsewhere still computes correct tiles).  The next tile is drawn during the last panel of the current one, and its
+//   first patch rows / U panel are requested BEFORE the epilogue, so their HBM round trip, the tile decode and the
+//   workgroup launch itself hide behind the epilogue's LDS exchange and stores.  The workgroup that draws the last value
+//   of a counter (range length + workgroups of the XCD - 1: every other draw has happened) resets it for the next launch.
 template <int VAR>
 __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p)
 {
     constexpr bool UDMA = (VAR & 1) != 0;
     constexpr bool APF = (VAR & 2) != 0;
+    constexpr bool PERSIST = (VAR & 4) != 0;
+    static_assert(!(UDMA && PERSIST), "the persistent form stages U through registers");
     __shared__ __attribute__((aligned(16))) float smem[2 * XPA + 2 * XPB + ((X_DBG & 256) ? 12288 : 0)];      // 48 KB
+    __shared__ int s_next;
     float *As = smem;
     float *Bs = smem + 2 * XPA;
 
@@ -306,25 +318,33 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     const int l31 = lane & 31;
     const int half = lane >> 5;
 
-    const int nwg = gridDim.x;
+    // the tile range of this workgroup's XCD: logical tiles [x_start, x_start + x_len)
+    const int nwg = PERSIST ? p.total : (int)gridDim.x;
     const int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7;
     const int xcd = bid & 7;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int x_start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int x_len = q + (xcd < r ? 1 : 0);
+    const int x_wgs = ((int)gridDim.x + 7 - xcd) >> 3;          // workgroups of this launch with bid % 8 == xcd
+    // draw the next tile of this XCD: index within the range, or -1 when the range is used up (lane 0 of wave 0 only)
+#define X_DRAW(DST)                                                                                \
+    {                                                                                              \
+        const unsigned d_ = atomicAdd(p.tile_ctr + xcd, 1u);                                       \
+        if (d_ == (unsigned)(x_len + x_wgs - 1)) atomicExch(p.tile_ctr + xcd, 0u);                 \
+        DST = d_ < (unsigned)x_len ? (int)d_ : -1;                                                 \
+    }
+    int cur = bid >> 3;                                         // index within the XCD's range
+    if constexpr (PERSIST) {
+        if (tid == 0) { int d; X_DRAW(d) s_next = d; }
+        __syncthreads();
+        cur = __builtin_amdgcn_readfirstlane(s_next);
+        if (cur < 0) return;
+    }
 #ifndef XGT
 #define XGT 8
 #endif
     constexpr int GT = XGT;
     const int per_group = GT * p.tiles_m;
-    const int tg = logical / per_group;
-    const int rem_g = logical - tg * per_group;
-    const int t_in_last = p.tiles_t - tg * GT;
-    const int gsz = t_in_last < GT ? t_in_last : GT;
-    const int tile_m = __builtin_amdgcn_readfirstlane(rem_g / gsz);
-    const int tile_t = __builtin_amdgcn_readfirstlane(tg * GT + (rem_g - tile_m * gsz));
-    const int m0 = tile_m * XBM;
-    const int t0 = tile_t * XBT;
-
     const int HW = p.H * p.W;
     const int CHW = p.C * HW;
 
@@ -332,34 +352,47 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     const int t_s = tid & 63;
     const int half_s = wave & 1;
     const int kk_s = wave >> 1;
-    const int tg_s = t0 + t_s;
-    const bool t_ok = tg_s < p.T;
-    const int b_s = t_ok ? tg_s / p.tpi : 0;
-    const int r_s = tg_s - b_s * p.tpi;
-    const int ti_s = r_s / p.tw;
-    const int tj_s = r_s - ti_s * p.tw;
-
-    const int b_first = __builtin_amdgcn_readfirstlane(t0 / p.tpi);
-    const float *tile_base = p.in + (size_t)b_first * CHW - (ptrdiff_t)(p.W + 1);
-    size_t rec = ((size_t)p.B - b_first) * CHW * sizeof(float) + (size_t)(p.W + 1) * sizeof(float);
-    if (rec > 0xFFFFFFFEull) rec = 0xFFFFFFFEull;
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void *)tile_base, 0, (int)(unsigned)rec, 0x00020000);
+    // per-tile staging state (re-derived for the next tile in front of the epilogue in the persistent form)
+    int m0, t0;
+    __amdgpu_buffer_rsrc_t rsrc;
     int pvr[4];
-    const bool left_s = (tj_s == 0);
-    const bool inv2_s = (2 * tj_s + 1 >= p.W);
-    const bool inv3_s = (2 * tj_s + 2 >= p.W);
-    {
-        const unsigned base = ((unsigned)(b_s - b_first) * (unsigned)CHW + (unsigned)(2 * ti_s) * (unsigned)p.W +
-                               (unsigned)(2 * tj_s) + (left_s ? 1u : 0u)) * 4u;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const int iy = 2 * ti_s - 1 + rr;
-            const bool ok = t_ok && iy >= 0 && iy < p.H;
-            pvr[rr] = ok ? (int)(base + (unsigned)(rr * p.W) * 4u) : -1;
-        }
+    bool left_s, inv2_s, inv3_s;
+    const float *u_tile;
+#define X_SETUP_TILE(IDX)                                                                          \
+    {                                                                                              \
+        const int logical = x_start + (IDX);                                                       \
+        const int tg = logical / per_group;                                                        \
+        const int rem_g = logical - tg * per_group;                                                \
+        const int t_in_last = p.tiles_t - tg * GT;                                                 \
+        const int gsz = t_in_last < GT ? t_in_last : GT;                                           \
+        const int tile_m = __builtin_amdgcn_readfirstlane(rem_g / gsz);                            \
+        const int tile_t = __builtin_amdgcn_readfirstlane(tg * GT + (rem_g - tile_m * gsz));       \
+        m0 = tile_m * XBM;                                                                         \
+        t0 = tile_t * XBT;                                                                         \
+        const int tg_s = t0 + t_s;                                                                 \
+        const bool t_ok = tg_s < p.T;                                                              \
+        const int b_s = t_ok ? tg_s / p.tpi : 0;                                                   \
+        const int r_s = tg_s - b_s * p.tpi;                                                        \
+        const int ti_s = r_s / p.tw;                                                               \
+        const int tj_s = r_s - ti_s * p.tw;                                                        \
+        const int b_first = __builtin_amdgcn_readfirstlane(t0 / p.tpi);                            \
+        const float *tile_base = p.in + (size_t)b_first * CHW - (ptrdiff_t)(p.W + 1);              \
+        size_t rec = ((size_t)p.B - b_first) * CHW * sizeof(float) + (size_t)(p.W + 1) * sizeof(float); \
+        if (rec > 0xFFFFFFFEull) rec = 0xFFFFFFFEull;                                              \
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)tile_base, 0, (int)(unsigned)rec, 0x00020000); \
+        left_s = (tj_s == 0);                                                                      \
+        inv2_s = (2 * tj_s + 1 >= p.W);                                                            \
+        inv3_s = (2 * tj_s + 2 >= p.W);                                                            \
+        const unsigned base = ((unsigned)(b_s - b_first) * (unsigned)CHW + (unsigned)(2 * ti_s) * (unsigned)p.W + \
+                               (unsigned)(2 * tj_s) + (left_s ? 1u : 0u)) * 4u;                    \
+        _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                         \
+            const int iy = 2 * ti_s - 1 + rr;                                                      \
+            const bool ok = t_ok && iy >= 0 && iy < p.H;                                           \
+            pvr[rr] = ok ? (int)(base + (unsigned)(rr * p.W) * 4u) : -1;                           \
+        }                                                                                          \
+        u_tile = p.u + (size_t)tile_m * p.nkb * XPA;                                               \
     }
-    const float *u_tile = p.u + (size_t)tile_m * p.nkb * XPA;
+    X_SETUP_TILE(cur)
 
     float xr[16];
     float ur[2][4];
@@ -415,10 +448,6 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     }
 
     f32x16 acc[8];
-#pragma unroll
-    for (int pp = 0; pp < 8; ++pp)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[pp][e] = 0.f;
 
     const int wt = wave & 1;
     const int ph = wave >> 1;
@@ -441,16 +470,26 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
 
     // ---- prologue: panel 0 -> LDS stage 0 -> fragment set 0; panel 1 -> registers ----
     // (nkb = C/4 is even and >= 4: the launcher requires C % 8 == 0, C >= 16)
+    // The panel-0 requests of the FIRST tile; in the persistent form those of every later tile are issued in front of
+    // the previous tile's epilogue.
     if constexpr (UDMA) {
         X_DMA_U(0, 0)
         X_DMA_U(1, 1)
         X_LOAD_X(0, xr)
+    } else {
+        X_LOAD_X(0, xr)
+        X_LOAD_U(0, ur)
+    }
+  for (;;) {
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[pp][e] = 0.f;
+    if constexpr (UDMA) {
         X_STORE_X(0, xr)
         X_LOAD_X(1, xr)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
-        X_LOAD_X(0, xr)
-        X_LOAD_U(0, ur)
         X_STORE_X(0, xr)
         X_STORE_U(0, ur)
         X_LOAD_X(1, xr)
@@ -506,17 +545,26 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
         X_ITER(kb, 0, true, true)
         X_ITER(kb + 1, 1, true, true)
     }
+    int drawn = -1;
+    if constexpr (PERSIST) {
+        if (tid == 0) X_DRAW(drawn)           // the atomic's round trip hides behind the last two panels
+    }
     X_ITER(kb, 0, true, false)
     X_ITER(kb + 1, 1, false, false)
+    if constexpr (PERSIST) {
+        if (tid == 0) s_next = drawn;
+    }
     __syncthreads();            // the epilogue reuses the stages: every wave must be done reading them
-#undef X_READ_FRAGS
-#undef X_ITER
-#undef X_PIPE
-#undef X_STORE_U
-#undef X_DMA_U
-#undef X_STORE_X
-#undef X_LOAD_U
-#undef X_LOAD_X
+    const int e_m0 = m0, e_t0 = t0;           // the tile the epilogue finishes
+    int nxt = -1;
+    if constexpr (PERSIST) {
+        nxt = __builtin_amdgcn_readfirstlane(s_next);
+        if (nxt >= 0) {                       // next tile: decode, first patch rows and U panel on their way before the epilogue
+            X_SETUP_TILE(nxt)
+            X_LOAD_X(0, xr)
+            X_LOAD_U(0, ur)
+        }
+    }
 
     // ---- epilogue ----
     // The plane half `ph` is wave-uniform: branch once so that every accumulator index below is a compile-time
@@ -531,8 +579,21 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
         if (s == 12345.678f && p.out) p.out[0] = s;
         return;
     }
-    if (ph) wino32_epilogue<1, APF>(p, acc, smem, wave, lane, m0, t0);
-    else wino32_epilogue<0, APF>(p, acc, smem, wave, lane, m0, t0);
+    if (ph) wino32_epilogue<1, APF>(p, acc, smem, wave, lane, e_m0, e_t0);
+    else wino32_epilogue<0, APF>(p, acc, smem, wave, lane, e_m0, e_t0);
+    if (!PERSIST || nxt < 0) break;
+    __syncthreads();            // the exchange strips are the panel stages of the next tile
+  }
+#undef X_READ_FRAGS
+#undef X_ITER
+#undef X_PIPE
+#undef X_STORE_U
+#undef X_DMA_U
+#undef X_STORE_X
+#undef X_LOAD_U
+#undef X_LOAD_X
+#undef X_SETUP_TILE
+#undef X_DRAW
 }
 
 // the epilogue addresses the output (and the fused [shortcut] tensors of the same shape) with 32-bit byte offsets
@@ -608,16 +669,33 @@ int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, int vari
     d.act = a.act;
     const long long blocks = (long long)d.tiles_m * d.tiles_t;
     if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    const dim3 grid((unsigned)blocks), block(256);
+    d.total = (int)blocks;
+    d.tile_ctr = a.tile_ctr;
     hipStream_t s = (hipStream_t)stream;
-    switch (variant & 3) {
-    case 0: hipLaunchKernelGGL(conv_f32_wino32_kernel<0>, grid, block, 0, s, d); break;
-    case 1: hipLaunchKernelGGL(conv_f32_wino32_kernel<1>, grid, block, 0, s, d); break;
-    case 2: hipLaunchKernelGGL(conv_f32_wino32_kernel<2>, grid, block, 0, s, d); break;
-    default: hipLaunchKernelGGL(conv_f32_wino32_kernel<3>, grid, block, 0, s, d); break;
+    const bool persist = (variant & 64) != 0 && a.tile_ctr != nullptr;
+    if (persist) {
+        // two workgroups per CU (what the kernel's registers and LDS allow), or one per tile on small layers
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+            n_cu = v;
+        }
+        const long long slots = 2LL * n_cu;
+        const dim3 grid((unsigned)(blocks < slots ? blocks : slots)), block(256);
+        if (variant & 2) hipLaunchKernelGGL(conv_f32_wino32_kernel<6>, grid, block, 0, s, d);
+        else hipLaunchKernelGGL(conv_f32_wino32_kernel<4>, grid, block, 0, s, d);
+    } else {
+        const dim3 grid((unsigned)blocks), block(256);
+        switch (variant & 3) {
+        case 0: hipLaunchKernelGGL(conv_f32_wino32_kernel<0>, grid, block, 0, s, d); break;
+        case 1: hipLaunchKernelGGL(conv_f32_wino32_kernel<1>, grid, block, 0, s, d); break;
+        case 2: hipLaunchKernelGGL(conv_f32_wino32_kernel<2>, grid, block, 0, s, d); break;
+        default: hipLaunchKernelGGL(conv_f32_wino32_kernel<3>, grid, block, 0, s, d); break;
+        }
     }
-    if (name) snprintf(name, name_len, "conv_f32_wino<32x64t,f2x2%s%s%s>", (variant & 1) ? ",udma" : "", (variant & 2) ? ",apf" : "",
-                       a.pool_out ? (a.out ? ",pool+" : ",pool") : "");
+    if (name) snprintf(name, name_len, "conv_f32_wino<32x64t,f2x2%s%s%s%s>", (!persist && (variant & 1)) ? ",udma" : "", (variant & 2) ? ",apf" : "",
+                       persist ? ",pers" : "", a.pool_out ? (a.out ? ",pool+" : ",pool") : "");
     return (int)hipGetLastError();
 }
 

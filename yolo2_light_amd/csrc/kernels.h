@@ -38,6 +38,8 @@ struct ConvF32Args {
     int act;              // YL_LINEAR / YL_LEAKY
     int tapmajor;         // K order of `wt`: 0 = (c,ky,kx) like im2col_cpu, 1 = (ky,kx,c) (needs C % 16 == 0)
     const float *wino32_u; // Winograd-packed weights (wino32_pack_weights) or nullptr: 3x3/1/1 layers only
+    unsigned *tile_ctr = nullptr;  // 8 zero-initialised device counters of this layer: work queues of the persistent Winograd
+                           // form (variant bit 6), one per XCD; every launch leaves them at zero again
 };
 // per-network kernel-selection knobs (snapshotted in Network: two networks driven from two host
 // threads, one per GPU, share no mutable launch state)
@@ -48,7 +50,8 @@ struct ConvF32Opts {
     // LDS-DMA, bit 1 Winograd epilogue requests the [shortcut] operand ahead of its LDS exchange, bit 2 1x1 direct
     // kernel loads the B panel as float4 rows, bit 3 LDS-free small-K kernel for the first layer (C*size^2 <= 32),
     // bit 4 Winograd from 32 input channels up (without it: from 64), bit 5 Winograd from 16 input channels up,
-    // bits 6-7 unused (round 3's alternative Winograd kernels, removed), bit 8 XNOR layers between XNOR layers keep the float epilogue instead of the count
+    // bit 6 persistent Winograd workgroups (two per CU draw tiles from per-XCD counters, the next tile's first loads
+    // are issued in front of the epilogue), bit 7 unused, bit 8 XNOR layers between XNOR layers keep the float epilogue instead of the count
     // threshold (conv_xnor.hip; same bits either way), bit 9 XNOR layers always use 64-filter workgroups where the layer
     // has 64 filters (default: 32-filter workgroups on shallow grids).  (An 8-byte-access epilogue for odd map widths was measured and dropped: no gain,
     // profiles/r2_ab_fp32_variants.txt.)

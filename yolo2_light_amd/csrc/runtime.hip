@@ -93,6 +93,8 @@ static void free_device(Network &net)
         if (l.d_weights_t) (void)hipFree(l.d_weights_t);
         if (l.d_wino32_u) (void)hipFree(l.d_wino32_u);
         l.d_wino32_u = nullptr;
+        if (l.d_tile_ctr) (void)hipFree(l.d_tile_ctr);
+        l.d_tile_ctr = nullptr;
         if (l.d_biases) (void)hipFree(l.d_biases);
         if (l.d_weights_i8) (void)hipFree(l.d_weights_i8);
         if (l.d_weights_bits) (void)hipFree(l.d_weights_bits);
@@ -202,6 +204,8 @@ static int upload_conv(Network &net, Layer &l)
         if (wino) {
             YL_HIP(hipMalloc((void **)&l.d_wino32_u, u_floats * sizeof(float)));
             l.packed_bytes[1] = u_floats * sizeof(float);
+            YL_HIP(hipMalloc((void **)&l.d_tile_ctr, 8 * sizeof(unsigned)));
+            YL_HIP(hipMemsetAsync(l.d_tile_ctr, 0, 8 * sizeof(unsigned), (hipStream_t)s));
         }
         if (net.device_pack) {
             int rc = pack_source_to_device(net, l.weights.data(), sizeof(float) * (size_t)M * K, xnor_fallback ? l.mean_arr.data() : nullptr, M);
@@ -669,6 +673,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = kernel_act;
             a.tapmajor = l.tapmajor;
             a.wino32_u = l.d_wino32_u;
+            a.tile_ctr = l.d_tile_ctr;
             if (l.fused_yolo >= 0) {
                 const Layer &yo = net.layers[l.fused_yolo];
                 a.yolo_entries = yo.classes + 5;
