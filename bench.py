@@ -50,14 +50,16 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3     # "Peak FP32 (matrix)": v_mfma_f32_32x32x2_f
 BF16_MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA
 INT8_MFMA_PEAK_TOPS = 5000.0        # i8 MFMA = 2x the bf16 rate (~2.5 PF dense): 2048 op/clk/SIMD; ubench 4404
 HBM_PEAK_GBS = 8000.0               # HBM3E spec; 6.29 TB/s measured for a float4 copy
-# XNOR roof.  v_xnor_b32 and v_bcnt_u32_b32 are HALF-rate VALU instructions on gfx950: a wave64 instruction occupies
-# its SIMD for 4 cycles (measured, tools/valu_issue_bench.hip -> profiles/r4_valu_issue_bench.txt: 4.24-4.28 clk at
-# 2.4 GHz per wave-instruction with 8 waves per SIMD, independent accumulators, VGPR or SGPR weights alike; v_fma_f32 /
-# v_add_u32 on the same harness: 2.5-2.6, the guide's 2-cycle SIMD-32 rate).  One v_xnor + one accumulating v_bcnt per
-# 32 bit-MACs and lane: 1024 SIMDs x 64 lanes x 32 / 8 clk x 2.4 GHz = 629 T bit-MAC/s nominal; the microbenchmark's
-# own best (nothing but these two instructions, every CU, 8 waves per SIMD) is 588 T bit-MAC/s.
-VALU_POPC_PEAK_TBITMAC = 629.0
-VALU_POPC_MEASURED_TBITMAC = 588.0
+# XNOR roof, from measured VALU issue rates (tools/valu_issue_bench.hip -> profiles/r4_valu_issue_bench.txt; clk at 2.4 GHz
+# per wave64 instruction and SIMD, 8 waves per SIMD, independent accumulators, SGPR weights): v_fma_f32 / v_add_u32 /
+# v_xor_b32 / v_and_b32 2.3-2.6 (the guide's 2-cycle SIMD-32 rate), v_xnor_b32 4.3 and v_bcnt_u32_b32 4.2 -- HALF-rate
+# instructions.  Round 3's kernel (v_xnor + accumulating v_bcnt per 32 bit-MACs and lane) had a nominal roof of
+# 1024 SIMDs x 64 lanes x 32 / 8 clk x 2.4 GHz = 629 T bit-MAC/s (microbenchmark of that mix: 588).  Round 4 counts
+# MISMATCHES with the full-rate v_xor_b32 instead: 2 + 4 = 6 clk nominal per 32 bit-MACs and lane = 839 T bit-MAC/s.
+# The two kinds do not overlap as the sum of their rates suggests: a kernel of nothing but 8 x v_xor then 8 x v_bcnt
+# reaches 3.89 clk per instruction (32-long runs: 3.76) = 647 T bit-MAC/s -- the measured ceiling of this mix.
+VALU_POPC_PEAK_TBITMAC = 839.0
+VALU_POPC_MEASURED_TBITMAC = 647.0
 
 
 def parse_args():
@@ -466,9 +468,10 @@ def xnor_roofline(leg):
         "frac": tbm / VALU_POPC_PEAK_TBITMAC,
         "measured_ceiling": VALU_POPC_MEASURED_TBITMAC, "frac_of_measured_ceiling": tbm / VALU_POPC_MEASURED_TBITMAC,
         "achieved_is": "9*C*M bit-MACs per output pixel of the XNOR convolutions / measured duration of their launches; "
-                       "peak = one v_xnor_b32 + one accumulating v_bcnt_u32_b32 per 32 bit-MACs and lane, both half-rate "
-                       "(4 clk per wave64 instruction, measured: profiles/r4_valu_issue_bench.txt), 1024 SIMDs, 2.4 GHz; "
-                       "measured_ceiling = what a kernel of nothing but these two instructions reaches on every CU",
+                       "peak = one v_xor_b32 (full rate, 2 clk per wave64 instruction) + one accumulating v_bcnt_u32_b32 "
+                       "(half rate, 4 clk) per 32 bit-MACs and lane, 1024 SIMDs, 2.4 GHz (rates measured: "
+                       "profiles/r4_valu_issue_bench.txt); measured_ceiling = what a kernel of nothing but these two "
+                       "instructions in the kernel's arrangement reaches on every CU (round 3's v_xnor form: peak 629, ceiling 588)",
         "hbm_gbs": gbs, "hbm_peak_gbs": HBM_PEAK_GBS, "hbm_frac": gbs / HBM_PEAK_GBS,
         "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / max(dom["launches"], 1),
         "traffic": traffic, "traffic_source": traffic_src,

@@ -41,13 +41,22 @@ enum Mix {
     BCNT_IND8,         // v_bcnt_u32_b32 only
     XNOR_IND8,         // v_xnor_b32 only
     ADD_IND8,          // v_add_u32 only (plain integer VALU)
+    XOR_IND8,          // v_xor_b32 only: is the plain logic op full rate where v_xnor_b32 is not?
+    XOR_BCNT_IND8_S,   // v_xor_b32 + v_bcnt_u32_b32 (acc), SGPR weights: the mismatch-count form of the XNOR convolution
+    AND_IND8,          // v_and_b32 only
+    XOR8_BCNT8_S,      // 8 x v_xor_b32 then 8 x v_bcnt_u32_b32 (acc): the same work as XOR_BCNT_IND8_S, batched by instruction kind
+    XNOR8_BCNT8_S,     // 8 x v_xnor_b32 then 8 x v_bcnt_u32_b32 (acc)
+    XOR32_BCNT32_S,    // 32 x v_xor_b32 then 32 x v_bcnt_u32_b32 (acc): does a longer run of one kind pay?
     N_MIX
 };
 static const char *mix_name[N_MIX] = {
     "v_fma_f32 dependent chain", "v_fma_f32 8 independent chains", "v_pk_fma_f32 8 independent chains",
     "v_xnor_b32+v_bcnt_u32_b32(acc) dependent", "v_xnor_b32+v_bcnt_u32_b32(acc) 8 independent, VGPR weights",
     "v_xnor_b32+v_bcnt_u32_b32(acc) 8 independent, SGPR weights", "v_bcnt_u32_b32(acc) 8 independent",
-    "v_xnor_b32 8 independent", "v_add_u32 8 independent"};
+    "v_xnor_b32 8 independent", "v_add_u32 8 independent", "v_xor_b32 8 independent",
+    "v_xor_b32+v_bcnt_u32_b32(acc) 8 independent, SGPR weights", "v_and_b32 8 independent",
+    "8 x v_xor_b32 then 8 x v_bcnt_u32_b32(acc), SGPR weights", "8 x v_xnor_b32 then 8 x v_bcnt_u32_b32(acc), SGPR weights",
+    "32 x v_xor_b32 then 32 x v_bcnt_u32_b32(acc), SGPR weights"};
 // VALU instructions per unrolled body (all bodies are 64 instructions)
 constexpr int BODY = 64;
 
@@ -123,6 +132,59 @@ __global__ __launch_bounds__(256) void bench_kernel(unsigned long long *cycles, 
             asm volatile(REP8("v_xnor_b32 %0, %8, %0\n v_xnor_b32 %1, %8, %1\n v_xnor_b32 %2, %8, %2\n v_xnor_b32 %3, %8, %3\n"
                               "v_xnor_b32 %4, %8, %4\n v_xnor_b32 %5, %8, %5\n v_xnor_b32 %6, %8, %6\n v_xnor_b32 %7, %8, %7\n")
                          : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4), "+v"(n5), "+v"(n6), "+v"(n7) : "v"(x));
+        } else if (MIX == XOR8_BCNT8_S || MIX == XNOR8_BCNT8_S) {
+#define YL_B8(OP)                                                                                                              \
+            asm volatile(REP4(OP " %8, %16, %24\n " OP " %9, %17, %24\n " OP " %10, %18, %24\n " OP " %11, %19, %24\n "          \
+                              OP " %12, %20, %24\n " OP " %13, %21, %24\n " OP " %14, %22, %24\n " OP " %15, %23, %24\n"         \
+                              "v_bcnt_u32_b32 %0, %8, %0\n v_bcnt_u32_b32 %1, %9, %1\n v_bcnt_u32_b32 %2, %10, %2\n v_bcnt_u32_b32 %3, %11, %3\n" \
+                              "v_bcnt_u32_b32 %4, %12, %4\n v_bcnt_u32_b32 %5, %13, %5\n v_bcnt_u32_b32 %6, %14, %6\n v_bcnt_u32_b32 %7, %15, %7\n") \
+                         : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4), "+v"(n5), "+v"(n6), "+v"(n7),                      \
+                           "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)               \
+                         : "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(s4), "s"(s5), "s"(s6), "s"(s7), "v"(x));
+            if (MIX == XOR8_BCNT8_S) { YL_B8("v_xor_b32") } else { YL_B8("v_xnor_b32") }
+#undef YL_B8
+        } else if (MIX == XOR32_BCNT32_S) {
+            unsigned u0, u1, u2, u3, u4, u5, u6, u7, u8, u9, u10, u11, u12, u13, u14, u15, u16, u17, u18, u19, u20, u21, u22, u23;
+            // 32 temporaries: t0-t7 + u0-u23; xors of x with 8 SGPR weights (each weight used 4 times with shifted copies)
+            asm volatile(
+                "v_xor_b32 %8, %40, %48\n v_xor_b32 %9, %41, %48\n v_xor_b32 %10, %42, %48\n v_xor_b32 %11, %43, %48\n"
+                "v_xor_b32 %12, %44, %48\n v_xor_b32 %13, %45, %48\n v_xor_b32 %14, %46, %48\n v_xor_b32 %15, %47, %48\n"
+                "v_xor_b32 %16, %40, %0\n v_xor_b32 %17, %41, %1\n v_xor_b32 %18, %42, %2\n v_xor_b32 %19, %43, %3\n"
+                "v_xor_b32 %20, %44, %4\n v_xor_b32 %21, %45, %5\n v_xor_b32 %22, %46, %6\n v_xor_b32 %23, %47, %7\n"
+                "v_xor_b32 %24, %41, %0\n v_xor_b32 %25, %42, %1\n v_xor_b32 %26, %43, %2\n v_xor_b32 %27, %44, %3\n"
+                "v_xor_b32 %28, %45, %4\n v_xor_b32 %29, %46, %5\n v_xor_b32 %30, %47, %6\n v_xor_b32 %31, %40, %7\n"
+                "v_xor_b32 %32, %42, %0\n v_xor_b32 %33, %43, %1\n v_xor_b32 %34, %44, %2\n v_xor_b32 %35, %45, %3\n"
+                "v_xor_b32 %36, %46, %4\n v_xor_b32 %37, %47, %5\n v_xor_b32 %38, %40, %6\n v_xor_b32 %39, %41, %7\n"
+                "v_bcnt_u32_b32 %0, %8, %0\n v_bcnt_u32_b32 %1, %9, %1\n v_bcnt_u32_b32 %2, %10, %2\n v_bcnt_u32_b32 %3, %11, %3\n"
+                "v_bcnt_u32_b32 %4, %12, %4\n v_bcnt_u32_b32 %5, %13, %5\n v_bcnt_u32_b32 %6, %14, %6\n v_bcnt_u32_b32 %7, %15, %7\n"
+                "v_bcnt_u32_b32 %0, %16, %0\n v_bcnt_u32_b32 %1, %17, %1\n v_bcnt_u32_b32 %2, %18, %2\n v_bcnt_u32_b32 %3, %19, %3\n"
+                "v_bcnt_u32_b32 %4, %20, %4\n v_bcnt_u32_b32 %5, %21, %5\n v_bcnt_u32_b32 %6, %22, %6\n v_bcnt_u32_b32 %7, %23, %7\n"
+                "v_bcnt_u32_b32 %0, %24, %0\n v_bcnt_u32_b32 %1, %25, %1\n v_bcnt_u32_b32 %2, %26, %2\n v_bcnt_u32_b32 %3, %27, %3\n"
+                "v_bcnt_u32_b32 %4, %28, %4\n v_bcnt_u32_b32 %5, %29, %5\n v_bcnt_u32_b32 %6, %30, %6\n v_bcnt_u32_b32 %7, %31, %7\n"
+                "v_bcnt_u32_b32 %0, %32, %0\n v_bcnt_u32_b32 %1, %33, %1\n v_bcnt_u32_b32 %2, %34, %2\n v_bcnt_u32_b32 %3, %35, %3\n"
+                "v_bcnt_u32_b32 %4, %36, %4\n v_bcnt_u32_b32 %5, %37, %5\n v_bcnt_u32_b32 %6, %38, %6\n v_bcnt_u32_b32 %7, %39, %7\n"
+                : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4), "+v"(n5), "+v"(n6), "+v"(n7),
+                  "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7),
+                  "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(u4), "=&v"(u5), "=&v"(u6), "=&v"(u7),
+                  "=&v"(u8), "=&v"(u9), "=&v"(u10), "=&v"(u11), "=&v"(u12), "=&v"(u13), "=&v"(u14), "=&v"(u15),
+                  "=&v"(u16), "=&v"(u17), "=&v"(u18), "=&v"(u19), "=&v"(u20), "=&v"(u21), "=&v"(u22), "=&v"(u23)
+                : "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(s4), "s"(s5), "s"(s6), "s"(s7), "v"(x));
+        } else if (MIX == XOR_IND8) {
+            asm volatile(REP8("v_xor_b32 %0, %8, %0\n v_xor_b32 %1, %8, %1\n v_xor_b32 %2, %8, %2\n v_xor_b32 %3, %8, %3\n"
+                              "v_xor_b32 %4, %8, %4\n v_xor_b32 %5, %8, %5\n v_xor_b32 %6, %8, %6\n v_xor_b32 %7, %8, %7\n")
+                         : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4), "+v"(n5), "+v"(n6), "+v"(n7) : "v"(x));
+        } else if (MIX == AND_IND8) {
+            asm volatile(REP8("v_and_b32 %0, %8, %0\n v_and_b32 %1, %8, %1\n v_and_b32 %2, %8, %2\n v_and_b32 %3, %8, %3\n"
+                              "v_and_b32 %4, %8, %4\n v_and_b32 %5, %8, %5\n v_and_b32 %6, %8, %6\n v_and_b32 %7, %8, %7\n")
+                         : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4), "+v"(n5), "+v"(n6), "+v"(n7) : "v"(x));
+        } else if (MIX == XOR_BCNT_IND8_S) {
+            asm volatile(REP4("v_xor_b32 %8, %16, %24\n v_bcnt_u32_b32 %0, %8, %0\n v_xor_b32 %9, %17, %24\n v_bcnt_u32_b32 %1, %9, %1\n"
+                              "v_xor_b32 %10, %18, %24\n v_bcnt_u32_b32 %2, %10, %2\n v_xor_b32 %11, %19, %24\n v_bcnt_u32_b32 %3, %11, %3\n"
+                              "v_xor_b32 %12, %20, %24\n v_bcnt_u32_b32 %4, %12, %4\n v_xor_b32 %13, %21, %24\n v_bcnt_u32_b32 %5, %13, %5\n"
+                              "v_xor_b32 %14, %22, %24\n v_bcnt_u32_b32 %6, %14, %6\n v_xor_b32 %15, %23, %24\n v_bcnt_u32_b32 %7, %15, %7\n")
+                         : "+v"(n0), "+v"(n1), "+v"(n2), "+v"(n3), "+v"(n4), "+v"(n5), "+v"(n6), "+v"(n7),
+                           "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+                         : "s"(s0), "s"(s1), "s"(s2), "s"(s3), "s"(s4), "s"(s5), "s"(s6), "s"(s7), "v"(x));
         } else {
             asm volatile(REP8("v_add_u32 %0, %8, %0\n v_add_u32 %1, %8, %1\n v_add_u32 %2, %8, %2\n v_add_u32 %3, %8, %3\n"
                               "v_add_u32 %4, %8, %4\n v_add_u32 %5, %8, %5\n v_add_u32 %6, %8, %6\n v_add_u32 %7, %8, %7\n")
@@ -192,5 +254,11 @@ int main()
     run<BCNT_IND8>(n_cu, clock_ghz, d_cycles, d_sink);
     run<XNOR_IND8>(n_cu, clock_ghz, d_cycles, d_sink);
     run<ADD_IND8>(n_cu, clock_ghz, d_cycles, d_sink);
+    run<XOR_IND8>(n_cu, clock_ghz, d_cycles, d_sink);
+    run<XOR_BCNT_IND8_S>(n_cu, clock_ghz, d_cycles, d_sink);
+    run<AND_IND8>(n_cu, clock_ghz, d_cycles, d_sink);
+    run<XOR8_BCNT8_S>(n_cu, clock_ghz, d_cycles, d_sink);
+    run<XNOR8_BCNT8_S>(n_cu, clock_ghz, d_cycles, d_sink);
+    run<XOR32_BCNT32_S>(n_cu, clock_ghz, d_cycles, d_sink);
     return 0;
 }

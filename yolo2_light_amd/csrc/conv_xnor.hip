@@ -205,18 +205,63 @@ __device__ __forceinline__ int popc_acc(unsigned x, int c)
     asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(c) : "v"(x));
     return c;
 }
+template <int CWC, bool W32, int W0, int T, int I, int N>
+__device__ __forceinline__ void xor_taps(const WSet &w, const unsigned (&lo)[9][CWC], const unsigned (&hi)[9][CWC], unsigned (&xl)[N], unsigned (&xh)[N])
+{
+    if constexpr (I < N) {
+        xl[I] = lo[T + I][0] ^ wset_dword<2 * (W0 + T + I)>(w);
+        xh[I] = W32 ? 0u : (hi[T + I][0] ^ wset_dword<2 * (W0 + T + I) + 1>(w));
+        xor_taps<CWC, W32, W0, T, I + 1, N>(w, lo, hi, xl, xh);
+    }
+}
 
-// accumulate taps [T, T1) of one filter whose 9 words start at word W0 of the set
+// accumulate taps [T, T1) of one filter whose 9 words start at word W0 of the set.
+// Round 4: the accumulators count MISMATCHES, popcount(x ^ w), and the kernel turns them into match counts once per
+// filter (count = counted bits - mismatches).  v_xnor_b32 is a half-rate instruction on gfx950 (4.3 clk per wave64
+// instruction), v_xor_b32 a full-rate one (2.4), v_bcnt_u32_b32 half-rate either way (tools/valu_issue_bench.hip,
+// profiles/r4_valu_issue_bench.txt); alternating the two kinds costs the slower rate for both, so the xors of a group
+// of taps are issued together in front of their popcounts (measured on the microbenchmark: 4.29 -> 3.91 clk per
+// instruction).  Padding and halo bits behave as before: a channel-pad bit is 0 in the input and 1 in the weights
+// (always a mismatch), an out-of-image word reads as 0.
 template <int CWC, bool W32, int W0, int T, int T1>
 __device__ __forceinline__ int xnor_acc(const WSet &w, const unsigned (&lo)[9][CWC], const unsigned (&hi)[9][CWC], int c)
 {
-    if constexpr (T < T1) {
-        c = popc_acc(~(lo[T][0] ^ wset_dword<2 * (W0 + T)>(w)), c);
-        if (!W32) c = popc_acc(~(hi[T][0] ^ wset_dword<2 * (W0 + T) + 1>(w)), c);
-        return xnor_acc<CWC, W32, W0, T + 1, T1>(w, lo, hi, c);
-    } else {
-        return c;
+    constexpr int NT_ = T1 - T;
+    if constexpr (NT_ > 0) {
+        unsigned xl[NT_], xh[NT_];
+        xor_taps<CWC, W32, W0, T, 0, NT_>(w, lo, hi, xl, xh);
+#pragma unroll
+        for (int i = 0; i < NT_; ++i) {
+            c = popc_acc(xl[i], c);
+            if (!W32) c = popc_acc(xh[i], c);
+        }
     }
+    return c;
+}
+
+// taps [T, T + N) of BOTH filters of a step: the xors of the two filters first, then their popcounts with the two
+// accumulator chains alternating
+template <int CWC, bool W32, int T, int N>
+__device__ __forceinline__ void xnor_acc2(const WSet &w, const unsigned (&lo)[9][CWC], const unsigned (&hi)[9][CWC], int &ca, int &cb)
+{
+    unsigned al[N], ah[N], bl[N], bh[N];
+    xor_taps<CWC, W32, 0, T, 0, N>(w, lo, hi, al, ah);
+    xor_taps<CWC, W32, 9, T, 0, N>(w, lo, hi, bl, bh);
+    // the xors (plain C: the weight dwords stay SGPR operands) are pinned in front of their popcounts; hipcc's scheduler
+    // interleaves the two kinds one by one otherwise
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        asm("" : "+v"(al[i]), "+v"(bl[i]));
+        if (!W32) asm("" : "+v"(ah[i]), "+v"(bh[i]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        ca = popc_acc(al[i], ca);
+        cb = popc_acc(bl[i], cb);
+        if (!W32) { ca = popc_acc(ah[i], ca); cb = popc_acc(bh[i], cb); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int CWC, int FT, bool W32>
@@ -304,12 +349,20 @@ __global__ __launch_bounds__(256) void conv_xnor_kernel(ConvXnorDev p)
                 wset_load(nxt, p.w_bits + ((size_t)qn * nchunk + chn) * 18);
             }
             __builtin_amdgcn_sched_barrier(0);          // the prefetch stays above this step's arithmetic
-            cnt[2 * st] = xnor_acc<CWC, W32, 0, 1, 9>(cur, in_lo, in_hi, cnt[2 * st]);
-            cnt[2 * st + 1] = xnor_acc<CWC, W32, 9, 0, 9>(cur, in_lo, in_hi, cnt[2 * st + 1]);
+            // (tap 0 of the second filter, then taps 1-8 of both in two groups of four: 16 xors, 16 popcounts)
+            cnt[2 * st + 1] = xnor_acc<CWC, W32, 9, 0, 1>(cur, in_lo, in_hi, cnt[2 * st + 1]);
+            xnor_acc2<CWC, W32, 1, 4>(cur, in_lo, in_hi, cnt[2 * st], cnt[2 * st + 1]);
+            xnor_acc2<CWC, W32, 5, 4>(cur, in_lo, in_hi, cnt[2 * st], cnt[2 * st + 1]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 
+    // mismatches -> matches: every counted bit (9 taps x Cw words x 32 or 64 bits, pads included) either matched or not
+    {
+        const int counted = 9 * p.Cw * (W32 ? 32 : 64);
+#pragma unroll
+        for (int f = 0; f < FT; ++f) cnt[f] = counted - cnt[f];
+    }
     if (!n_ok) return;
     const int K = 9 * p.C;
     const size_t obase = (size_t)bimg * p.M * p.HW + pix;
