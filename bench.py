@@ -18,8 +18,12 @@ Rank 0 prints ONE JSON line with the driver's fields plus
                     kernel the 16-multiply form incl. odd-size tile padding, i.e. what the MFMA pipe issued)
                     / their HIP-event-measured duration inside the timed region, vs the 157.3 TFLOP/s FP32
                     matrix peak: `frac` <= 1.  The algorithmic rate (2*M*K*N) and the Winograd
-                    speed-up are separate fields.  `traffic` is read from the committed PMC passes
-                    (profiles/pmc_traffic.json; counters need their own serialising rocprofv3 runs).
+                    speed-up are separate fields.  `traffic` of the FP32 leg is MEASURED in the run (N=1, default
+                    line): two child runs of one step under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE
+                    (separate passes); the committed passes (profiles/pmc_traffic.json) are the fallback and the
+                    source for the other legs.
+  "torchrun_world1" -- the driver's multi-GPU launch form (torch.distributed.run, RCCL all-gather in the step) at
+                    world size 1 on this box, so that path executes on every default run (N=1 only).
   "int8"         -- value / ms_per_step of the INT8 leg, its roofline against HBM (algorithmic bytes of the
                     dominant INT8 kernel's launches / their measured duration vs 8 TB/s) with the INT8-MFMA
                     rate beside it, and the INT8-vs-FP32 detection agreement on the same images.
@@ -376,6 +380,84 @@ def pmc_traffic(leg, kernel_name: str):
     if leg.B != ref_batch:
         src += "; scaled linearly to this rank's batch of %d" % leg.B
     return traffic, src
+
+
+_KERNEL_SYMBOL = {          # bench kernel instance -> substring of the C++ kernel name rocprofv3 reports
+    "conv_f32_wino": "conv_f32_wino32_kernel<", "conv_i8_mfma<128x128>": "conv_i8_mfma_kernel<128, 128",
+    "conv_bf16_mfma<128x128>": "conv_bf16_mfma_kernel<128, 128", "conv_xnor": "conv_xnor_kernel<",
+}
+
+
+def live_pmc_traffic(args, kernel_name: str, mode: str, timeout_s: float = 240.0):
+    """HBM bytes per launch of `kernel_name`, MEASURED in this invocation: two child runs of this script (one step of the
+    same workload, --no-extras --raw-head --nms 0 so that only launches of the bench batch exist) under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` -- separate passes, no other tracing domain,
+    as MI355X_MICROARCH.md prescribes -- mean over the kernel's dispatches, FETCH_SIZE x2 (gfx950 counts 64 B per 128-B
+    request), counters are KiB.  Returns (bytes, source) or (None, reason); the committed passes (pmc_traffic.json)
+    stay the fallback."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, "rocprofv3 not found"
+    sym = next((v for k, v in _KERNEL_SYMBOL.items() if kernel_name.startswith(k)), None)
+    if sym is None:
+        return None, "no kernel symbol known for %s" % kernel_name
+    vals = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="yl_pmc_%s_" % counter.lower())
+        cmd = [rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pmc", "--",
+               sys.executable, os.path.join(ROOT, "bench.py"), "--model", args.model, "--size", str(args.size),
+               "--batch", str(args.batch), "--mode", mode, "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+               "--no-e2e", "--no-extras", "--raw-head", "--nms", "0"]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+        except (subprocess.TimeoutExpired, OSError) as ex:
+            return None, "rocprofv3 pass %s failed: %r" % (counter, ex)
+        files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None, "rocprofv3 pass %s: exit %d, %d csv" % (counter, r.returncode, len(files))
+        tot, n = 0.0, 0
+        for f in files:
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if sym in (row.get("Kernel_Name") or "") and (row.get("Counter_Name") or "") == counter:
+                        tot += float(row.get("Counter_Value") or 0.0)
+                        n += 1
+        shutil.rmtree(out, ignore_errors=True)
+        if n == 0:
+            return None, "no dispatch of %s in the %s pass" % (sym, counter)
+        vals[counter] = (tot / n, n)
+    traffic = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
+    return traffic, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in two child runs of one "
+                     "step of this workload (%d dispatches each), FETCH_SIZE %.1f KiB x2 + WRITE_SIZE %.1f KiB per launch"
+                     % (vals["FETCH_SIZE"][1], vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]))
+
+
+def torchrun_world1(args, timeout_s: float = 300.0):
+    """The driver's N > 1 launch form at world size 1 on this box: `python -m torch.distributed.run --nproc-per-node 1
+    bench.py --gpus 1` -- the one-process-per-GPU path (RCCL process group, all-gather of the detection records inside the
+    step) executes on every default run, not only when a multi-GPU node is available."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--model", args.model, "--size", str(args.size),
+           "--batch", str(args.batch), "--mode", "fp32", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-e2e", "--no-extras"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
+    line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
+    if r.returncode != 0 or line is None:
+        return {"error": "exit %d: %s" % (r.returncode, r.stderr[-300:])}
+    d = json.loads(line)
+    return {"value": d["value"], "unit": "images/sec", "ms_per_step": d["ms_per_step"], "n_gpus": d["n_gpus"],
+            "what": "python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 --mode fp32 --steps 5: RCCL process "
+                    "group of one rank, all_gather_into_tensor of the detection records inside every step"}
 
 
 def fp32_roofline(leg, args):
@@ -811,6 +893,23 @@ def main():
                         extras[key] = side_leg(args, torch, dist, dev, stream, Network, weights, zoo, m, sz, b)
                     except Exception as ex:
                         extras[key] = {"error": repr(ex)}
+        if world == 1 and not use_dist and not args.no_extras and do_fp32 and not xnor_model:
+            try:
+                extras["torchrun_world1"] = torchrun_world1(args)
+            except Exception as ex:
+                extras["torchrun_world1"] = {"error": repr(ex)}
+            # the dominant FP32 kernel's HBM traffic, measured now (the committed passes remain the fallback)
+            rl = result["fp32"].get("roofline") if "fp32" in result else None
+            if rl and rl.get("kernel"):
+                try:
+                    t_live, src = live_pmc_traffic(args, rl["kernel"], "fp32")
+                except Exception as ex:
+                    t_live, src = None, repr(ex)
+                if t_live is not None:
+                    rl["traffic_committed_passes"] = rl.get("traffic")
+                    rl["traffic"], rl["traffic_source"] = t_live, src
+                else:
+                    rl["traffic_source"] = (rl.get("traffic_source") or "") + "; live PMC pass unavailable: %s" % src
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
