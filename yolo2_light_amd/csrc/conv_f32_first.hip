@@ -74,9 +74,13 @@ __device__ __forceinline__ void first_load_window(float (&win)[R][6], __amdgpu_b
     }
 }
 
-template <int C, int MP, bool Q>
+// SIGNS: only the sign words are wanted (FP32 first layer -> [maxpool] -> XNOR convolution, tiny-yolo-obj_xnor.cfg): the
+// activation is not evaluated -- linear and leaky keep the sign, (x > 0) == (leaky(x) > 0) including +-0 -- and no FP32
+// row is stored; the bit of filter m is (acc + bias > 0), the same float sum the full epilogue activates.
+template <int C, int MP, bool Q, bool SIGNS = false>
 __global__ __launch_bounds__(256, Q ? 3 : 4) void conv_f32_first_kernel(ConvFirstDev p)
 {
+    static_assert(!(Q && SIGNS), "sign words or int8 units");
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const bool live = idx < p.total;
     const int q = (int)(idx % p.Wq);
@@ -192,12 +196,12 @@ __global__ __launch_bounds__(256, Q ? 3 : 4) void conv_f32_first_kernel(ConvFirs
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
                 float v = acc[ml][px] + bv;
-                if (p.act == YL_LEAKY) v = (v > 0.f) ? v : (float)(.1 * (double)v);
+                if (!SIGNS && p.act == YL_LEAKY) v = (v > 0.f) ? v : (float)(.1 * (double)v);
                 acc[ml][px] = v;
                 if (m < p.M) word[px] |= (v > 0.f ? 1u : 0u) << m;
             }
         }
-        if (live && p.out) {
+        if (!SIGNS && live && p.out) {
 #pragma unroll
             for (int ml = 0; ml < 8; ++ml) {
                 const int m = mh * 8 + ml;
@@ -429,10 +433,14 @@ int launch_conv_f32_first(const ConvF32Args &a, void *stream, char *name, size_t
         return (int)hipGetLastError();
     }
 #define YL_FIRST_LAUNCH(CC, MPP, QQ) hipLaunchKernelGGL((conv_f32_first_kernel<CC, MPP, QQ>), grid, block, 0, s, d)
+    const bool signs = a.bits_out && !a.out && !a.q_out;
 #define YL_FIRST_C(CC)                                                                             \
     do {                                                                                           \
         if (a.q_out) { if (wide) YL_FIRST_LAUNCH(CC, 32, true); else YL_FIRST_LAUNCH(CC, 16, true); }   \
-        else { if (wide) YL_FIRST_LAUNCH(CC, 32, false); else YL_FIRST_LAUNCH(CC, 16, false); }        \
+        else if (signs) {                                                                          \
+            if (wide) hipLaunchKernelGGL((conv_f32_first_kernel<CC, 32, false, true>), grid, block, 0, s, d);   \
+            else hipLaunchKernelGGL((conv_f32_first_kernel<CC, 16, false, true>), grid, block, 0, s, d);        \
+        } else { if (wide) YL_FIRST_LAUNCH(CC, 32, false); else YL_FIRST_LAUNCH(CC, 16, false); }      \
     } while (0)
     switch (a.C) {
     case 1: YL_FIRST_C(1); break;
@@ -441,7 +449,7 @@ int launch_conv_f32_first(const ConvF32Args &a, void *stream, char *name, size_t
     }
 #undef YL_FIRST_C
 #undef YL_FIRST_LAUNCH
-    if (name) snprintf(name, name_len, "conv_f32_first<valu,4px,m%d%s>", wide ? 32 : 16, a.q_out ? (a.out ? ",q" : ",qonly") : "");
+    if (name) snprintf(name, name_len, "conv_f32_first<valu,4px,m%d%s>", wide ? 32 : 16, a.q_out ? (a.out ? ",q" : ",qonly") : (signs ? ",signs" : ""));
     return (int)hipGetLastError();
 }
 
