@@ -392,8 +392,12 @@ def test_full_size_vs_reference_library(name, width, height, batch):
             assert matched.mean() > 0.99
             rr, gg = r[matched], g[j[matched]]
             np.testing.assert_allclose(gg[:, 4], rr[:, 4], rtol=1e-4, atol=1e-5)
-            probs_ok = np.isclose(gg[:, 6:], rr[:, 6:], rtol=1e-3, atol=1e-4).all(axis=1)
-            assert probs_ok.mean() > 0.98, "per-class probabilities after NMS disagree on %.2f%% of boxes" % (
+            # per-class probabilities after NMS under north_star's own tolerance (1e-4 relative): measured 100 % of
+            # 3 761 boxes at 608 and of 33-35 at 416 (1e-5: 50 % at 608); a suppression decided by a near-tie of two
+            # IoUs may flip for one box in a thousand
+            probs_ok = np.isclose(gg[:, 6:], rr[:, 6:], rtol=1e-4, atol=1e-5).all(axis=1)
+            print("image %d: %d boxes, class probabilities within 1e-4 on %.4f of them" % (b, len(rr), probs_ok.mean()))
+            assert probs_ok.mean() >= 0.999, "per-class probabilities after NMS disagree on %.2f%% of boxes" % (
                 100 * (1 - probs_ok.mean()))
     net.close()
 
