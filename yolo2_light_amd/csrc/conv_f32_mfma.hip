@@ -563,7 +563,9 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
         // layers too small to give every CU two workgroups fall back to 64x64 tiles.
         if (a.M <= 32) cfg = 3;
         else if (a.M <= 64) cfg = (a.size == 3) ? 4 : 2;      // 3x3 stride 2, M = 64: 64x64 2.34 ms vs 64x128 2.54
-        else if (a.size == 1 || a.M <= 256) cfg = (nblocks(128, 128) >= 512) ? 12 : 4;
+        // round 4 sweep (profiles/r4_sweep_stride2_tiles.txt): 3x3 layers from 128 filters up take the 8-wave 128x256 tile
+        // as well (M = 128, 256 at stride 2: 1.92 -> 1.82 ms, 1.81 -> 1.74 ms)
+        else if (a.size == 1 || a.M < 128) cfg = (nblocks(128, 128) >= 512) ? 12 : 4;
         else cfg = (nblocks(128, 256) >= 384) ? 10 : ((nblocks(128, 128) >= 512) ? 12 : 4);
         if (cfg <= 3 && nblocks(cfg == 2 ? 64 : 32, cfg == 3 ? 256 : 128) < 512) cfg = 4;
     }
