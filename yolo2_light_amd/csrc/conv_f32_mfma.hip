@@ -422,7 +422,7 @@ template <int BM, int BN, int WM, int WN, int BK, int NWAVES>
 static int launch_pipe(const ConvF32Dev &d, int ks, bool tapmajor, hipStream_t s, bool vec4 = false)
 {
     // the folded [yolo] epilogue exists for the two tiles head convolutions take (64x64, 128x128r)
-    constexpr bool YOLO_TILE = (BM == 64 && BN == 64) || (BM == 128 && BN == 128 && WM == 4);
+    constexpr bool YOLO_TILE = (BM == 64 && BN == 64) || (BM == 128 && BN == 128 && WM == 4) || (BM == 128 && BN == 256 && WM == 4);
     if (d.yolo_entries > 0 && !(YOLO_TILE && ks == 1 && !tapmajor)) return (int)hipErrorInvalidValue;
     ConvF32Dev p = d;
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -485,7 +485,7 @@ static int launch_conv_f32_direct(const ConvF32Args &a, int cfg, int variant, vo
     d.yolo_entries = a.yolo_entries;
     if (a.yolo_entries > 0) {
         if (a.size != 1 || a.pad != 0 || a.tapmajor || a.q_out || a.add) return (int)hipErrorInvalidValue;
-        if (cfg != 4 && cfg != 12) cfg = 12;
+        if (cfg != 4 && cfg != 12 && cfg != 10) cfg = 12;
     }
     hipStream_t s = (hipStream_t)stream;
     int ks = 0;
@@ -543,8 +543,9 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
     if (a.bits_out)                                                   // sign-word side output: only the first-layer kernels have it
         return smallk_applicable(a) ? launch_conv_f32_smallk(a, stream, name, name_len) : (int)hipErrorInvalidValue;
     if (a.yolo_entries > 0)                                           // folded [yolo]: 1x1 direct kernel, two tiles
-        return launch_conv_f32_direct(a, (o.force_tile == 14 || o.force_tile == 22) ? o.force_tile - 10 :
-                                      (((long long)((a.M + 127) / 128) * (((long long)a.B * a.OH * a.OW + 127) / 128) >= 512) ? 12 : 4),
+        return launch_conv_f32_direct(a, (o.force_tile == 14 || o.force_tile == 22 || o.force_tile == 20) ? o.force_tile - 10 :
+                                      (((long long)((a.M + 127) / 128) * (((long long)a.B * a.OH * a.OW + 255) / 256) >= 384) ? 10 :
+                                       (((long long)((a.M + 127) / 128) * (((long long)a.B * a.OH * a.OW + 127) / 128) >= 512) ? 12 : 4)),
                                       o.variant, stream, name, name_len);
     if (a.wino32_u && (o.force_tile == 31 || (o.force_tile == 0 && o.winograd && a.C >= ((o.variant & 32) ? 16 : ((o.variant & 16) ? 32 : 64)) &&
                                              wino32_fits(a.B, a.M, a.H, a.W))))
@@ -565,6 +566,9 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
         else if (a.M <= 64) cfg = (a.size == 3) ? 4 : 2;      // 3x3 stride 2, M = 64: 64x64 2.34 ms vs 64x128 2.54
         // round 4 sweep (profiles/r4_sweep_stride2_tiles.txt): 3x3 layers from 128 filters up take the 8-wave 128x256 tile
         // as well (M = 128, 256 at stride 2: 1.92 -> 1.82 ms, 1.81 -> 1.74 ms)
+        // round 4, in-network A/B (profiles/r4_ab_1x1_tile.txt): 1x1 layers from 128 filters on the 8-wave 128x256 tile,
+        // 22 launches 5.17 -> 4.82 ms, +0.7 % on the step
+        else if (a.size == 1 && a.M >= 128 && nblocks(128, 256) >= 384) cfg = 10;
         else if (a.size == 1 || a.M < 128) cfg = (nblocks(128, 128) >= 512) ? 12 : 4;
         else cfg = (nblocks(128, 256) >= 384) ? 10 : ((nblocks(128, 128) >= 512) ? 12 : 4);
         if (cfg <= 3 && nblocks(cfg == 2 ? 64 : 32, cfg == 3 ? 256 : 128) < 512) cfg = 4;
