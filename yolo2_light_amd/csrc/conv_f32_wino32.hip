@@ -115,6 +115,36 @@ __device__ __forceinline__ void input_transform32(const float (&d)[16], float (&
     }
 }
 
+// The same transform with the column masks folded in (round 4, VAR bit 3): the patch comes as loaded -- for a left-edge
+// tile from one column early, so its column 0 holds whatever precedes the row (finite: real data or the zeroed front pad
+// of the tensor) -- and the masks m0 / m2 / m3 (1.0 or 0.0 per lane: column 0 of a left-edge tile, columns 2 / 3 beyond
+// the right edge) enter the SECOND stage as multipliers: masking column s of d scales w[.][s] by m_s exactly, so
+// fma(w0, m0, -w2) is the old (m0*w0) - w2 with one rounding, bit for bit (a difference is possible only in the SIGN of
+// an exact zero of V).  24 v_cndmask per patch become 0 (even widths) or 4 v_mul (odd widths, column 2): on gfx950 the
+// f32 MFMA shares its datapath with the VALU -- every VALU instruction of ANY wave on the SIMD costs the matrix pipe
+// ~4.9 cycles (tools/mfma_f32_bench.hip, profiles/r4_mfma_f32_skeleton_bench.txt) -- so the kernel's efficiency is
+// 1024 / (1024 + 4.9 * VALU per panel and wave) and the instruction count of the staging code is what bounds it.
+template <bool ODD_W>
+__device__ __forceinline__ void input_transform32m(const float (&d)[16], float (&v)[16], float m0, float m2, float m3)
+{
+    float w[16];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        w[0 * 4 + s] = d[0 * 4 + s] - d[2 * 4 + s];
+        w[1 * 4 + s] = d[1 * 4 + s] + d[2 * 4 + s];
+        w[2 * 4 + s] = d[2 * 4 + s] - d[1 * 4 + s];
+        w[3 * 4 + s] = d[1 * 4 + s] - d[3 * 4 + s];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float w2 = ODD_W ? __fmul_rn(w[i * 4 + 2], m2) : w[i * 4 + 2];      // even widths have no column-2 mask
+        v[i * 4 + 0] = __fmaf_rn(w[i * 4 + 0], m0, -w2);
+        v[i * 4 + 1] = w[i * 4 + 1] + w2;
+        v[i * 4 + 2] = w2 - w[i * 4 + 1];
+        v[i * 4 + 3] = __fmaf_rn(-w[i * 4 + 3], m3, w[i * 4 + 1]);
+    }
+}
+
 }  // namespace
 
 // Epilogue of one wave.  Wave (wt, PH) holds M[i][j] for rows i = 2*PH, 2*PH+1 (planes 8*PH + 4*(i&1) + j) of the
@@ -306,6 +336,8 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     constexpr bool UDMA = (VAR & 1) != 0;
     constexpr bool APF = (VAR & 2) != 0;
     constexpr bool PERSIST = (VAR & 4) != 0;
+    constexpr bool LS = (VAR & 8) != 0;          // left-edge patches one column early, column masks folded into the transform
+    constexpr bool ODDW = (VAR & 16) != 0;       // (with LS) odd map width: the last tile column also masks patch column 2
     static_assert(!(UDMA && PERSIST), "the persistent form stages U through registers");
     __shared__ __attribute__((aligned(16))) float smem[2 * XPA + 2 * XPB + ((X_DBG & 256) ? 12288 : 0)];      // 48 KB
     __shared__ int s_next;
@@ -357,6 +389,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     __amdgpu_buffer_rsrc_t rsrc;
     int pvr[4];
     bool left_s, inv2_s, inv3_s;
+    float m0f = 1.f, m2f = 1.f, m3f = 1.f;
     const float *u_tile;
 #define X_SETUP_TILE(IDX)                                                                          \
     {                                                                                              \
@@ -383,8 +416,9 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
         left_s = (tj_s == 0);                                                                      \
         inv2_s = (2 * tj_s + 1 >= p.W);                                                            \
         inv3_s = (2 * tj_s + 2 >= p.W);                                                            \
+        m0f = left_s ? 0.f : 1.f; m2f = inv2_s ? 0.f : 1.f; m3f = inv3_s ? 0.f : 1.f;              \
         const unsigned base = ((unsigned)(b_s - b_first) * (unsigned)CHW + (unsigned)(2 * ti_s) * (unsigned)p.W + \
-                               (unsigned)(2 * tj_s) + (left_s ? 1u : 0u)) * 4u;                    \
+                               (unsigned)(2 * tj_s) + ((!LS && left_s) ? 1u : 0u)) * 4u;           \
         _Pragma("unroll") for (int rr = 0; rr < 4; ++rr) {                                         \
             const int iy = 2 * ti_s - 1 + rr;                                                      \
             const bool ok = t_ok && iy >= 0 && iy < p.H;                                           \
@@ -427,8 +461,12 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     {                                                                                              \
         float va[16];                                                                              \
         if (!(X_DBG & 32)) {                                                                       \
-            fix_rows32(XR, left_s, inv2_s, inv3_s);                                                \
-            input_transform32(XR, va);                                                             \
+            if constexpr (LS) {                                                                    \
+                input_transform32m<ODDW>(XR, va, m0f, m2f, m3f);                                   \
+            } else {                                                                               \
+                fix_rows32(XR, left_s, inv2_s, inv3_s);                                            \
+                input_transform32(XR, va);                                                         \
+            }                                                                                      \
         } else {                                                                                   \
             _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) va[e_] = XR[e_];                     \
         }                                                                                          \
@@ -448,6 +486,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     }
 
     f32x16 acc[8];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     const int wt = wave & 1;
     const int ph = wave >> 1;
@@ -481,10 +520,6 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
         X_LOAD_U(0, ur)
     }
   for (;;) {
-#pragma unroll
-    for (int pp = 0; pp < 8; ++pp)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[pp][e] = 0.f;
     if constexpr (UDMA) {
         X_STORE_X(0, xr)
         X_LOAD_X(1, xr)
@@ -509,13 +544,15 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     //               (fragments of panel kb-1) completed before the PREVIOUS barrier
     //   second half (8 MFMAs, k 2/3): fragments of panel kb+1 -> set SET^1, panel kb+2 -> registers
     // so no LDS latency is exposed in front of an MFMA block.
-#define X_ITER(KB, SET, DO_STORE, DO_LOAD)                                                         \
+#define X_ITER(KB, SET, DO_STORE, DO_LOAD) X_ITER_(KB, SET, DO_STORE, DO_LOAD, false)
+    /* FIRST: the accumulators start as the inline constant 0 of the MFMA's C operand instead of 128 v_mov per tile */ \
+#define X_ITER_(KB, SET, DO_STORE, DO_LOAD, FIRST)                                                 \
     {                                                                                              \
         const int buf = (KB) & 1;                                                                  \
         if (DO_STORE && !UDMA && !(X_DBG & 4)) X_STORE_U(buf ^ 1, ur)                              \
         if (DO_STORE && !(X_DBG & 4)) X_STORE_X(buf ^ 1, xr)                                       \
         _Pragma("unroll") for (int pp = 0; pp < 8; ++pp)                                           \
-            if (!(X_DBG & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][pp].x, fb[SET][pp][0], acc[pp], 0, 0, 0); \
+            if (!(X_DBG & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][pp].x, fb[SET][pp][0], (FIRST) ? zero16 : acc[pp], 0, 0, 0); \
         if (DO_STORE && X_DBG == 0) {                                                              \
             _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                     \
                 X_PIPE(0x002, 9) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                \
@@ -540,7 +577,10 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
 
-    int kb = 0;
+    // (nkb >= 4: the first pair of panels always loads panels 2 and 3)
+    X_ITER_(0, 0, true, true, true)
+    X_ITER(1, 1, true, true)
+    int kb = 2;
     for (; kb + 4 <= p.nkb; kb += 2) {
         X_ITER(kb, 0, true, true)
         X_ITER(kb + 1, 1, true, true)
@@ -673,6 +713,8 @@ int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, int vari
     d.tile_ctr = a.tile_ctr;
     hipStream_t s = (hipStream_t)stream;
     const bool persist = (variant & 64) != 0 && a.tile_ctr != nullptr;
+    // VAR bit 3: the input tensor has the library's front pad -> the transform with folded column masks
+    const bool ls = a.in_front_pad && (variant & 128) == 0;          // variant bit 7: A/B switch, keep the register-shift form
     if (persist) {
         // two workgroups per CU (what the kernel's registers and LDS allow), or one per tile on small layers
         static int n_cu = 0;
@@ -683,15 +725,31 @@ int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, int vari
         }
         const long long slots = 2LL * n_cu;
         const dim3 grid((unsigned)(blocks < slots ? blocks : slots)), block(256);
-        if (variant & 2) hipLaunchKernelGGL(conv_f32_wino32_kernel<6>, grid, block, 0, s, d);
-        else hipLaunchKernelGGL(conv_f32_wino32_kernel<4>, grid, block, 0, s, d);
+        if (ls && (a.W & 1)) {
+            if (variant & 2) hipLaunchKernelGGL(conv_f32_wino32_kernel<30>, grid, block, 0, s, d);
+            else hipLaunchKernelGGL(conv_f32_wino32_kernel<28>, grid, block, 0, s, d);
+        } else if (ls) {
+            if (variant & 2) hipLaunchKernelGGL(conv_f32_wino32_kernel<14>, grid, block, 0, s, d);
+            else hipLaunchKernelGGL(conv_f32_wino32_kernel<12>, grid, block, 0, s, d);
+        } else {
+            if (variant & 2) hipLaunchKernelGGL(conv_f32_wino32_kernel<6>, grid, block, 0, s, d);
+            else hipLaunchKernelGGL(conv_f32_wino32_kernel<4>, grid, block, 0, s, d);
+        }
     } else {
         const dim3 grid((unsigned)blocks), block(256);
-        switch (variant & 3) {
+        switch ((variant & 3) | (ls ? 8 : 0) | ((ls && (a.W & 1)) ? 16 : 0)) {
         case 0: hipLaunchKernelGGL(conv_f32_wino32_kernel<0>, grid, block, 0, s, d); break;
         case 1: hipLaunchKernelGGL(conv_f32_wino32_kernel<1>, grid, block, 0, s, d); break;
         case 2: hipLaunchKernelGGL(conv_f32_wino32_kernel<2>, grid, block, 0, s, d); break;
-        default: hipLaunchKernelGGL(conv_f32_wino32_kernel<3>, grid, block, 0, s, d); break;
+        case 3: hipLaunchKernelGGL(conv_f32_wino32_kernel<3>, grid, block, 0, s, d); break;
+        case 8: hipLaunchKernelGGL(conv_f32_wino32_kernel<8>, grid, block, 0, s, d); break;
+        case 9: hipLaunchKernelGGL(conv_f32_wino32_kernel<9>, grid, block, 0, s, d); break;
+        case 10: hipLaunchKernelGGL(conv_f32_wino32_kernel<10>, grid, block, 0, s, d); break;
+        case 11: hipLaunchKernelGGL(conv_f32_wino32_kernel<11>, grid, block, 0, s, d); break;
+        case 24: hipLaunchKernelGGL(conv_f32_wino32_kernel<24>, grid, block, 0, s, d); break;
+        case 25: hipLaunchKernelGGL(conv_f32_wino32_kernel<25>, grid, block, 0, s, d); break;
+        case 26: hipLaunchKernelGGL(conv_f32_wino32_kernel<26>, grid, block, 0, s, d); break;
+        default: hipLaunchKernelGGL(conv_f32_wino32_kernel<27>, grid, block, 0, s, d); break;
         }
     }
     if (name) snprintf(name, name_len, "conv_f32_wino<32x64t,f2x2%s%s%s%s>", (!persist && (variant & 1)) ? ",udma" : "", (variant & 2) ? ",apf" : "",

@@ -38,6 +38,9 @@ struct ConvF32Args {
     int act;              // YL_LINEAR / YL_LEAKY
     int tapmajor;         // K order of `wt`: 0 = (c,ky,kx) like im2col_cpu, 1 = (ky,kx,c) (needs C % 16 == 0)
     const float *wino32_u; // Winograd-packed weights (wino32_pack_weights) or nullptr: 3x3/1/1 layers only
+    bool in_front_pad = false;     // `in` has >= 4 readable bytes in front of it holding a FINITE value (library-owned tensors:
+                           // yl_internal.h ACT_FRONT_PAD); the Winograd kernel then fetches left-edge patches one column early
+                           // and folds the column masks into the transform instead of shifting registers
     unsigned *tile_ctr = nullptr;  // 8 zero-initialised device counters of this layer: work queues of the persistent Winograd
                            // form (variant bit 6), one per XCD; every launch leaves them at zero again
 };
@@ -51,7 +54,8 @@ struct ConvF32Opts {
     // kernel loads the B panel as float4 rows, bit 3 LDS-free small-K kernel for the first layer (C*size^2 <= 32),
     // bit 4 Winograd from 32 input channels up (without it: from 64), bit 5 Winograd from 16 input channels up,
     // bit 6 persistent Winograd workgroups (two per CU draw tiles from per-XCD counters, the next tile's first loads
-    // are issued in front of the epilogue), bit 7 unused, bit 8 XNOR layers between XNOR layers keep the float epilogue instead of the count
+    // are issued in front of the epilogue), bit 7 Winograd input transform in its round-3 form (register shift + 24 selects
+    // per patch instead of column masks folded into the transform; A/B switch), bit 8 XNOR layers between XNOR layers keep the float epilogue instead of the count
     // threshold (conv_xnor.hip; same bits either way), bit 9 XNOR layers always use 64-filter workgroups where the layer
     // has 64 filters (default: 32-filter workgroups on shallow grids).  (An 8-byte-access epilogue for odd map widths was measured and dropped: no gain,
     // profiles/r2_ab_fp32_variants.txt.)

@@ -87,7 +87,7 @@ static void free_device(Network &net)
     // yl_network_forward, _detect_batch, _set_input_u8); the stream is non-blocking, so be explicit
     if (net.stream) (void)hipStreamSynchronize((hipStream_t)net.stream);
     for (Layer &l : net.layers) {
-        if (l.d_output && !l.d_output_alias) (void)hipFree(l.d_output);
+        if (l.d_output && !l.d_output_alias) (void)hipFree(l.d_output - ACT_FRONT_PAD);
         l.d_output = nullptr;
         if (l.host_in_heads) { l.host_output = nullptr; l.host_kind = HOST_NONE; l.host_in_heads = false; }
         if (l.d_weights_t) (void)hipFree(l.d_weights_t);
@@ -109,7 +109,7 @@ static void free_device(Network &net)
     }
     if (net.d_pack_src) (void)hipFree(net.d_pack_src);
     net.d_pack_src = nullptr; net.pack_src_bytes = 0;
-    if (net.d_input) (void)hipFree(net.d_input);
+    if (net.d_input) (void)hipFree(net.d_input - ACT_FRONT_PAD);
     if (net.d_qbuf) (void)hipFree(net.d_qbuf);
     if (net.d_bitbuf) (void)hipFree(net.d_bitbuf);
     if (net.d_binbuf) (void)hipFree(net.d_binbuf);
@@ -371,7 +371,11 @@ static int to_device(Network &net, int device)
     select_conv_modes(net);
     net.qbuf_bytes = 0; net.bitbuf_bytes = 0; net.binbuf_bytes = 0;
     const size_t in_elems = (size_t)net.batch * net.c * net.h * net.w;
-    YL_HIP(hipMalloc((void **)&net.d_input, in_elems * sizeof(float)));
+    // every activation tensor the library owns has ACT_FRONT_PAD readable floats in front of it: the Winograd kernel reads
+    // ONE float before a tensor (column -1 of the first patch row of the first image, masked to zero in the transform)
+    YL_HIP(hipMalloc((void **)&net.d_input, (in_elems + ACT_FRONT_PAD) * sizeof(float)));
+    YL_HIP(hipMemsetAsync(net.d_input, 0, ACT_FRONT_PAD * sizeof(float), (hipStream_t)net.stream));
+    net.d_input += ACT_FRONT_PAD;
     net.pinned_bytes = in_elems * sizeof(float);
     YL_HIP(hipHostMalloc(&net.h_pinned, net.pinned_bytes, hipHostMallocDefault));
 
@@ -383,7 +387,9 @@ static int to_device(Network &net, int device)
             l.d_output_alias = true;
         } else {
             l.d_output_alias = false;
-            YL_HIP(hipMalloc((void **)&l.d_output, out_elems * sizeof(float)));
+            YL_HIP(hipMalloc((void **)&l.d_output, (out_elems + ACT_FRONT_PAD) * sizeof(float)));
+            YL_HIP(hipMemsetAsync(l.d_output, 0, ACT_FRONT_PAD * sizeof(float), (hipStream_t)net.stream));      // finite: it is multiplied by 0
+            l.d_output += ACT_FRONT_PAD;
         }
         if (l.type == YL_CONVOLUTIONAL) {
             int rc = upload_conv(net, l);
@@ -674,6 +680,8 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.tapmajor = l.tapmajor;
             a.wino32_u = l.d_wino32_u;
             a.tile_ctr = l.d_tile_ctr;
+            // the input tensor is library memory with the front pad (a caller's device pointer as the network input is not)
+            a.in_front_pad = conv_in != net.d_binbuf && !(i == 0 && conv_in != net.d_input);
             if (l.fused_yolo >= 0) {
                 const Layer &yo = net.layers[l.fused_yolo];
                 a.yolo_entries = yo.classes + 5;

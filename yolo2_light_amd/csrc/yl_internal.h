@@ -16,6 +16,8 @@ namespace yl {
 enum ConvMode { CONV_F32 = 0, CONV_INT8 = 1, CONV_XNOR = 2, CONV_BF16 = 3 };
 enum HostKind { HOST_NONE = 0, HOST_CALLER = 1, HOST_PINNED = 2 };
 
+constexpr int ACT_FRONT_PAD = 64;      // floats (256 B) of readable, zeroed memory in front of every library-owned activation tensor
+
 struct Layer {
     int type = YL_BLANK;
     int activation = YL_LINEAR;
