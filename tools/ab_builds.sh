@@ -21,7 +21,7 @@ if [ "$MODE" = build ]; then
 else
   for v in $VALS; do
     echo "== build $v variant=$VARIANT"
-    YOLO2HIP_LIB=$PWD/tools/ab/libyolo2hip_x$v.so timeout 300 python tools/sweep_conv.py --batch 64 --tiles 31 --only ${SHAPES:-6,9,12,15} --iters 5 --variant $VARIANT 2>&1 | grep -E "^\{" | python -c "
+    YOLO2HIP_LIB=$PWD/tools/ab/libyolo2hip_x$v.so timeout 300 python tools/sweep_conv.py --batch 64 --tiles 31 --only ${SHAPES:-6,9,12,15} --iters ${ITERS:-5} --variant $VARIANT 2>&1 | grep -E "^\{" | python -c "
 import sys, json
 for l in sys.stdin:
     r=json.loads(l); print(r['shape'], r['M'], r['C'], r['H'], r['kernel'], '%.3f ms %.1f TF' % (r['ms'], r['tflops']))

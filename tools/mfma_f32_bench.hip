@@ -281,6 +281,80 @@ static void run_spec(int n_cu, float *d_sink)
     }
 }
 
+// Sustained rate of the bare MFMA loop over ~1 s of back-to-back launches, with constant operands (every lane the same
+// small integers) and with pseudo-random operands in [-1, 1) per lane and register: the clock the chip sustains depends on
+// the switching activity of the matrix pipe, so the second number -- not 157.3 -- is the ceiling a convolution on real
+// activations can reach.
+template <bool RANDOM>
+__global__ __launch_bounds__(256, 2) void sustained_kernel(float *sink, int iters)
+{
+    const int tid = threadIdx.x;
+    f32x16 acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+    float2 fa[2][8], fb[2][8];
+    unsigned h = (blockIdx.x * 256u + tid) * 2654435761u + 12345u;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            float r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                h = h * 1664525u + 1013904223u;
+                r[k] = RANDOM ? (float)(int)(h >> 8) * (1.f / 8388608.f) - 1.f : (float)(p + k + s);
+            }
+            fa[s][p] = make_float2(r[0], r[1]);
+            fb[s][p] = make_float2(r[2], r[3]);
+        }
+    for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][p].x, fb[s][p].x, acc[p], 0, 0, 0);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][p].y, fb[s][p].y, acc[p], 0, 0, 0);
+        }
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t += acc[p][e];
+    if (t == 123.456f) sink[0] = t;
+}
+
+template <bool RANDOM>
+static void run_sustained(int n_cu, float *d_sink)
+{
+    const int iters = 100000, launches = 14;
+    const int blocks = n_cu * 2;
+    hipEvent_t ev[launches + 1];
+    for (auto &e : ev) CHECK(hipEventCreate(&e));
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(ev[0]));
+    for (int l = 0; l < launches; ++l) {
+        hipLaunchKernelGGL(sustained_kernel<RANDOM>, dim3(blocks), dim3(256), 0, 0, d_sink, iters);
+        CHECK(hipEventRecord(ev[l + 1]));
+    }
+    CHECK(hipEventSynchronize(ev[launches]));
+    const double flops = (double)blocks * 4 * iters * 16 * (2.0 * 32 * 32 * 2);
+    printf("sustained, %s operands: 2 workgroups per CU, %d launches of %d iterations back to back; TFLOP/s per launch:",
+           RANDOM ? "pseudo-random [-1,1)" : "constant small-integer", launches, iters);
+    double last4 = 0.;
+    for (int l = 0; l < launches; ++l) {
+        float ms = 0.f;
+        CHECK(hipEventElapsedTime(&ms, ev[l], ev[l + 1]));
+        const double tf = flops / (ms * 1e-3) / 1e12;
+        printf(" %.1f", tf);
+        if (l >= launches - 4) last4 += tf / 4.;
+    }
+    printf("\n  -> last four: %.1f TFLOP/s = %.3f of 157.3 (%.2f GHz equivalent of the 2.4 GHz peak clock)\n", last4, last4 / 157.3, last4 / 157.3 * 2.4);
+    for (auto &e : ev) CHECK(hipEventDestroy(e));
+}
+
 static const float4 *g_src = nullptr;
 static size_t g_mask = 0;
 
@@ -321,6 +395,13 @@ int main()
         CHECK(hipMalloc(&g, n * sizeof(float4)));
         CHECK(hipMemset(g, 0, n * sizeof(float4)));
         g_src = g; g_mask = n - 1;
+    }
+    if (getenv("MFMA_SUSTAINED_ONLY") == nullptr || atoi(getenv("MFMA_SUSTAINED_ONLY")) >= 0) {
+        run_sustained<false>(n_cu, d_sink);
+        run_sustained<true>(n_cu, d_sink);
+        run_sustained<false>(n_cu, d_sink);
+        run_sustained<true>(n_cu, d_sink);
+        if (getenv("MFMA_SUSTAINED_ONLY") && atoi(getenv("MFMA_SUSTAINED_ONLY")) > 0) return 0;
     }
     run<0>(n_cu, d_sink, "16 MFMAs per iteration, nothing else");
     run<1>(n_cu, d_sink, "+ 16 ds_read_b64 of the next operands");

@@ -34,6 +34,7 @@ def main():
                     help="forced tile ids: 11..22 = direct kernel tiles, 0 = heuristic, 31 = Winograd (3x3/1/1 only)")
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--only", default="", help="comma list of shape indices")
+    ap.add_argument("--external-input", action="store_true", help="time the layer on a caller-owned device tensor (no front pad)")
     ap.add_argument("--variant", type=int, default=-1, help="yl_network_set_variant bits, applied before to_device")
     ap.add_argument("--input", default="rand", choices=["rand", "zeros", "relu"],
                     help="input data: U(-0.3, 0.7), all zeros (DVFS probe: same instructions, less switching), or a leaky-like mix")
@@ -67,13 +68,17 @@ def main():
             x.zero_()
         elif args.input == "relu":
             x = torch.where(x > 0, x, 0.1 * x)
+        # run from the library's own input tensor (front-padded like every activation tensor inside a network, which is
+        # what selects the Winograd kernel's folded-mask transform and its 64 x 32 tiling), not from torch's buffer
+        net.predict(x.cpu().numpy())
+        xin = net.input_dev if not args.external_input else x.data_ptr()
         flops = 2.0 * M * K * d.out_h * d.out_w * B
         best = None
         for t in tiles:
             net.set_conv_tile(t)
             try:
-                net.profile(x.data_ptr(), 1)          # warm-up
-                ms, _ = net.profile(x.data_ptr(), args.iters)
+                net.profile(xin, 1)          # warm-up
+                ms, _ = net.profile(xin, args.iters)
             except Exception as e:                    # a tile that does not apply to this shape
                 print("# shape %d tile %d: %s" % (si, t, e), flush=True)
                 continue

@@ -322,15 +322,28 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
     __syncthreads();
 
     // one k-block; DO_STORE: registers (panel kb+1) -> LDS[buf^1]; DO_LOAD: panel kb+2 -> registers
-#define YL_ITER(KB, DO_STORE, DO_LOAD)                                                             \
+    // LDS addressing.  Left alone, hipcc keeps one register per fragment and adds the (runtime) stage offset to each of them
+    // in every iteration: ~0.9 v_add_u32 per MFMA, and on gfx950 a VALU instruction costs the f32 matrix pipe ~4.9 cycles
+    // (tools/mfma_f32_bench.hip) -- 6 % of a 64-cycle v_mfma_f32_32x32x2_f32 -- plus 16 VGPRs.  Two remedies:
+    //  * the steady-state loop is unrolled by two, BUF is then a compile-time constant and every address is a loop-invariant
+    //    register + an immediate offset (3-7 VALU per 64 MFMAs).  Costs up to 35 VGPRs of overlap between the two bodies: the
+    //    8-wave tiles (two workgroups per CU = 128 VGPRs) and the 32-deep panels would lose a wave per SIMD, so only the 4-wave
+    //    tiles with 16-deep panels are unrolled;
+    //  * the others, and the tail iterations of all, keep the runtime stage but pass the two fragment offsets through an empty
+    //    asm: opaque to the compiler, they stay ONE register each and the reads become base + immediate (15 VALU per 32 MFMAs).
+#define YL_ITER(KB, DO_STORE, DO_LOAD) YL_ITER_(KB, (KB) & 1, true, DO_STORE, DO_LOAD)
+#define YL_ITER_(KB, BUF, OPAQUE, DO_STORE, DO_LOAD)                                               \
     {                                                                                              \
-        const int buf = (KB) & 1;                                                                  \
+        const int buf = (BUF);                                                                     \
         if (DO_LOAD) { YL_PANEL_SETUP() }                                                          \
-        const float *Ab = As + buf * BK * BM + wm0 + l31;                                          \
-        const float *Bb = Bs + buf * BK * BN + wn0 + l31;                                          \
+        int a_off = buf * BK * BM + wm0 + l31 + half * BM;                                         \
+        int b_off = buf * BK * BN + wn0 + l31 + half * BN;                                         \
+        if (OPAQUE) asm volatile("" : "+v"(a_off), "+v"(b_off));                                   \
+        const float *Ab = As + a_off;                                                              \
+        const float *Bb = Bs + b_off;                                                              \
         float av[2][TM], bv[2][TN];                                                                \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) av[0][i] = Ab[half * BM + i * 32];          \
-        _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[0][j] = Bb[half * BN + j * 32];          \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) av[0][i] = Ab[i * 32];                      \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) bv[0][j] = Bb[j * 32];                      \
         _Pragma("unroll") for (int ks = 0; ks < KSTEPS; ++ks) {                                    \
             const int cur = ks & 1, nxt = cur ^ 1;                                                 \
             _Pragma("unroll") for (int e = ks * APT / KSTEPS; e < (ks + 1) * APT / KSTEPS; ++e) {  \
@@ -350,9 +363,9 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
             }                                                                                      \
             if (ks + 1 < KSTEPS) {                                                                 \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i)                                     \
-                    av[nxt][i] = Ab[(2 * (ks + 1) + half) * BM + i * 32];                          \
+                    av[nxt][i] = Ab[2 * (ks + 1) * BM + i * 32];                                   \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                     \
-                    bv[nxt][j] = Bb[(2 * (ks + 1) + half) * BN + j * 32];                          \
+                    bv[nxt][j] = Bb[2 * (ks + 1) * BN + j * 32];                                   \
             }                                                                                      \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                         \
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                     \
@@ -365,10 +378,17 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_f32_mfma_pipe_kernel(ConvF32
     }
 
     int kb = 0;
+    if constexpr (NWAVES == 4 && BK == 16) {
+        for (; kb + 3 < nkb; kb += 2) {
+            YL_ITER_(kb, 0, false, true, true)
+            YL_ITER_(kb + 1, 1, false, true, true)
+        }
+    }
     for (; kb + 2 < nkb; ++kb) YL_ITER(kb, true, true)
     if (kb + 1 < nkb) { YL_ITER(kb, true, false) ++kb; }
     if (kb < nkb) YL_ITER(kb, false, false)
 #undef YL_ITER
+#undef YL_ITER_
 #undef YL_PANEL_SETUP
 #undef YL_PANEL_ADVANCE
 #undef YL_LOAD_A
@@ -563,13 +583,18 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
         // (TM=1,TN=4) for wider 3x3 layers; 64x128 / 32x256 for the narrow-M early layers;
         // layers too small to give every CU two workgroups fall back to 64x64 tiles.
         if (a.M <= 32) cfg = 3;
-        else if (a.M <= 64) cfg = (a.size == 3) ? 4 : 2;      // 3x3 stride 2, M = 64: 64x64 2.34 ms vs 64x128 2.54
+        // 3x3 stride 2, M = 64 (yolov3 layer 1): 64x128 2.04 ms vs 64x64 2.16 since the unrolled K loop (round 4,
+        // profiles/r4_sweep_direct_tiles_steady_state.txt; before it 2.54 vs 2.34)
+        else if (a.M <= 64) cfg = 2;
         // round 4 sweep (profiles/r4_sweep_stride2_tiles.txt): 3x3 layers from 128 filters up take the 8-wave 128x256 tile
         // as well (M = 128, 256 at stride 2: 1.92 -> 1.82 ms, 1.81 -> 1.74 ms)
         // round 4, in-network A/B (profiles/r4_ab_1x1_tile.txt): 1x1 layers from 128 filters on the 8-wave 128x256 tile,
         // 22 launches 5.17 -> 4.82 ms, +0.7 % on the step
         else if (a.size == 1 && a.M >= 128 && nblocks(128, 256) >= 384) cfg = 10;
         else if (a.size == 1 || a.M < 128) cfg = (nblocks(128, 128) >= 512) ? 12 : 4;
+        // same sweep: 3x3 stride 2 from 256 filters up on the 4-wave 128x128 tile (1.64 / 1.68 / 1.68 ms vs 1.73 / 1.70 / 1.72
+        // on the 8-wave 128x256 one, which keeps M = 128: 1.73 vs 1.75)
+        else if (a.M >= 256 && nblocks(128, 128) >= 512) cfg = 12;
         else cfg = (nblocks(128, 256) >= 384) ? 10 : ((nblocks(128, 128) >= 512) ? 12 : 4);
         if (cfg <= 3 && nblocks(cfg == 2 ? 64 : 32, cfg == 3 ? 256 : 128) < 512) cfg = 4;
     }

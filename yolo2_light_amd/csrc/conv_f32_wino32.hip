@@ -45,7 +45,7 @@
 // X_DBG (build-time timing experiments, -DX_DBG=<bits>; results are garbage): 1 no patch loads in the
 // K loop, 2 no weight loads, 4 no transform / LDS stores, 8 no MFMAs, 16 transform without the patch
 // stores, 32 patch stores without the transform, 64 no barriers inside the K loop, 128 no epilogue, 256 one
-// workgroup per CU (48 KB of dead LDS more).  tools/ab_builds.sh runs such builds side by side
+// workgroup per CU (48 KB of dead LDS more), 512 no weight-panel LDS stores in the K loop.  tools/ab_builds.sh runs such builds side by side
 // on one GPU box (DESIGN.md, K1w "what still bounds it").
 #ifndef X_DBG
 #define X_DBG 0
@@ -391,6 +391,12 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     bool left_s, inv2_s, inv3_s;
     float m0f = 1.f, m2f = 1.f, m3f = 1.f;
     const float *u_tile;
+    // the packed U through a buffer descriptor: lane offset tid * 16, tile / panel offsets in the scalar soffset -> no VALU
+    // address arithmetic in the K loop (64-bit global addresses cost 5 VALU per pair of panels)
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.u, 0, (int)((unsigned)p.tiles_m * (unsigned)p.nkb * (unsigned)(XPA * 4)), 0x00020000);
+    const int u_lane = tid * 16;
+    int u_off = 0;
 #define X_SETUP_TILE(IDX)                                                                          \
     {                                                                                              \
         const int logical = x_start + (IDX);                                                       \
@@ -425,6 +431,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
             pvr[rr] = ok ? (int)(base + (unsigned)(rr * p.W) * 4u) : -1;                           \
         }                                                                                          \
         u_tile = p.u + (size_t)tile_m * p.nkb * XPA;                                               \
+        u_off = tile_m * p.nkb * (XPA * 4);                                                        \
     }
     X_SETUP_TILE(cur)
 
@@ -440,12 +447,12 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
             XR[rr * 4 + 2] = __uint_as_float(q0[2]); XR[rr * 4 + 3] = __uint_as_float(q0[3]);      \
         }                                                                                          \
     }
-#define X_LOAD_U(KB, UR)                                                                               \
+#define X_LOAD_U(KB, UR)                                                                           \
     {                                                                                              \
-        const float4 *src = reinterpret_cast<const float4 *>(u_tile + (size_t)(KB) * XPA);         \
         _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                            \
-            const float4 t4 = src[tid + e * 256];                                                  \
-            UR[e][0] = t4.x; UR[e][1] = t4.y; UR[e][2] = t4.z; UR[e][3] = t4.w;                    \
+            const u32x4v t4 = __builtin_amdgcn_raw_buffer_load_b128(rs_u, u_lane, u_off + (KB) * (XPA * 4) + e * 4096, 0); \
+            UR[e][0] = __uint_as_float(t4[0]); UR[e][1] = __uint_as_float(t4[1]);                  \
+            UR[e][2] = __uint_as_float(t4[2]); UR[e][3] = __uint_as_float(t4[3]);                  \
         }                                                                                          \
     }
 #define X_DMA_U(KB, BUF)                                                                           \
@@ -549,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
 #define X_ITER_(KB, SET, DO_STORE, DO_LOAD, FIRST)                                                 \
     {                                                                                              \
         const int buf = (KB) & 1;                                                                  \
-        if (DO_STORE && !UDMA && !(X_DBG & 4)) X_STORE_U(buf ^ 1, ur)                              \
+        if (DO_STORE && !UDMA && !(X_DBG & (4 | 512))) X_STORE_U(buf ^ 1, ur)                              \
         if (DO_STORE && !(X_DBG & 4)) X_STORE_X(buf ^ 1, xr)                                       \
         _Pragma("unroll") for (int pp = 0; pp < 8; ++pp)                                           \
             if (!(X_DBG & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][pp].x, fb[SET][pp][0], (FIRST) ? zero16 : acc[pp], 0, 0, 0); \
