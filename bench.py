@@ -88,6 +88,7 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--layers", action="store_true", help="also print a per-layer table to stderr")
     ap.add_argument("--tile", type=int, default=0, help="force K1 tile config (tuning)")
+    ap.add_argument("--no-winograd", action="store_true", help="A/B: 3x3 stride-1 layers on the direct kernels (yl_network_set_winograd 0)")
     ap.add_argument("--variant", type=int, default=-1, help="FP32 schedule variant bits (yl_network_set_variant; A/B runs)")
     ap.add_argument("--i8-tile", type=int, default=0, help="force K2 (INT8) tile config (tuning)")
     ap.add_argument("--no-fuse", action="store_true", help="keep [shortcut] layers as separate kernels")
@@ -241,7 +242,8 @@ class Leg:
         self.stream = stream
         # quantized: 0 FP32, 1 -quantized INT8, 2 the opt-in BF16 variant of the FP32 path
         self.net = Network.load(cfg, wts, b_local, 1 if quantized == 1 else 0, device=dev.index, fuse=not args.no_fuse,
-                                bf16=(quantized == 2), variant=(args.variant if args.variant >= 0 else None))
+                                bf16=(quantized == 2), variant=(args.variant if args.variant >= 0 else None),
+                                winograd=not args.no_winograd)
         self.net.set_stream(stream.cuda_stream)
         if args.tile:
             self.net.set_conv_tile(args.tile)

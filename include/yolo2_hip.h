@@ -304,15 +304,16 @@ int yl_network_pull_heads(yl_network *net);
  * yl_network_set_nms_mode: yl_network_detect_batch's suppression stage, 1 = one workgroup per
  *   (image, class) (default), 0 = one workgroup per image; same rows either way. */
 int yl_network_set_conv_tile(yl_network *net, int cfg);
-/* schedule variants of the FP32 kernels kept switchable for same-box A/B measurements (results are identical):
- * bit 0 Winograd U panels by LDS-DMA, bit 1 Winograd epilogue prefetches the fused [shortcut] operand,
- * bit 2 float4 B-panel rows in the 1x1 direct kernel, bit 3 LDS-free first-layer kernel, bit 4 Winograd from 32
- * input channels up, bit 5 (takes effect at the next yl_network_to_device: it selects the weight packing) the Winograd
- * kernel with all 16 planes of a block in one wave and the output transform in registers, bit 6 (with bit 5) its
- * warp-specialised form (4 matrix waves that only issue MFMAs + 4 staging waves), bit 7 (at yl_network_to_device,
- * without bit 5) the 64-filter x 64-tile 8-wave Winograd kernel for layers with >= 64 filters, bit 8 sign-only XNOR
- * layers evaluate the float epilogue instead of comparing the match count with its threshold, bit 9 XNOR layers
- * with >= 64 filters always run 64-filter workgroups (default: 32 on shallow grids); -1 = built-in default */
+/* kernel-selection / schedule switches kept for same-box A/B measurements.  Bits 0-3 and 6-9 change the schedule only
+ * (bit-identical results); bits 4, 5 and 10 change WHICH kernel a layer takes (results within the FP32 contract):
+ * bit 0 Winograd U panels by LDS-DMA, bit 1 Winograd epilogue prefetches the fused [shortcut] operand, bit 2 float4 B-panel
+ * rows in the 1x1 direct kernel, bit 3 LDS-free first-layer kernel, bit 4 Winograd from 32 input channels up, bit 5 from 16,
+ * bit 6 persistent Winograd workgroups (per-XCD tile counters), bit 7 the Winograd input transform in its register-shift
+ * form (default: column masks folded into the transform), bit 8 sign-only XNOR layers evaluate the float epilogue instead of
+ * comparing the match count with its threshold, bit 9 XNOR layers with >= 64 filters always run 64-filter workgroups
+ * (default: 32 on shallow grids), bit 10 the direct FP32 layers with C % 16 == 0 and more than 32 filters on the BF16 matrix
+ * pipe with every operand as the exact sum of three bf16 pieces (conv_f32_x3.hip; FP32 tensors, FP32-class accuracy);
+ * -1 = built-in default (bits 1-5 and 10) */
 int yl_network_set_variant(yl_network *net, int bits);
 /* Opt-in BF16 variant of the FP32 path (north_star (a) "FP32/BF16"; BEFORE yl_network_to_device): every FP32
  * convolution whose input has whole 8-channel groups runs on v_mfma_f32_32x32x16_bf16 with both operands rounded

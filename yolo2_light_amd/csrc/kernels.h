@@ -12,7 +12,9 @@ namespace yl {
 // removed from the library in round 4; bit 5 has a new meaning since, bits 6-7 are ignored.)
 // round 4: bit 5 (Winograd from 16 input channels: yolov3-tiny's 16 -> 32 layer at 208 x 208, 0.175 ms on the direct 32x256
 // tile + 0.063 ms of [maxpool] -> 0.119 ms with the pooling folded into the Winograd epilogue; config 2 +7.8 %)
-constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8 | 16 | 32;
+// bit 10 (round 4): the direct FP32 layers on the BF16 matrix pipe with three-piece operands (K1x, conv_f32_x3.hip): +1.8 ... +7 %
+// on the step depending on the box (the kernel drives the chip into its power cap), same accuracy against float64
+constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8 | 16 | 32 | 1024;
 
 // ---- K1: FP32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 ----
 struct ConvF32Args {
@@ -38,6 +40,7 @@ struct ConvF32Args {
     int act;              // YL_LINEAR / YL_LEAKY
     int tapmajor;         // K order of `wt`: 0 = (c,ky,kx) like im2col_cpu, 1 = (ky,kx,c) (needs C % 16 == 0)
     const float *wino32_u; // Winograd-packed weights (wino32_pack_weights) or nullptr: 3x3/1/1 layers only
+    const void *x3_w = nullptr; // the weights as three bf16 pieces (x3_pack_weights, conv_f32_x3.hip) or nullptr
     bool in_front_pad = false;     // `in` has >= 4 readable bytes in front of it holding a FINITE value (library-owned tensors:
                            // yl_internal.h ACT_FRONT_PAD); the Winograd kernel then fetches left-edge patches one column early
                            // and folds the column masks into the transform instead of shifting registers
@@ -69,6 +72,11 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
 // 32 filters x 64 tiles per workgroup, two workgroups per CU
 bool wino_applicable(int C, int M, int size, int stride, int pad);
 bool wino32_fits(int B, int M, int H, int W);     // output tensor below 4 GB (32-bit byte offsets in the epilogue)
+// K1x (conv_f32_x3.hip): the same FP32 convolution on the BF16 matrix pipe, every operand the exact sum of three bf16 pieces
+bool x3_applicable(int C, int M, int size, int stride, int pad);
+size_t x3_packed_bytes(int C, int M, int size);
+void x3_pack_weights(const float *w, int C, int M, int size, void *dst);
+int launch_conv_f32_x3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len);
 size_t wino32_packed_floats(int C, int M);
 void wino32_pack_weights(const float *w, int C, int M, float *dst);
 // K1s (conv_f32_smallk.hip): LDS-free kernel for first layers (C*size^2 <= 32, filters <= 32)

@@ -93,6 +93,8 @@ static void free_device(Network &net)
         if (l.d_weights_t) (void)hipFree(l.d_weights_t);
         if (l.d_wino32_u) (void)hipFree(l.d_wino32_u);
         l.d_wino32_u = nullptr;
+        if (l.d_weights_x3) (void)hipFree(l.d_weights_x3);
+        l.d_weights_x3 = nullptr;
         if (l.d_tile_ctr) (void)hipFree(l.d_tile_ctr);
         l.d_tile_ctr = nullptr;
         if (l.d_biases) (void)hipFree(l.d_biases);
@@ -233,6 +235,14 @@ static int upload_conv(Network &net, Layer &l)
                 wino32_pack_weights(l.weights.data(), l.c, M, u32.data());
                 YL_STAGE(stage_h2d(net.device, l.d_wino32_u, u32.data(), u32.size() * sizeof(float)));
             }
+        }
+        // the split-operand form of the same weights for K1x (host-side split: three bf16 pieces per weight, exact)
+        if (!xnor_fallback && x3_applicable(l.c, M, l.size, l.stride, l.pad)) {
+            const size_t xb = x3_packed_bytes(l.c, M, l.size);
+            std::vector<unsigned char> w3(xb);
+            x3_pack_weights(l.weights.data(), l.c, M, l.size, w3.data());
+            YL_HIP(hipMalloc(&l.d_weights_x3, xb));
+            YL_STAGE(stage_h2d(net.device, l.d_weights_x3, w3.data(), xb));
         }
     } else if (l.conv_mode == CONV_INT8) {
         if (!l.quant_ready) { set_error("INT8 layer without yl_network_quantize()"); return YL_ERR_STATE; }
@@ -679,6 +689,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = kernel_act;
             a.tapmajor = l.tapmajor;
             a.wino32_u = l.d_wino32_u;
+            a.x3_w = l.d_weights_x3;
             a.tile_ctr = l.d_tile_ctr;
             // the input tensor is library memory with the front pad (a caller's device pointer as the network input is not)
             a.in_front_pad = conv_in != net.d_binbuf && !(i == 0 && conv_in != net.d_input);
@@ -1512,7 +1523,7 @@ int yl_network_get_boxes(yl_network *net, int image, int w, int h, float thresh,
 int yl_network_set_conv_tile(yl_network *net, int cfg)
 {
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }
-    if (!(cfg == 0 || (cfg >= 11 && cfg <= 22) || cfg == 31 || cfg == 41)) { set_error("unknown tile id"); return YL_ERR_ARG; }
+    if (!(cfg == 0 || (cfg >= 11 && cfg <= 22) || cfg == 31 || cfg == 41 || (cfg >= 51 && cfg <= 53))) { set_error("unknown tile id"); return YL_ERR_ARG; }
     net->net.conv_opts.force_tile = cfg;
     return YL_OK;
 }
@@ -1520,7 +1531,7 @@ int yl_network_set_conv_tile(yl_network *net, int cfg)
 int yl_network_set_variant(yl_network *net, int bits)
 {
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }
-    if (bits < -1 || bits > 1023) { set_error("unknown variant bits"); return YL_ERR_ARG; }
+    if (bits < -1 || bits > 2047) { set_error("unknown variant bits"); return YL_ERR_ARG; }
     net->net.conv_opts.variant = bits < 0 ? YL_VARIANT_DEFAULT : bits;
     return YL_OK;
 }

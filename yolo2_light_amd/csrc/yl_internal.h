@@ -61,6 +61,7 @@ struct Layer {
     int   Kpad = 0, Mpad = 0;
     int   tapmajor = 0;                  // K order of d_weights_t (see conv_f32_mfma.hip)
     float *d_wino32_u = nullptr;         // FP32 3x3/1/1: Winograd-packed U (conv_f32_wino32.hip), else nullptr
+    void *d_weights_x3 = nullptr;        // FP32, C % 16 == 0: the weights as three bf16 pieces (conv_f32_x3.hip), else nullptr
     unsigned *d_tile_ctr = nullptr;      //       8 work counters (one per XCD) of the persistent Winograd form, zero between launches
     size_t packed_bytes[4] = {0, 0, 0, 0};   // bytes of d_weights_t, d_wino32_u, d_weights_i8, d_weights_bits (yl_debug_layer_packed)
     int8_t *d_weights_i8 = nullptr;      // INT8: [K16pad][Mpad][16] int8 units; BF16: [K8pad][Mpad][8] bf16 units
