@@ -162,6 +162,20 @@ def model_files(name: str, width: int, height: int, seed: int = 1):
     return _MODEL_CACHE[key]
 
 
+def _variant_default() -> int:
+    """YL_VARIANT_DEFAULT as csrc/kernels.h defines it (what yl_network_set_variant(net, -1) selects)"""
+    import re
+    text = open(os.path.join(ROOT, "yolo2_light_amd", "csrc", "kernels.h")).read()
+    m = re.search(r"constexpr int YL_VARIANT_DEFAULT = ([0-9 |]+);", text)
+    v = 0
+    for tok in m.group(1).split("|"):
+        v |= int(tok)
+    return v
+
+
+VARIANT_DEFAULT = _variant_default()
+
+
 def seeded_input(batch: int, c: int, h: int, w: int, seed: int = 2222222) -> np.ndarray:
     """U[0,1) images, seed echoing srand(2222222) (src/main.c:165)."""
     rng = np.random.default_rng(seed)

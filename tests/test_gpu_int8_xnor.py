@@ -447,7 +447,7 @@ softmax=1
 """
 
 
-@pytest.mark.parametrize("variant", [30, 30 | 512, 30 | 256], ids=["ft-by-grid", "ft64", "float-epilogue"])
+@pytest.mark.parametrize("variant", [0, 512, 256], ids=["ft-by-grid", "ft64", "float-epilogue"])
 def test_xnor_sign_domain_ragged_filter_counts(variant):
     """Sign words between XNOR layers whose filter counts are NOT multiples of 64 (70, 130, 33, 100): the bits above
     the last filter of the last word must be zeros whichever workgroup shape wrote the word (32-filter tiles write
@@ -463,7 +463,7 @@ def test_xnor_sign_domain_ragged_filter_counts(variant):
     x = common.seeded_input(batch, 3, height, width)
     plain = Network.load(cfg, wts, batch, 0, device=0)
     fused = Network.load(cfg, wts, batch, 0, device=0, fuse=True)
-    fused.set_variant(variant)
+    fused.set_variant(common.VARIANT_DEFAULT | variant)      # the XNOR switches on top of the default kernel selection
     # poison the sign-word ring first: a run of the same network on another image leaves stale words in every slot
     fused.predict(common.seeded_input(batch, 3, height, width, seed=5))
     a = plain.predict(x).copy()
@@ -501,7 +501,7 @@ def test_xnor_sign_thresholds_match_the_float_epilogue():
     x = common.seeded_input(2, 3, 96, 96)
     a = net.predict(x).copy()
     for bits in (256, 512, 256 | 512):   # float epilogue / 64-filter workgroups / both, on top of YL_VARIANT_DEFAULT
-        net.set_variant(30 | bits)
+        net.set_variant(common.VARIANT_DEFAULT | bits)
         b = net.predict(x).copy()
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), bits
     net.close()
