@@ -335,7 +335,8 @@ int yl_network_set_nms_mode(yl_network *net, int mode);
 int yl_network_set_device_pack(yl_network *net, int on);
 /* Test hook: the packed weight image of conv layer i as it sits on the device: which = 0 k-major FP32 panels,
  * 1 Winograd U, 2 int8 / bf16 units, 3 XNOR sign words; XNOR layers also 4 = int32 count thresholds of the sign-only
- * epilogue [Mpad] + the number of filters without one, 5 = mean[M], 6 = bias[M].  Returns its size in bytes (0 = none);
+ * epilogue [Mpad] + the number of filters without one, 5 = mean[M], 6 = bias[M]; 7 = the weights as three bf16 pieces
+ * (conv_f32_x3.hip).  Returns its size in bytes (0 = none);
  * copies it when dst_host != NULL (dst_bytes >= size). */
 long long yl_debug_layer_packed(yl_network *net, int i, int which, void *dst_host, long long dst_bytes);
 /* Test hook (host only, no GPU needed): the Winograd weight transform U = G g G^T of a 3x3 layer

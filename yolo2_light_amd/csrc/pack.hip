@@ -113,6 +113,31 @@ __global__ __launch_bounds__(256) void pack_bf16_units_kernel(const float *__res
     }
 }
 
+// K1x weights (conv_f32_x3.hip): every weight as three bf16 pieces, w3[panel][piece 3][k-octet 2][Mpad][8] (pre-zeroed), panel =
+// (c / 16) * taps + tap; the same integer round-to-nearest-even split as x3_pack_weights on the host (the subtractions are exact)
+__global__ __launch_bounds__(256) void pack_x3_kernel(const float *__restrict__ w, uint16_t *__restrict__ dst, int M, int C, int taps, int Mpad)
+{
+    const size_t total = (size_t)M * C * taps;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(idx % taps);
+        const int c = (int)((idx / taps) % C);
+        const int m = (int)(idx / ((size_t)taps * C));
+        float r = w[idx];
+        uint16_t h[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+            unsigned u = __float_as_uint(r);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            h[pc] = (uint16_t)(u >> 16);
+            r = __fsub_rn(r, __uint_as_float((unsigned)h[pc] << 16));
+        }
+        const size_t panel = (size_t)(c / 16) * taps + t;
+        const int oct = (c % 16) / 8, e = c % 8;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) dst[(((panel * 3 + pc) * 2 + oct) * Mpad + m) * 8 + e] = h[pc];
+    }
+}
+
 // XNOR sign words [Mpad/2][Cw][2][9] (pre-set to all ones: channel-pad bits and pad filters never match);
 // bit = (w > 0) (src/additionally.c:123,1544); one lane per (m, tap, channel word)
 __global__ __launch_bounds__(256) void pack_xnor_words_kernel(const float *__restrict__ w, uint64_t *__restrict__ dst, int M, int C, int Cw)
@@ -161,6 +186,13 @@ int dev_pack_bf16_units(const float *d_w, uint16_t *d_dst, int M, int C, int tap
 {
     hipLaunchKernelGGL(pack_bf16_units_kernel, dim3(pack_blocks((size_t)M * C * taps)), dim3(256), 0, (hipStream_t)stream,
                        d_w, d_dst, M, C, taps, G, Mpad);
+    return (int)hipGetLastError();
+}
+
+int dev_pack_x3(const float *d_w, void *d_dst, int M, int C, int taps, int Mpad, void *stream)
+{
+    hipLaunchKernelGGL(pack_x3_kernel, dim3(pack_blocks((size_t)M * C * taps)), dim3(256), 0, (hipStream_t)stream,
+                       d_w, (uint16_t *)d_dst, M, C, taps, Mpad);
     return (int)hipGetLastError();
 }
 

@@ -236,13 +236,20 @@ static int upload_conv(Network &net, Layer &l)
                 YL_STAGE(stage_h2d(net.device, l.d_wino32_u, u32.data(), u32.size() * sizeof(float)));
             }
         }
-        // the split-operand form of the same weights for K1x (host-side split: three bf16 pieces per weight, exact)
+        // the split-operand form of the same weights for K1x (three bf16 pieces per weight, exact); on the device from the raw
+        // weights the packers above already uploaded, or on the host -- bit-identical (test_gpu_prep.py)
         if (!xnor_fallback && x3_applicable(l.c, M, l.size, l.stride, l.pad)) {
             const size_t xb = x3_packed_bytes(l.c, M, l.size);
-            std::vector<unsigned char> w3(xb);
-            x3_pack_weights(l.weights.data(), l.c, M, l.size, w3.data());
             YL_HIP(hipMalloc(&l.d_weights_x3, xb));
-            YL_STAGE(stage_h2d(net.device, l.d_weights_x3, w3.data(), xb));
+            l.packed_bytes[4] = xb;
+            if (net.device_pack) {
+                YL_HIP(hipMemsetAsync(l.d_weights_x3, 0, xb, (hipStream_t)s));
+                YL_LAUNCH(dev_pack_x3(reinterpret_cast<const float *>(net.d_pack_src), l.d_weights_x3, M, l.c, taps, (int)(xb / ((size_t)(l.c / 16) * taps * 96)), s), "pack_x3");
+            } else {
+                std::vector<unsigned char> w3(xb);
+                x3_pack_weights(l.weights.data(), l.c, M, l.size, w3.data());
+                YL_STAGE(stage_h2d(net.device, l.d_weights_x3, w3.data(), xb));
+            }
         }
     } else if (l.conv_mode == CONV_INT8) {
         if (!l.quant_ready) { set_error("INT8 layer without yl_network_quantize()"); return YL_ERR_STATE; }
@@ -1572,13 +1579,16 @@ int yl_network_set_device_pack(yl_network *net, int on)
 long long yl_debug_layer_packed(yl_network *net, int i, int which, void *dst_host, long long dst_bytes)
 {
     YL_LAYER_OR(YL_ERR_ARG)
-    if (!net->net.on_device || which < 0 || which > 6) { set_error("bad argument / not on device"); return YL_ERR_STATE; }
+    if (!net->net.on_device || which < 0 || which > 7) { set_error("bad argument / not on device"); return YL_ERR_STATE; }
     const void *src = nullptr;
     long long need = 0;
     if (which <= 3) {
         src = which == 0 ? (const void *)l.d_weights_t : which == 1 ? (const void *)l.d_wino32_u
             : which == 2 ? (const void *)l.d_weights_i8 : (const void *)l.d_weights_bits;
         need = src ? (long long)l.packed_bytes[which] : 0;
+    } else if (which == 7) {                                  // K1x: the weights as three bf16 pieces
+        src = l.d_weights_x3;
+        need = src ? (long long)l.packed_bytes[4] : 0;
     } else if (l.type == YL_CONVOLUTIONAL && l.d_thr) {       // XNOR layers: thresholds (+ the not-a-step count), mean, bias
         src = which == 4 ? (const void *)l.d_thr : which == 5 ? (const void *)l.d_mean : (const void *)l.d_biases;
         need = which == 4 ? (long long)sizeof(int) * (l.Mpad + 1) : (long long)sizeof(float) * l.n;

@@ -271,7 +271,7 @@ class Network:
     def layer_packed(self, i: int, which: int) -> Optional[np.ndarray]:
         """the packed weight image of conv layer i on the device as bytes (which: 0 k-major FP32, 1 Winograd U,
         2 int8 / bf16 units, 3 XNOR sign words, 4 XNOR count thresholds int32[Mpad + 1], 5 / 6 XNOR mean / bias
-        float32[M]); None if the layer has none"""
+        float32[M], 7 the three-piece bf16 weights of conv_f32_x3.hip); None if the layer has none"""
         n = lib.yl_debug_layer_packed(self._h, i, which, None, 0)
         if n < 0:
             raise YoloHipError("yl_debug_layer_packed failed: " + _lib.last_error())
