@@ -344,6 +344,10 @@ long long yl_debug_layer_packed(yl_network *net, int i, int which, void *dst_hos
  * [m/32][c/4][xi 16][half 2][m 32][kk 2] with channel = panel*4 + 2*kk + half.  (16 / 64 selected round 3's
  * alternative kernels, removed in round 4: YL_ERR_ARG.)  dst == NULL returns the number of floats needed. */
 long long yl_debug_wino_pack(const float *weights, int c, int m, int tiling, float *dst, long long dst_floats);
+/* Test hook (host only): the weights of a convolution (weights[m][c][size][size], c % 16 == 0) as conv_f32_x3.hip reads them:
+ * every weight as three bf16 numbers whose sum is the weight exactly, [panel][piece 3][k-octet 2][Mpad][8] with panel =
+ * (channel / 16) * size^2 + tap, Mpad = m rounded up to 128, zero padded.  dst == NULL returns the number of bytes needed. */
+long long yl_debug_x3_pack(const float *weights, int c, int m, int size, void *dst, long long dst_bytes);
 
 /* On-device detection compaction (new): threshold test
  * `objectness > thresh` (src/additionally.c:4341) and box decode

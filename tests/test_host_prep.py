@@ -136,6 +136,46 @@ def test_winograd_weight_packing(C, M, tiling):
                 assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (tm, ml, c)
 
 
+@pytest.mark.parametrize("C,M,size", [(16, 33, 3), (32, 128, 1), (48, 70, 3), (64, 255, 1), (32, 20, 5)])
+def test_x3_weight_split_is_exact(C, M, size):
+    """conv_f32_x3.hip's weights: every FP32 weight as three bf16 numbers.  Their sum is the weight EXACTLY (the kernel's
+    products are then FP32-exact up to the three dropped cross terms), each piece is the round-to-nearest-even bf16 of what
+    the pieces before it left, and the units sit where the kernel's lanes read them; filters beyond M are zero."""
+    import ctypes as Cc
+    from yolo2_light_amd._lib import lib
+    rng = np.random.default_rng(C * 1000 + M + size)
+    # nine octaves of magnitude, a few exact zeros and exact bf16 values
+    w = (rng.standard_normal((M, C, size, size)) * np.exp(rng.uniform(-4, 2, (M, C, size, size)))).astype(np.float32)
+    w[rng.random(w.shape) < 0.02] = 0.0
+    w[0, 0] = np.float32(1.5)
+    fp = Cc.POINTER(Cc.c_float)
+    assert lib.yl_debug_x3_pack(w.ctypes.data_as(fp), C + 1, M, size, None, 0) < 0            # C % 16 != 0: not this kernel's layer
+    need = lib.yl_debug_x3_pack(w.ctypes.data_as(fp), C, M, size, None, 0)
+    taps = size * size
+    mpad = (M + 127) // 128 * 128
+    assert need == (C // 16) * taps * 6 * mpad * 16
+    raw = np.full(need // 2, 0x7fc0, dtype=np.uint16)
+    assert lib.yl_debug_x3_pack(w.ctypes.data_as(fp), C, M, size, raw.ctypes.data_as(Cc.c_void_p), need) == need
+    units = raw.reshape(C // 16, taps, 3, 2, mpad, 8)               # [channel block][tap][piece][k-octet][filter][k]
+    pieces = (units.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    assert not np.any(units[:, :, :, :, M:, :])                      # pad filters are zero
+    # back to [m][c][tap]
+    got = pieces[:, :, :, :, :M, :].transpose(4, 0, 3, 5, 1, 2).reshape(M, C, taps, 3)
+    want = w.reshape(M, C, taps).astype(np.float64)
+    assert np.array_equal(got.sum(axis=3), want)                     # a1 + a2 + a3 == a, exactly
+
+    def bf16_rne(x32):
+        u = x32.astype(np.float32).view(np.uint32).astype(np.uint64)
+        return (((u + 0x7fff + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+
+    r = w.reshape(M, C, taps).astype(np.float32)
+    for pc in range(3):
+        h = bf16_rne(r)
+        assert np.array_equal(h.view(np.uint32), got[..., pc].astype(np.float32).view(np.uint32)), pc
+        r = (r - h).astype(np.float32)
+    assert np.all(np.abs(got[..., 1]) <= np.abs(got[..., 0]) * 2.0 ** -8 + 1e-45)      # each piece 8 bits below the one before
+
+
 @pytest.mark.skipif(not refbind.available(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("name,width,height", [("yolov3", 64, 64), ("yolov3-tiny", 96, 96), ("yolov3-spp", 64, 64),
                                                ("yolov2-voc", 96, 96), ("tiny-yolo-voc", 96, 96)])

@@ -1652,6 +1652,16 @@ long long yl_debug_wino_pack(const float *weights, int c, int m, int tiling, flo
     return (long long)need;
 }
 
+long long yl_debug_x3_pack(const float *weights, int c, int m, int size, void *dst, long long dst_bytes)
+{
+    if (!weights || m <= 0 || !x3_applicable(c, m, size, 1, 0)) { set_error("bad argument"); return YL_ERR_ARG; }
+    const size_t need = x3_packed_bytes(c, m, size);
+    if (!dst) return (long long)need;
+    if (dst_bytes < (long long)need) { set_error("dst too small"); return YL_ERR_ARG; }
+    x3_pack_weights(weights, c, m, size, dst);
+    return (long long)need;
+}
+
 // ------------------------------------------------------------------ INT8 calibration tool
 float yl_entropy_from_histogram(const uint32_t *counts, int max_bin, float bin_width)
 {
