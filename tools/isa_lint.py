@@ -3,10 +3,11 @@
 patterns that cost round 2 time before they were found in the ISA rather than in a counter:
   * dynamic register indexing (s_set_gpr_idx_on / v_movrel*): an accumulator array indexed by a runtime value
     (conv_f32_wino32.hip's epilogue indexed 128 accumulators by the wave's plane half: 72 pairs + 330 v_mov);
-  * scratch (private memory) traffic: a local array that was not promoted to registers.
+  * scratch (private memory) traffic: a local array that was not promoted to registers;
+  * (round 4) buffer accesses wrapped in waterfall loops: a descriptor that ended up in VGPRs.
 
 Usage: python tools/isa_lint.py [file.hip ...]        (default: every kernel source under yolo2_light_amd/csrc)
-Exit code 1 if any kernel uses scratch or dynamic register indexing."""
+Exit code 1 if any kernel uses scratch, dynamic register indexing or waterfall loops."""
 import glob
 import os
 import re
@@ -40,11 +41,16 @@ def lint(path: str):
         lds = field("group_segment_fixed_size")
         scratch = int(field("private_segment_fixed_size"))
         dyn = len(re.findall(r"s_set_gpr_idx_on|v_movrel", body))
+        # waterfall loop: a buffer instruction whose descriptor the compiler holds in VGPRs (a "uniform" value it computed on
+        # the vector unit, e.g. a division): v_readfirstlane x4 + v_cmp_eq_u64 x2 + s_and_saveexec around EVERY access
+        # (conv_f32_x3.hip's first version: 11 of them per K-loop iteration)
+        wfall = len(re.findall(r"s_and_saveexec_b64[^\n]*\n(?:[^\n]*\n){0,2}?\s*buffer_(?:load|store)", body))
         scr = len(re.findall(r"\bscratch_(load|store)", body))
         flag = ""
-        if scratch or scr or dyn:
+        if scratch or scr or dyn or wfall:
             flag = "   <-- " + ", ".join(x for x in ("scratch %d B" % scratch if scratch or scr else "",
-                                                   "%d dynamic register index ops" % dyn if dyn else "") if x)
+                                                   "%d dynamic register index ops" % dyn if dyn else "",
+                                                   "%d buffer accesses in waterfall loops" % wfall if wfall else "") if x)
             bad += 1
         short = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip() or name
         print("%-110s vgpr %4s lds %6s%s" % (short[:110], vgpr, lds, flag))
