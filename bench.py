@@ -2,7 +2,10 @@
 """bench.py -- images/sec of the YOLO inference hot path on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N > 1 is launched with torch.distributed.run, one rank per GPU (RCCL).
+  N > 1 runs one rank per GPU (RCCL).  Under torch.distributed.run (RANK set: the driver's form) this process IS
+  a rank and WORLD_SIZE must equal N; started plainly with N > 1 the script launches the N ranks itself
+  (relaunch_one_rank_per_gpu) and fails loudly when the node has fewer than N devices -- `--gpus N` never times
+  fewer than N GPUs.
 A "step" = one pass of the hot path over one batch of synthetic images that are already resident in
 HBM: forward of every layer -> on-device detection decode + compaction + per-class NMS for every image
 (yl_network_detect_batch) -> (N>1) RCCL all-gather of the fixed-capacity detection records.
@@ -807,23 +810,54 @@ def int8_vs_reference_int8(Network, cfg_q, wts, size, device, thresh, nms, image
     }
 
 
+def relaunch_one_rank_per_gpu(n: int) -> int:
+    """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: start N ranks of this script
+    (one process per GPU, RCCL) on THIS node and hand their exit code back.  Refuses loudly when the node
+    has fewer than N devices instead of timing fewer GPUs than the line would then claim."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    print("bench.py: --gpus %d outside torch.distributed.run -> launching %d ranks (one per GPU, RCCL) on this node; "
+          "%d device(s) visible" % (n, n, have), file=sys.stderr)
+    if have < n and not os.environ.get("YL_BENCH_FORCE_LAUNCH"):     # the override exists for tests/test_bench_launch.py
+        print("bench.py: --gpus %d needs %d visible GPUs, this node has %d: refusing to time fewer GPUs than asked for"
+              % (n, n, have), file=sys.stderr)
+        return 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", YL_BENCH_LAUNCH="self-relaunch")
+    return subprocess.call(cmd, cwd=ROOT, env=env)
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(relaunch_one_rank_per_gpu(args.gpus))
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: the line's n_gpus must be the number of ranks that ran"
+                         % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # launched by torch.distributed.run (RANK set) -> always use the RCCL path, even at world 1,
     # so the single-GPU box exercises exactly the code the multi-GPU runs execute
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py rank %d of %d needs GPU %d: the HIP path has no CPU fallback (%d device(s) visible)"
+                         % (rank, world, local_rank, torch.cuda.device_count() if torch.cuda.is_available() else 0))
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -944,8 +978,29 @@ def main():
         result[("fp32", "int8", "bf16")[quantized]] = info
         leg.close()
 
+    weak = None
+    if world > 1 and args.scaling == "strong" and do_fp32 and not args.no_extras:
+        # the same model at `--batch` images PER GPU (weak scaling) beside the strong-scaled `value`: separates what the
+        # sharding + RCCL gather cost from what the kernels lose on 64/N images per GPU
+        import copy
+        wargs = copy.copy(args)
+        wargs.global_batch = args.batch * world
+        del x
+        torch.cuda.empty_cache()
+        gen.manual_seed(2222222 + rank)
+        xw = torch.rand((args.batch, 3, args.size, args.size), generator=gen, device=dev, dtype=torch.float32)
+        leg = Leg(wargs, torch, dist, dev, stream, Network, cfg, wts, 0, args.batch, world, use_dist)
+        el = leg.run(xw, args.steps, args.warmup)
+        weak = {"value": wargs.global_batch * args.steps / el, "unit": "images/sec", "ms_per_step": el / args.steps * 1e3,
+                "global_batch": wargs.global_batch, "images_per_gpu": args.batch, "scaling": "weak",
+                "what": "FP32 leg with --batch images on EVERY GPU (global batch x%d), same step incl. the RCCL all-gather" % world}
+        leg.close()
+        x = xw
+
     if rank == 0:
         extras = {}
+        if weak is not None:
+            extras["weak_scaling"] = weak
         if world == 1 and not args.no_extras and do_fp32 and not xnor_model:
             try:
                 extras["batch_sweep"] = batch_sweep(args, torch, dev, stream, Network, cfg, wts, x)
@@ -1010,6 +1065,9 @@ def main():
             "value": head["value"],
             "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "launch": {"ranks": world, "rccl_ranks": (dist.get_world_size() if use_dist else 0),
+                       "form": (os.environ.get("YL_BENCH_LAUNCH") or ("torch.distributed.run" if use_dist else "single process")),
+                       "gpus_flag": args.gpus},
             "ms_per_step": head["ms_per_step"],
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
