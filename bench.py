@@ -215,6 +215,31 @@ def wino_executed_flops(li: dict, B: int) -> float:
     return 2.0 * m * li["c"] * 16.0 * tiles
 
 
+def row3_executed_flops(li: dict, B: int, name: str) -> float:
+    """BF16-MFMA FLOPs conv_f32_row3 issues: four planes x six piece products per (filter, channel, filter row, tile of two
+    output columns), filters padded to 32, tiles = B * h * ceil(w / 2) padded to the workgroup's tile count (in the name)"""
+    import re
+    m = re.search(r"<(\d+)x(\d+)t", name)
+    bt = int(m.group(2)) if m else 128
+    tiles = B * li["h"] * ((li["w"] + 1) // 2)
+    tiles = (tiles + bt - 1) // bt * bt
+    mm = (li["n"] + 31) // 32 * 32
+    return 2.0 * mm * (3.0 * li["c"]) * 4.0 * tiles * 6.0
+
+
+def kernel_pipe(name: str) -> str:
+    """which execution pipe a convolution kernel instance issues its multiplies on"""
+    if name.startswith("conv_f32_row3") or name.startswith("conv_f32_x3") or name.startswith("conv_bf16"):
+        return "bf16_mfma"
+    if name.startswith("conv_f32_first"):
+        return "fp32_valu"
+    if name.startswith("conv_i8"):
+        return "int8_mfma"
+    if name.startswith("conv_xnor"):
+        return "valu_popcount"
+    return "fp32_mfma"
+
+
 def iou(a, b):
     def ov(x1, w1, x2, w2):
         return min(x1 + w1 / 2, x2 + w2 / 2) - max(x1 - w1 / 2, x2 - w2 / 2)
@@ -377,7 +402,14 @@ class Leg:
             rd, wr = net.layer_traffic(i)
             k = kern.setdefault(name, {"flops": 0.0, "exec_flops": 0.0, "bytes": 0.0, "ms": 0.0, "launches": 0})
             k["flops"] += flops
-            k["exec_flops"] += wino_executed_flops(li, B) if "wino" in name else flops
+            if "wino" in name:
+                k["exec_flops"] += wino_executed_flops(li, B)          # FP32 MFMA: 16 multiplies per 2x2 tile
+            elif name.startswith("conv_f32_row3"):
+                k["exec_flops"] += row3_executed_flops(li, B, name)    # BF16 MFMA: 4 planes x 6 piece products per tile pair
+            elif name.startswith("conv_f32_x3"):
+                k["exec_flops"] += 6.0 * flops                         # BF16 MFMA: 6 piece products per multiply
+            else:
+                k["exec_flops"] += flops
             k["bytes"] += rd + wr
             k["ms"] += float(self.layer_ms[i])
             k["launches"] += 1
@@ -447,7 +479,8 @@ def pmc_traffic(leg, kernel_name: str):
 
 
 _KERNEL_SYMBOL = {          # bench kernel instance -> substring of the C++ kernel name rocprofv3 reports
-    "conv_f32_wino": "conv_f32_wino32_kernel<", "conv_i8_mfma<128x128>": "conv_i8_mfma_kernel<128, 128",
+    "conv_f32_wino": "conv_f32_wino32_kernel<", "conv_f32_row3": "conv_f32_row3_kernel<", "conv_f32_x3": "conv_f32_x3_kernel<",
+    "conv_i8_mfma<128x128>": "conv_i8_mfma_kernel<128, 128",
     "conv_bf16_mfma<128x128>": "conv_bf16_mfma_kernel<128, 128", "conv_xnor": "conv_xnor_kernel<",
 }
 
@@ -525,34 +558,61 @@ def torchrun_world1(args, timeout_s: float = 300.0):
 
 
 def fp32_roofline(leg, args):
+    """Roofline block of the FP32 leg.  Since round 4 the FP32 convolutions issue their multiplies on THREE pipes: the BF16
+    matrix pipe (K1r row-wise Winograd and K1x direct layers: FP32 operands as exact sums of three bf16 pieces, six piece
+    products per multiply), the FP32 matrix instruction (2-D Winograd with a folded [maxpool], layers with C % 16 != 0, <= 32
+    filters) and the FP32 vector ALU (first layer).  `achieved` / `peak` / `frac` are the dominant kernel's on ITS pipe --
+    executed (issued) FLOPs incl. tile padding / measured launch time; the algorithmic rate 2*M*K*N is separate."""
+    peaks = {"bf16_mfma": BF16_MFMA_PEAK_TFLOPS, "fp32_mfma": FP32_MATRIX_PEAK_TFLOPS, "fp32_valu": FP32_MATRIX_PEAK_TFLOPS}
     kern = leg.kernels()
     dom_name = max(kern, key=lambda n: kern[n]["flops"])
     dom = kern[dom_name]
+    pipe = kernel_pipe(dom_name)
+    peak = peaks[pipe]
     sec = dom["ms"] * 1e-3
     executed = dom["exec_flops"] / sec / 1e12 if sec > 0 else 0.0
     algorithmic = dom["flops"] / sec / 1e12 if sec > 0 else 0.0
     conv_ms = sum(k["ms"] for k in kern.values())
     conv_flops = sum(k["flops"] for k in kern.values())
-    conv_exec = sum(k["exec_flops"] for k in kern.values())
     traffic, traffic_src = pmc_traffic(leg, dom_name)
     n = max(dom["launches"], 1)
+    per_pipe = {}
+    for nm, k in kern.items():
+        pp = per_pipe.setdefault(kernel_pipe(nm), {"ms_per_step": 0.0, "executed_flops": 0.0, "algorithmic_flops": 0.0, "launches": 0})
+        pp["ms_per_step"] += k["ms"]; pp["executed_flops"] += k["exec_flops"]; pp["algorithmic_flops"] += k["flops"]
+        pp["launches"] += k["launches"]
+    for pn, pp in per_pipe.items():
+        t = pp["ms_per_step"] * 1e-3
+        pp["share_of_conv_time"] = pp["ms_per_step"] / conv_ms if conv_ms > 0 else 0.0
+        pp["executed_tflops"] = pp.pop("executed_flops") / t / 1e12 if t > 0 else 0.0
+        pp["algorithmic_tflops"] = pp.pop("algorithmic_flops") / t / 1e12 if t > 0 else 0.0
+        pp["peak_tflops"] = peaks[pn]
+        pp["frac"] = pp["executed_tflops"] / peaks[pn]
+    all_alg = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     return {
-        "bound": "mfma", "kernel": dom_name,
-        "achieved": executed, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": executed / FP32_MATRIX_PEAK_TFLOPS,
-        "achieved_is": "executed MFMA FLOPs (Winograd: 16 multiplies per 2x2 tile incl. tile padding) / measured launch time",
+        "bound": "mfma", "pipe": pipe, "kernel": dom_name,
+        "achieved": executed, "peak": peak, "unit": "TFLOP/s",
+        "frac": executed / peak,
+        "achieved_is": {"bf16_mfma": "issued BF16-MFMA FLOPs (six bf16 piece products per FP32 multiply; row-wise Winograd: 4 planes per "
+                                     "filter row and tile of two output columns; incl. tile padding) / measured launch time, vs the dense "
+                                     "bf16 MFMA peak",
+                        "fp32_mfma": "executed FP32-MFMA FLOPs (Winograd: 16 multiplies per 2x2 tile incl. tile padding) / measured launch time",
+                        "fp32_valu": "fma FLOPs / measured launch time"}[pipe],
         "algorithmic_tflops": algorithmic,                      # 2*M*K*N per launch / the same time (SURVEY 8d)
-        "algorithmic_speedup": dom["flops"] / dom["exec_flops"] if dom["exec_flops"] else None,
+        "algorithmic_vs_fp32_matrix_peak": algorithmic / FP32_MATRIX_PEAK_TFLOPS,
+        "issued_per_algorithmic_flop": dom["exec_flops"] / dom["flops"] if dom["flops"] else None,
         "traffic": traffic,
         "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": dom["bytes"] / n,
         "algorithmic_flops_per_launch": dom["flops"] / n, "executed_flops_per_launch": dom["exec_flops"] / n,
         "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / n,
-        "all_conv_algorithmic_tflops": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
-        "all_conv_executed_tflops": conv_exec / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
-        "all_conv_executed_frac": (conv_exec / (conv_ms * 1e-3) / 1e12) / FP32_MATRIX_PEAK_TFLOPS if conv_ms > 0 else 0.0,
+        "all_conv_algorithmic_tflops": all_alg,
+        "all_conv_algorithmic_vs_fp32_matrix_peak": all_alg / FP32_MATRIX_PEAK_TFLOPS,   # north_star's target: >= 0.70
+        "per_pipe": per_pipe,
         "conv_ms_per_step": conv_ms, "other_layers_ms_per_step": float(leg.layer_ms.sum() - conv_ms),
-        "by_kernel": {nm: {"executed_tflops": (k["exec_flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0),
+        "by_kernel": {nm: {"pipe": kernel_pipe(nm),
+                           "executed_tflops": (k["exec_flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0),
+                           "frac_of_pipe_peak": (k["exec_flops"] / (k["ms"] * 1e-3) / 1e12 / peaks.get(kernel_pipe(nm), 1e30) if k["ms"] > 0 else 0.0),
                            "algorithmic_tflops": (k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0),
                            "algorithmic_gbs": (k["bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0),
                            "ms_per_step": k["ms"], "launches": k["launches"]} for nm, k in kern.items()},
@@ -780,10 +840,12 @@ def int8_vs_reference_int8(Network, cfg_q, wts, size, device, thresh, nms, image
     if not refbind.available(fast=True):
         return None
     ref = refbind.RefNetwork(cfg_q, wts, 1, 1, fast=True)
+    ref_fp = refbind.RefNetwork(cfg_q, wts, 1, 0, fast=True)     # the reference's FP32 path on the same images: how far ITS INT8 is from ITS FP32
     hip = Network.load(cfg_q, wts, 1, 1, device=device, fuse=True)
     rng = np.random.default_rng(2222222)
     heads = [i for i in range(hip.n) if hip.layer_info(i)["type"] in (21, 22)]
-    ref_rows, hip_rows = [], []
+    ref_rows, hip_rows, ref_fp_rows = [], [], []
+    fp_corr = {i: [] for i in heads}
     err2 = {i: 0.0 for i in heads}; nrm2 = {i: 0.0 for i in heads}; exact = {i: 0 for i in heads}; total = {i: 0 for i in heads}
     for _ in range(images):
         x = rng.random((1, 3, size, size), dtype=np.float32)
@@ -795,9 +857,22 @@ def int8_vs_reference_int8(Network, cfg_q, wts, size, device, thresh, nms, image
             exact[i] += int((g == r).sum()); total[i] += r.size
         ref_rows.append(ref.get_detections(0, size, size, thresh, nms=nms))
         hip_rows.append(hip.get_boxes(0, size, size, thresh, nms=nms))
+        q_heads = {i: ref.layer_output(i).astype(np.float64).ravel() for i in heads}
+        ref_fp.predict(x)
+        ref_fp_rows.append(ref_fp.get_detections(0, size, size, thresh, nms=nms))
+        for i in heads:
+            fp_corr[i].append(float(np.corrcoef(ref_fp.layer_output(i).astype(np.float64).ravel(), q_heads[i])[0, 1]))
     hip.close()
     agree = detection_agreement(ref_rows, hip_rows)
+    ref_q_vs_fp = detection_agreement(ref_fp_rows, ref_rows)
     return {
+        "reference_int8_vs_reference_fp32": {
+            "what": "the REFERENCE's own network_predict_quantized against its own network_predict_cpu on the same images and "
+                    "synthetic weights: what `agreement_vs_fp32` of the HIP legs has to be read against -- the reference's 8-bit scheme "
+                    "itself does not reproduce FP32 detections on i.i.d. weights, and the HIP INT8 path reproduces the reference's INT8",
+            "reference_fp32_detections": ref_q_vs_fp["fp32_detections"], "reference_int8_detections": ref_q_vs_fp["int8_detections"],
+            "matched": ref_q_vs_fp["matched"], "recall": ref_q_vs_fp["recall_vs_fp32"], "precision": ref_q_vs_fp["precision_vs_fp32"],
+            "head_pearson": [float(np.mean(fp_corr[i])) for i in heads]},
         "images": images,
         "reference_int8_detections": agree["fp32_detections"], "hip_int8_detections": agree["int8_detections"],
         "matched": agree["matched"], "recall_vs_reference_int8": agree["recall_vs_fp32"],
@@ -928,12 +1003,23 @@ def main():
                 info["roofline"] = int8_roofline(leg)
             else:
                 info["roofline"] = fp32_roofline(leg, args)
+                fam = {}
+                for nm, k in leg.kernels().items():
+                    f = nm.split("<")[0]
+                    fam[f] = fam.get(f, 0) + k["launches"]
+                info["arithmetic"] = (
+                    "FP32 tensors in and out of every layer, FP32 accumulation; of the %d convolutions per step %d run as row-wise Winograd "
+                    "F(2,3) and %d as direct convolutions on the BF16 MFMA pipe with every operand the exact sum of three bf16 pieces "
+                    "(six piece products per multiply, FP32-class accuracy: tests/test_gpu_parity.py::test_fp32_error_vs_float64_truth), "
+                    "%d as Winograd F(2x2,3x3) and %d as direct convolutions on the FP32 MFMA, %d on the FP32 vector ALU" % (
+                        sum(fam.values()), fam.get("conv_f32_row3", 0), fam.get("conv_f32_x3", 0), fam.get("conv_f32_wino", 0),
+                        fam.get("conv_f32_mfma_pipe", 0) + fam.get("conv_f32_smallk", 0), fam.get("conv_f32_first", 0)))
                 if world == 1 and not args.no_extras:
                     clk = leg.sample_sclk(x, dev.index)
                     if clk:
                         rl = info["roofline"]
                         rl["sclk_mhz"] = clk
-                        rl["peak_at_sclk"] = FP32_MATRIX_PEAK_TFLOPS * clk / NOMINAL_SCLK_MHZ
+                        rl["peak_at_sclk"] = rl["peak"] * clk / NOMINAL_SCLK_MHZ
                         rl["frac_at_sclk"] = rl["achieved"] / rl["peak_at_sclk"] if rl.get("achieved") else None
                         rl["sclk_note"] = ("shader clock reported by rocm-smi while this leg runs (median of 3 samples over untimed steps "
                                            "after the timed region); `peak` and `frac` are at the 2.4 GHz of MI355X_MICROARCH.md, "
@@ -1078,7 +1164,8 @@ def main():
                                        ("BIT1-XNOR" if xnor_model else "FP32") if do_fp32 else ("INT8" if do_int8 else "BF16")),
                        "global_batch": args.global_batch,
                        "parallelism": "image-batch sharding x%d (%s scaling)" % (world, args.scaling),
-                       "gflop_per_image": head.get("gflop_per_image")},
+                       "gflop_per_image": head.get("gflop_per_image"),
+                       "arithmetic": head.get("arithmetic")},
             "roofline": head.get("roofline"),
             "detect_ms_per_step": head.get("detect_ms_per_step"),
             "detections_per_image": head.get("detections_per_image"),

@@ -298,22 +298,26 @@ int yl_network_pull_heads(yl_network *net);
  * yl_network_set_conv_tile: force the K1 kernel of every FP32 convolution of this network, any time:
  *   0 = built-in heuristic (default), 11..22 = direct implicit-GEMM tile 1..12 (conv_f32_mfma.hip),
  *   31 = Winograd F(2x2,3x3) (conv_f32_wino32.hip; a launch fails on layers it does not apply to),
- *   41 = LDS-free first-layer kernel (conv_f32_smallk.hip; C*size^2 <= 32 and filters <= 32 only).
+ *   41 = LDS-free first-layer kernel (conv_f32_smallk.hip; C*size^2 <= 32 and filters <= 32 only),
+ *   51..53 = the three-piece BF16 kernel's tiles (conv_f32_x3.hip), 61..69 = the row-wise Winograd kernel's tiles and
+ *   schedules (conv_f32_row3.hip; 3x3 / stride 1 / pad 1 layers with C % 16 == 0 only).
  * yl_network_set_winograd: 0 = never pick Winograd heuristically and do not pack its weights, 1 = default;
  *   BEFORE yl_network_to_device.
  * yl_network_set_nms_mode: yl_network_detect_batch's suppression stage, 1 = one workgroup per
  *   (image, class) (default), 0 = one workgroup per image; same rows either way. */
 int yl_network_set_conv_tile(yl_network *net, int cfg);
 /* kernel-selection / schedule switches kept for same-box A/B measurements.  Bits 0-3 and 6-9 change the schedule only
- * (bit-identical results); bits 4, 5 and 10 change WHICH kernel a layer takes (results within the FP32 contract):
+ * (bit-identical results); bits 4, 5, 10 and 11 change WHICH kernel a layer takes (results within the FP32 contract):
  * bit 0 Winograd U panels by LDS-DMA, bit 1 Winograd epilogue prefetches the fused [shortcut] operand, bit 2 float4 B-panel
  * rows in the 1x1 direct kernel, bit 3 LDS-free first-layer kernel, bit 4 Winograd from 32 input channels up, bit 5 from 16,
  * bit 6 persistent Winograd workgroups (per-XCD tile counters), bit 7 the Winograd input transform in its register-shift
  * form (default: column masks folded into the transform), bit 8 sign-only XNOR layers evaluate the float epilogue instead of
  * comparing the match count with its threshold, bit 9 XNOR layers with >= 64 filters always run 64-filter workgroups
  * (default: 32 on shallow grids), bit 10 the direct FP32 layers with C % 16 == 0 and more than 32 filters on the BF16 matrix
- * pipe with every operand as the exact sum of three bf16 pieces (conv_f32_x3.hip; FP32 tensors, FP32-class accuracy);
- * -1 = built-in default (bits 1-5 and 10) */
+ * pipe with every operand as the exact sum of three bf16 pieces (conv_f32_x3.hip; FP32 tensors, FP32-class accuracy),
+ * bit 11 the 3x3 / stride-1 layers Winograd would take as ROW-WISE Winograd F(2,3) on the BF16 matrix pipe, three-piece
+ * operands (conv_f32_row3.hip) instead of F(2x2,3x3) on the FP32 matrix instruction;
+ * -1 = built-in default (bits 1-5, 10 and 11) */
 int yl_network_set_variant(yl_network *net, int bits);
 /* Opt-in BF16 variant of the FP32 path (north_star (a) "FP32/BF16"; BEFORE yl_network_to_device): every FP32
  * convolution whose input has whole 8-channel groups runs on v_mfma_f32_32x32x16_bf16 with both operands rounded
@@ -333,21 +337,8 @@ int yl_network_set_nms_mode(yl_network *net, int mode);
  * 1 (default) = the prepared weights are uploaded as they are and packed by kernels on the device (csrc/pack.hip),
  * 0 = packed by host loops and uploaded inflated.  Bit-identical images either way.  BEFORE yl_network_to_device. */
 int yl_network_set_device_pack(yl_network *net, int on);
-/* Test hook: the packed weight image of conv layer i as it sits on the device: which = 0 k-major FP32 panels,
- * 1 Winograd U, 2 int8 / bf16 units, 3 XNOR sign words; XNOR layers also 4 = int32 count thresholds of the sign-only
- * epilogue [Mpad] + the number of filters without one, 5 = mean[M], 6 = bias[M]; 7 = the weights as three bf16 pieces
- * (conv_f32_x3.hip).  Returns its size in bytes (0 = none);
- * copies it when dst_host != NULL (dst_bytes >= size). */
-long long yl_debug_layer_packed(yl_network *net, int i, int which, void *dst_host, long long dst_bytes);
-/* Test hook (host only, no GPU needed): the Winograd weight transform U = G g G^T of a 3x3 layer
- * (weights[m][c][3][3]) packed the way the kernel reads it.  tiling must be 32 (conv_f32_wino32.hip):
- * [m/32][c/4][xi 16][half 2][m 32][kk 2] with channel = panel*4 + 2*kk + half.  (16 / 64 selected round 3's
- * alternative kernels, removed in round 4: YL_ERR_ARG.)  dst == NULL returns the number of floats needed. */
-long long yl_debug_wino_pack(const float *weights, int c, int m, int tiling, float *dst, long long dst_floats);
-/* Test hook (host only): the weights of a convolution (weights[m][c][size][size], c % 16 == 0) as conv_f32_x3.hip reads them:
- * every weight as three bf16 numbers whose sum is the weight exactly, [panel][piece 3][k-octet 2][Mpad][8] with panel =
- * (channel / 16) * size^2 + tap, Mpad = m rounded up to 128, zero padded.  dst == NULL returns the number of bytes needed. */
-long long yl_debug_x3_pack(const float *weights, int c, int m, int size, void *dst, long long dst_bytes);
+/* (The test / lab instrumentation of the library -- packed-weight read-back, host-side packers -- is declared in
+ * include/yolo2_hip_lab.h: not part of the drop-in boundary, nothing a caller of network_predict needs.) */
 
 /* On-device detection compaction (new): threshold test
  * `objectness > thresh` (src/additionally.c:4341) and box decode

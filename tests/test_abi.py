@@ -1,5 +1,5 @@
-"""The C-ABI library loads and exports every symbol include/yolo2_hip.h declares
-(no compute calls: this runs without a GPU)."""
+"""The C-ABI library loads and exports every symbol include/*.h declares -- the drop-in boundary (yolo2_hip.h) and the
+test / lab instrumentation (yolo2_hip_lab.h) -- (no compute calls: this runs without a GPU)."""
 import os
 import re
 
@@ -7,13 +7,22 @@ import common  # noqa: F401
 from yolo2_light_amd import _lib
 
 HEADER = os.path.join(common.ROOT, "include", "yolo2_hip.h")
+LAB_HEADER = os.path.join(common.ROOT, "include", "yolo2_hip_lab.h")
 
 
-def header_functions():
-    text = open(HEADER).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"\b(yl_[a-z0-9_]+)\s*\(", text)
+def header_functions(paths=(HEADER, LAB_HEADER)):
+    names = []
+    for path in paths:
+        text = open(path).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"\b(yl_[a-z0-9_]+)\s*\(", text)
     return sorted(set(names))
+
+
+def test_the_drop_in_header_declares_no_test_hooks():
+    """the yl_debug_* hooks are lab instrumentation, not part of the boundary a caller sees"""
+    assert not [n for n in header_functions((HEADER,)) if n.startswith("yl_debug")]
+    assert [n for n in header_functions((LAB_HEADER,)) if n.startswith("yl_debug")]
 
 
 def test_every_declared_symbol_is_exported():

@@ -284,7 +284,11 @@ def test_winograd_switch_off_keeps_direct_kernel():
     net.close()
     net = _net_from([d], B, W, H, Cc)
     net.predict(x)
-    assert "wino" in net.layer_kernel(0)
+    assert "conv_f32_row3<" in net.layer_kernel(0)          # default since round 5: row-wise F(2,3) on the BF16 pipe (K1r)
+    net.close()
+    net = _net_from([d], B, W, H, Cc, variant=62 | 1024)
+    net.predict(x)
+    assert "wino" in net.layer_kernel(0)                    # without variant bit 11: the 2-D FP32 Winograd kernel
     net.close()
 
 
@@ -509,29 +513,33 @@ def test_fp32_error_vs_float64_truth(name, width, height):
         ref = refbind.RefNetwork(cfg, wts, batch, 0, fast=fast)
         ref.predict(x)
         runs[tag] = [ref.layer_output(i) for i in range(ref.n)]
-    # "hip": the shipped default (Winograd on the 3x3 / stride-1 layers, K1x = three-piece bf16 operands on the other layers
-    # with C % 16 == 0); "hip_direct": every layer on the FP32-MFMA direct kernel (variant without bit 10, Winograd off);
-    # "hip_x3": every layer K1x takes on K1x, the 3x3 / stride-1 ones included (Winograd off) -- not a shipped configuration
-    for tag, wino, variant in (("hip", True, None), ("hip_direct", False, 62), ("hip_x3", False, 62 | 1024)):
+    # "hip": the shipped default (round 5: K1r = row-wise Winograd F(2,3) with three-piece bf16 operands on the 3x3 / stride-1
+    # layers -- the 2-D FP32 Winograd kernel where a [maxpool] is folded in --, K1x = three-piece bf16 operands on the other
+    # layers with C % 16 == 0); "hip_wino": round 4's default (2-D FP32 Winograd + K1x); "hip_direct": every layer on the
+    # FP32-MFMA direct kernel (variant without bits 10 / 11, Winograd off); "hip_x3": every layer K1x takes on K1x, the
+    # 3x3 / stride-1 ones included (Winograd off) -- not a shipped configuration
+    for tag, wino, variant in (("hip", True, None), ("hip_wino", True, 62 | 1024), ("hip_direct", False, 62), ("hip_x3", False, 62 | 1024)):
         net = Network.load(cfg, wts, batch, 0, device=0, winograd=wino, variant=variant)
         net.predict(x)
         if tag == "hip":
-            assert any("conv_f32_x3<" in net.layer_kernel(i) for i in range(net.n)) and any("wino" in net.layer_kernel(i) for i in range(net.n))
+            assert any("conv_f32_x3<" in net.layer_kernel(i) for i in range(net.n)) and any("conv_f32_row3<" in net.layer_kernel(i) for i in range(net.n))
+        if tag == "hip_wino":
+            assert any("wino" in net.layer_kernel(i) for i in range(net.n)) and not any("row3" in net.layer_kernel(i) for i in range(net.n))
         if tag == "hip_direct":
             assert not any("x3" in net.layer_kernel(i) or "wino" in net.layer_kernel(i) for i in range(net.n))
         runs[tag] = [net.layer_output(i) for i in range(net.n)]
         net.close()
-    worst = {"hip": 0.0, "hip_direct": 0.0, "hip_x3": 0.0}
+    worst = {"hip": 0.0, "hip_wino": 0.0, "hip_direct": 0.0, "hip_x3": 0.0}
     for i in range(host.n):
         e = {t: common.error_vs_truth(runs[t][i], truth.outputs[i]) for t in runs}
-        for t in ("hip", "hip_direct", "hip_x3"):
+        for t in ("hip", "hip_wino", "hip_direct", "hip_x3"):
             for k, what in ((0, "relative RMS error"), (1, "max error / layer RMS")):
                 allowed = 1.5 * max(e["scalar"][k], e["avx"][k])
                 worst[t] = max(worst[t], e[t][k] / max(allowed, 1e-30))
                 assert e[t][k] <= allowed, "layer %d %s: %s %.3g vs reference scalar %.3g / AVX %.3g" % (
                     i, t, what, e[t][k], e["scalar"][k], e["avx"][k])
-    print("%s %dx%d: worst (HIP error) / (1.5 x reference error): default %.3f, FP32-MFMA direct %.3f, K1x everywhere %.3f" % (
-        name, width, height, worst["hip"], worst["hip_direct"], worst["hip_x3"]))
+    print("%s %dx%d: worst (HIP error) / (1.5 x reference error): default (K1r + K1x) %.3f, 2-D FP32 Winograd + K1x %.3f, FP32-MFMA direct %.3f, "
+          "K1x everywhere %.3f" % (name, width, height, worst["hip"], worst["hip_wino"], worst["hip_direct"], worst["hip_x3"]))
     # The heads, element by element, under north_star's own tolerance (1e-4 relative).  No FP32 evaluation of a
     # 75-layer network is within 1e-4 of the truth on EVERY element (cancellation results): what is asserted is that
     # the HIP path meets the tolerance at least as often as the reference's worse build.  (How often each path
@@ -545,11 +553,11 @@ def test_fp32_error_vs_float64_truth(name, width, height):
         t = truth.outputs[i]
         s = runs["scalar"][i].astype(np.float64)
         within = {tg: float(np.mean(np.abs(runs[tg][i] - t) <= 1e-4 * np.abs(t))) for tg in runs}
-        differs = {tg: float(np.mean(np.abs(runs[tg][i] - s) > 1e-4 * np.abs(s))) for tg in ("avx", "hip", "hip_direct", "hip_x3")}
+        differs = {tg: float(np.mean(np.abs(runs[tg][i] - s) > 1e-4 * np.abs(s))) for tg in ("avx", "hip", "hip_wino", "hip_direct", "hip_x3")}
         print("head %d: within 1e-4 of the truth %s; differs from reference scalar by more than 1e-4 %s" % (
             i, {k: "%.5f" % v for k, v in within.items()}, {k: "%.2e" % v for k, v in differs.items()}))
         assert min(within["scalar"], within["avx"]) > 0.99
-        for tg in ("hip", "hip_direct"):
+        for tg in ("hip", "hip_wino", "hip_direct"):
             assert within[tg] >= min(within["scalar"], within["avx"]) - 1e-4, "head %d %s: %r" % (i, tg, within)
         # K1x on all 75 layers (not shipped: the default keeps Winograd): its products drop the three smallest cross terms
         # (<= 3 * 2^-24 relative, as large as FP32's own rounding), so the per-layer error is ~1.4x the FP32-MFMA kernel's

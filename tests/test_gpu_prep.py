@@ -51,7 +51,7 @@ def test_device_prep_equals_host_prep(name, width, height, quantized):
 ])
 def test_device_packers_equal_host_packers(name, width, height, quantized, bf16, variant):
     """csrc/pack.hip against the host loops of runtime.hip / conv_f32_wino32.hip: every packed weight image a network
-    uploads (k-major FP32 panels, Winograd U, int8 / bf16 16-byte units, XNOR sign words, K1x's three-piece bf16 weights)
+    uploads (k-major FP32 panels, Winograd U, int8 / bf16 16-byte units, XNOR sign words, K1x's three-piece bf16 weights, K1r's row-transformed ones)
     identical byte for byte,
     and the same forward pass."""
     cfg, wts = common.model_files(name, width, height)
@@ -60,7 +60,7 @@ def test_device_packers_equal_host_packers(name, width, height, quantized, bf16,
     for i, li in enumerate(nets[0].layers()):
         if li["type"] != common.CONV:
             continue
-        for which in (0, 1, 2, 3, 7):          # 7: the three-piece bf16 weights of K1x (conv_f32_x3.hip)
+        for which in (0, 1, 2, 3, 7, 8):       # 7 / 8: the three-piece bf16 weights of K1x / K1r (conv_f32_x3.hip, conv_f32_row3.hip)
             a, b = nets[0].layer_packed(i, which), nets[1].layer_packed(i, which)
             assert (a is None) == (b is None), "layer %d image %d" % (i, which)
             if a is not None:

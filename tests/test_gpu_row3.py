@@ -1,0 +1,172 @@
+"""K1r (conv_f32_row3.hip): the 3x3 / stride-1 / pad-1 FP32 convolution as row-wise Winograd F(2,3) on the BF16 matrix pipe
+with three-piece operands -- against the oracle restatement of forward_convolutional_layer_cpu
+(src/yolov2_forward_network.c:204-261), against a float64 convolution, and for the properties the other FP32 kernels hold:
+every tile / schedule bit-identical to every other, fused [shortcut] == the unfused pair bit for bit, batch items
+independent of what shares their workgroup.
+"""
+import numpy as np
+import pytest
+
+import common
+import descs as D
+from common import Network, fp, fp32_close
+
+pytestmark = pytest.mark.gpu
+
+ROW3_TILES = list(range(61, 70))         # yl_network_set_conv_tile: 61..69 = conv_f32_row3.hip's tiles and schedules
+
+ROW3_SHAPES = [
+    # B, C, H, W, M, act
+    (2, 16, 13, 13, 33, D.LEAKY),          # one channel block (3 groups), M tail, odd width: 7 tiles per row, the last half empty
+    (3, 32, 19, 19, 70, D.LINEAR),         # odd size 19 (yolov3-608's last scale), linear
+    (1, 256, 13, 13, 512, D.LEAKY),        # deep K: 48 groups, 4 filter tiles of 128
+    (2, 48, 11, 9, 96, D.LEAKY),           # H != W, both odd, three channel blocks
+    (2, 64, 38, 38, 128, D.LEAKY),         # even width, several tile blocks
+    (1, 32, 76, 76, 64, D.LEAKY),          # many tile blocks, M = 64
+    (4, 128, 6, 10, 255, D.LINEAR),        # M = 255, a tile block spans images
+    (9, 16, 5, 5, 16, D.LEAKY),            # 15 tiles per image: a block of 128 tiles spans 9 images, mostly empty
+    (1, 16, 4, 4, 8, D.LEAKY),             # the smallest layer the dispatcher sends here
+]
+
+
+def _layer(shape, seed):
+    B, Cc, H, W, M, act = shape
+    rng = np.random.default_rng(seed + M + H)
+    K = Cc * 9
+    wts = rng.normal(0, np.sqrt(2.0 / K), M * K).astype(np.float32)
+    bias = rng.normal(0, 0.5, M).astype(np.float32)
+    # nine octaves of magnitude: every piece of the split carries signal
+    x = (rng.standard_normal((B, Cc, H, W)) * np.exp(rng.uniform(-6, 3, (B, Cc, H, W)))).astype(np.float32)
+    return wts, bias, x
+
+
+def _single(shape, wts, bias, variant=0):
+    B, Cc, H, W, M, act = shape
+    d = D.conv(B, W, H, Cc, M, 3, 1, 1, act, wts, bias)
+    net = Network.from_desc([d], B, W, H, Cc, 0)
+    net.set_variant(variant)
+    net.to_device(0)
+    return net, d
+
+
+@pytest.mark.parametrize("shape", ROW3_SHAPES)
+@pytest.mark.parametrize("tile", [61, 62, 63, 64, 66, 68])
+def test_conv_row3_vs_oracle(olib, shape, tile):
+    B, Cc, H, W, M, act = shape
+    wts, bias, x = _layer(shape, 2718)
+    net, d = _single(shape, wts, bias)
+    net.set_conv_tile(tile)
+    got = net.predict(x).copy()
+    assert "conv_f32_row3<" in net.layer_kernel(0), net.layer_kernel(0)
+    ref = np.zeros(B * d.outputs, dtype=np.float32)
+    olib.oracle_conv_f32(fp(x), fp(wts), fp(bias), fp(ref), B, Cc, H, W, M, 3, 1, 1, act)
+    ok, ratio, worst = fp32_close(got, ref)
+    assert ok, "tile %d shape %r: err/allowed %.3g at %d: got %r ref %r" % (tile, shape, ratio, worst, got[worst], ref[worst])
+    assert ratio < 0.2          # FP32-roundoff class, like the FP32-MFMA and the 2-D Winograd kernel
+    # against a float64 convolution: not farther from the truth than 1.5x the FP32-MFMA kernel on the same layer
+    net.set_conv_tile(14)
+    direct = net.predict(x).copy()
+    assert "row3" not in net.layer_kernel(0)
+    import torch
+    truth = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wts.reshape(M, Cc, 3, 3)).double(),
+                                       torch.from_numpy(bias).double(), stride=1, padding=1)
+    if act == D.LEAKY:
+        truth = torch.where(truth > 0, truth, 0.1 * truth)
+    truth = truth.numpy().reshape(-1)
+    rms = float(np.sqrt(np.mean(truth ** 2)))
+    e_r3 = float(np.sqrt(np.mean((got.astype(np.float64) - truth) ** 2))) / rms
+    e_f32 = float(np.sqrt(np.mean((direct.astype(np.float64) - truth) ** 2))) / rms
+    assert e_r3 <= 1.5 * e_f32 + 1e-9, "shape %r: rms error vs float64 %.3g (row3) vs %.3g (FP32 MFMA)" % (shape, e_r3, e_f32)
+    net.close()
+
+
+@pytest.mark.parametrize("shape", ROW3_SHAPES)
+def test_row3_tiles_and_schedules_bit_identical(shape):
+    """nine instances (workgroup tile, planes per panel, where the barrier sits): the same products in the same order"""
+    wts, bias, x = _layer(shape, 31415)
+    net, _ = _single(shape, wts, bias)
+    base = None
+    names = set()
+    for tile in ROW3_TILES:
+        net.set_conv_tile(tile)
+        got = net.predict(x).copy()
+        names.add(net.layer_kernel(0))
+        if base is None:
+            base = got
+        assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), "tile %d shape %r" % (tile, shape)
+    assert len(names) == len(ROW3_TILES) and all("conv_f32_row3<" in n for n in names), names
+    net.close()
+
+
+@pytest.mark.parametrize("width,height,act", [(38, 38, D.LEAKY), (19, 19, D.LEAKY), (13, 9, D.LINEAR)])
+def test_row3_fused_shortcut_is_bit_identical(width, height, act):
+    """conv(1x1) -> conv(3x3, K1r) -> [shortcut]: the epilogue that adds the residual operand (out_add only) against the
+    two-kernel form, and the heuristic picks K1r for the 3x3 layer with the default variant"""
+    B, Cc, M = 3, 64, 64
+    rng = np.random.default_rng(5)
+    w1 = rng.normal(0, np.sqrt(2.0 / Cc), Cc * Cc).astype(np.float32)
+    w2 = rng.normal(0, np.sqrt(2.0 / (Cc * 9)), M * Cc * 9).astype(np.float32)
+    b1 = rng.normal(0, 0.5, Cc).astype(np.float32)
+    b2 = rng.normal(0, 0.5, M).astype(np.float32)
+    x = rng.standard_normal((B, Cc, height, width)).astype(np.float32)
+
+    def build(fuse):
+        descs = [D.conv(B, width, height, Cc, Cc, 1, 1, 0, D.LEAKY, w1, b1),
+                 D.conv(B, width, height, Cc, M, 3, 1, 1, act, w2, b2),
+                 D.shortcut(B, 0, (width, height, Cc), (width, height, M))]
+        net = Network.from_desc(descs, B, width, height, Cc, 0)
+        net.set_fusion(fuse)
+        net.to_device(0)
+        return net
+
+    plain, fused = build(False), build(True)
+    a, b = plain.predict(x).copy(), fused.predict(x).copy()
+    assert "conv_f32_row3<" in plain.layer_kernel(1) and "conv_f32_row3<" in fused.layer_kernel(1)
+    assert not fused.layer_materialised(1)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    plain.close(); fused.close()
+
+
+def test_row3_batch_items_independent():
+    """image k of a batch of 5 == the same image alone, bit for bit (tiles of several images share workgroups at 13 x 13)"""
+    shape = (5, 32, 13, 13, 96, D.LEAKY)
+    wts, bias, x = _layer(shape, 1618)
+    net, _ = _single(shape, wts, bias, variant=-1)
+    got = net.predict(x).copy().reshape(5, -1)
+    assert "conv_f32_row3<" in net.layer_kernel(0)
+    net.close()
+    one = (1,) + shape[1:]
+    net1, _ = _single(one, wts, bias, variant=-1)
+    for k in (0, 2, 4):
+        alone = net1.predict(x[k:k + 1]).copy().reshape(-1)
+        assert np.array_equal(alone.view(np.uint32), got[k].view(np.uint32)), "image %d" % k
+    net1.close()
+
+
+def test_row3_whole_network_yolov3():
+    """yolov3 with the default variant (K1r on the 3x3 / stride-1 layers, K1x on the direct ones) against the same network
+    with the 2-D FP32 Winograd kernel: every materialised tensor within the FP32 contract, the same boxes, and fused ==
+    unfused bit for bit"""
+    name, width, height, batch = "yolov3", 160, 96, 2
+    cfg, wts = common.model_files(name, width, height)
+    x = common.seeded_input(batch, 3, height, width)
+    ref = Network.load(cfg, wts, batch, 0, device=0, fuse=True, variant=62 | 1024)
+    a = Network.load(cfg, wts, batch, 0, device=0, fuse=True)
+    b = Network.load(cfg, wts, batch, 0, device=0, fuse=False)
+    ref.predict(x); a.predict(x); b.predict(x)
+    kernels = [a.layer_kernel(i) for i in range(a.n)]
+    assert sum("conv_f32_row3<" in k for k in kernels) >= 30, kernels
+    assert not any("conv_f32_row3<" in ref.layer_kernel(i) for i in range(ref.n))
+    for i in range(a.n):
+        if not a.layer_materialised(i):
+            continue
+        ya, yb = a.layer_output(i), b.layer_output(i)
+        assert np.array_equal(ya.view(np.uint32), yb.view(np.uint32)), "fused vs unfused, layer %d" % i
+        if ref.layer_materialised(i):
+            ok, ratio, worst = fp32_close(ya, ref.layer_output(i))
+            assert ok, "layer %d (%s): err/allowed %.3g" % (i, kernels[i], ratio)
+    for im in range(batch):
+        ra, rr = a.get_boxes(im, width, height, 0.24, nms=0.4), ref.get_boxes(im, width, height, 0.24, nms=0.4)
+        assert ra.shape == rr.shape and np.allclose(ra, rr, rtol=1e-4, atol=1e-5)
+        assert np.array_equal(ra, b.get_boxes(im, width, height, 0.24, nms=0.4))
+    ref.close(); a.close(); b.close()

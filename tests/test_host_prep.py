@@ -176,6 +176,53 @@ def test_x3_weight_split_is_exact(C, M, size):
     assert np.all(np.abs(got[..., 1]) <= np.abs(got[..., 0]) * 2.0 ** -8 + 1e-45)      # each piece 8 bits below the one before
 
 
+@pytest.mark.parametrize("C,M", [(16, 33), (32, 128), (48, 70), (64, 255)])
+def test_row3_weight_transform_and_split_are_exact(C, M):
+    """conv_f32_row3.hip's weights: the row transform of every filter row, U0 = g0, U1 = (g0 + g1 + g2) / 2,
+    U2 = (g0 - g1 + g2) / 2, U3 = g2, formed in double and rounded ONCE to FP32, then as three bf16 numbers whose sum is U
+    exactly; the units sit where the kernel's lanes read them ([group = (c / 16) * 3 + ky][plane][piece][k-octet][filter][k]);
+    filters beyond M are zero.  And F(2,3) with these U reproduces the 3-tap correlation (float64 check of the algebra)."""
+    import ctypes as Cc
+    from yolo2_light_amd._lib import lib
+    rng = np.random.default_rng(C * 977 + M)
+    w = (rng.standard_normal((M, C, 3, 3)) * np.exp(rng.uniform(-4, 2, (M, C, 3, 3)))).astype(np.float32)
+    w[rng.random(w.shape) < 0.02] = 0.0
+    fp = Cc.POINTER(Cc.c_float)
+    assert lib.yl_debug_row3_pack(w.ctypes.data_as(fp), C + 1, M, None, 0) < 0               # C % 16 != 0: not this kernel's layer
+    need = lib.yl_debug_row3_pack(w.ctypes.data_as(fp), C, M, None, 0)
+    mpad = (M + 127) // 128 * 128
+    assert need == (C // 16) * 3 * 24 * mpad * 16
+    raw = np.full(need // 2, 0x7fc0, dtype=np.uint16)
+    assert lib.yl_debug_row3_pack(w.ctypes.data_as(fp), C, M, raw.ctypes.data_as(Cc.c_void_p), need) == need
+    units = raw.reshape(C // 16, 3, 4, 3, 2, mpad, 8)                # [channel block][ky][plane][piece][k-octet][filter][k]
+    assert not np.any(units[:, :, :, :, :, M:, :])                   # pad filters are zero
+    pieces = (units.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    # -> [m][c][ky][plane][piece]
+    got = pieces[:, :, :, :, :, :M, :].transpose(5, 0, 4, 6, 1, 2, 3).reshape(M, C, 3, 4, 3)
+    g = w.astype(np.float64)                                         # [m][c][ky][kx]
+    u64 = np.stack([g[..., 0], (.5 * g[..., 0] + .5 * g[..., 1]) + .5 * g[..., 2],
+                    (.5 * g[..., 0] - .5 * g[..., 1]) + .5 * g[..., 2], g[..., 2]], axis=-1)
+    u32 = u64.astype(np.float32)                                     # one rounding
+    assert np.array_equal(got.sum(axis=4), u32.astype(np.float64))   # a1 + a2 + a3 == U, exactly
+
+    def bf16_rne(x32):
+        u = x32.astype(np.float32).view(np.uint32).astype(np.uint64)
+        return (((u + 0x7fff + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+
+    r = u32.copy()
+    for pc in range(3):
+        h = bf16_rne(r)
+        assert np.array_equal(h.view(np.uint32), got[..., pc].astype(np.float32).view(np.uint32)), pc
+        r = (r - h).astype(np.float32)
+    # the algebra, in float64 with the un-rounded U: Y(2t) = M0 + M1 + M2, Y(2t+1) = M1 - M2 - M3
+    d = rng.standard_normal(4)
+    gg = g[0, 0, 0]
+    uu = u64[0, 0, 0]
+    v = np.array([d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]])
+    mm = uu * v
+    assert np.allclose([mm[0] + mm[1] + mm[2], mm[1] - mm[2] - mm[3]], [d[0:3] @ gg, d[1:4] @ gg], rtol=1e-12, atol=1e-12)
+
+
 @pytest.mark.skipif(not refbind.available(), reason="oracle/_ref not built")
 @pytest.mark.parametrize("name,width,height", [("yolov3", 64, 64), ("yolov3-tiny", 96, 96), ("yolov3-spp", 64, 64),
                                                ("yolov2-voc", 96, 96), ("tiny-yolo-voc", 96, 96)])

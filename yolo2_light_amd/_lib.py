@@ -118,6 +118,7 @@ _SIGS = {
     "yl_network_layer_tree": (C.c_int, [_vp, C.c_int, c_int_p, c_int_p]),
     "yl_debug_wino_pack": (C.c_longlong, [c_float_p, C.c_int, C.c_int, C.c_int, c_float_p, C.c_longlong]),
     "yl_debug_x3_pack": (C.c_longlong, [c_float_p, C.c_int, C.c_int, C.c_int, _vp, C.c_longlong]),
+    "yl_debug_row3_pack": (C.c_longlong, [c_float_p, C.c_int, C.c_int, _vp, C.c_longlong]),
     "yl_network_compact_detections": (C.c_int, [_vp, C.c_float, C.c_int, _vp, _vp]),
     "yl_network_detect_batch": (C.c_int, [_vp, c_int_p, c_int_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,
                                           _vp, _vp]),

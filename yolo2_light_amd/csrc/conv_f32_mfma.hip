@@ -548,8 +548,13 @@ bool conv_f32_pool_fusable(const ConvF32Args &a0, const ConvF32Opts &o)
 
 // Kernel choice for one FP32 convolution.  o.force_tile: 0 = heuristic, 11..22 = direct tile
 // 1..12 of launch_conv_f32_direct, 31 = Winograd (error if the layer has no packed U).
-int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, char *name, size_t name_len)
+int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o_in, void *stream, char *name, size_t name_len)
 {
+    // force_tile 61..69 picks the tile / schedule of K1r WHERE a layer qualifies for it; every other layer of the network
+    // keeps the heuristic (a whole network can be swept with one setting)
+    ConvF32Opts o = o_in;
+    int row3_tile = 0;
+    if (o.force_tile >= 61 && o.force_tile <= 69) { row3_tile = o.force_tile - 60; o.force_tile = 0; }
     // measured on MI355X (tools/sweep_conv.py, yolov3-608 shapes, B=64): with 32 input channels
     // ([64,288,92416]) Winograd wins stand-alone (1.59 vs 2.16 ms) but not in the network, where the
     // layer carries a fused shortcut and is bound by 3 GB of epilogue traffic (2.31 vs 2.2 ms): C >= 64.
@@ -567,6 +572,11 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o, void *stream, ch
     //  layer is bound by its tensors and the split's extra instructions only cost; profiles/r4_x3_per_layer.txt)
     const bool wino_takes = a.wino32_u && (o.force_tile == 31 || (o.force_tile == 0 && o.winograd &&
         a.C >= ((o.variant & 32) ? 16 : ((o.variant & 16) ? 32 : 64)) && wino32_fits(a.B, a.M, a.H, a.W)));
+    // K1r: the 3x3 / stride-1 layers as row-wise Winograd F(2,3) on the BF16 matrix pipe with three-piece operands (variant bit
+    // 11; force_tile 61..69 = its tiles); the layers with a pooled output keep the 2-D Winograd kernel (an F(2x2) tile is a window)
+    if (a.row3_w && a.in_front_pad && !a.pool_out && !a.q_out && !a.bits_out && a.yolo_entries == 0 && (a.out || a.add) && o.force_tile == 0 &&
+        ((wino_takes && (o.variant & 2048)) || row3_tile))
+        return launch_conv_f32_row3(a, row3_tile, stream, name, name_len);
     if (!wino_takes && a.x3_w && (a.out || a.add) && !a.q_out && !a.pool_out && !a.bits_out && (a.yolo_entries == 0 || (a.size == 1 && !a.add)) &&
         ((o.force_tile == 0 && (o.variant & 1024) && a.M > 32) || (o.force_tile >= 51 && o.force_tile <= 53)))
         return launch_conv_f32_x3(a, o.force_tile >= 51 ? o.force_tile - 50 : 0, stream, name, name_len);

@@ -1,0 +1,573 @@
+// conv_f32_row3.hip -- K1r: the 3x3 / stride-1 / pad-1 FP32 convolution as ROW-WISE Winograd F(2,3) on the BF16 matrix
+// pipe, every operand the exact sum of three bf16 pieces.
+//
+// Same layer as conv_f32_wino32.hip and conv_f32_x3.hip (forward_convolutional_layer_cpu's FP32 branch,
+// src/yolov2_forward_network.c:204-261: im2col + gemm_nn + bias + leaky; gemm_nn src/additionally.c:1272-1286), FP32
+// tensors in and out.  conv_f32_wino32.hip runs F(2x2,3x3) on v_mfma_f32_32x32x2_f32, which shares the FP32 vector
+// datapath with every VALU instruction on the SIMD and stalls near 0.64 of its peak; conv_f32_x3.hip moved the direct
+// layers to v_mfma_f32_32x32x16_bf16 with three-piece operands (6 MFMAs per 16 k, FP32-class accuracy), but six BF16
+// MFMAs per 16 k and tap do not beat 8 / 2.25 FP32 ones, and F(2x2,3x3) with three-piece operands does not fit the LDS
+// (16 planes x 3 pieces).  The ONE-dimensional transform does: for an output row oy and a pair of output columns
+// (2t, 2t+1), with d0..d3 = the input row iy = oy + ky - 1 at columns 2t-1 .. 2t+2 and g0..g2 = the filter row ky,
+//
+//     V0 = d0 - d2    V1 = d1 + d2          V2 = d2 - d1          V3 = d1 - d3          (FP32, one rounding each)
+//     U0 = g0         U1 = (g0+g1+g2)/2     U2 = (g0-g1+g2)/2     U3 = g2               (double, rounded once)
+//     M[xi] = sum over (c, ky) of U[xi] * V[xi]                                         (four GEMMs with K = 3 C)
+//     Y(2t) = M0 + M1 + M2        Y(2t+1) = M1 - M2 - M3
+//
+// 4 multiplies per 2 outputs and (c, ky) instead of 6: with U and V split into three bf16 pieces each that is
+// 6 / 1.5 = 4 BF16 MFMAs per 16 k and tap triple -- 136 matrix-pipe cycles where FP32 F(2x2,3x3) needs 228 and K1x 204.
+// Accuracy: the transforms only add and subtract (U's halves are formed in double), the split is exact, the dropped
+// cross terms a2 b3 + a3 b2 + a3 b3 are <= 2^-26 |a b| (conv_f32_x3.hip); checked against the oracle and against a
+// float64 convolution like the other FP32 kernels (tests/test_gpu_parity.py).
+//
+//   tiles        n = (b * H + oy) * TW + tx, TW = ceil(W / 2); a workgroup owns BM filters x BT consecutive tiles x 4 planes
+//   K order      groups g = (channel block c / 16, ky); a panel = PP planes of one group (PP = 2: two panels per group)
+//   weights      wr[group][plane 4][piece 3][k-octet 2][Mpad][8] bf16 (row3_pack_weights / pack_row3_kernel)
+//   LDS stage    A[plane][piece][k-octet][BM], B[plane][piece][k-octet][BT] 16-byte units, two stages
+//   staging      a thread owns one tile and FOUR channels of every group: four 16-byte row loads (columns 2t-1 .. 2t+2;
+//                the row above / below the image through the buffer range check, the columns left / right of it by
+//                selects), V for the four planes, three-piece split (conv_f32_x3.hip's), one ds_write_b64 per plane and
+//                piece; lane pairs write the two halves of a unit, a wave 512 contiguous bytes
+//   waves        wave (wm, wn) owns TM x TN blocks of 32 filters x 32 tiles for ALL four planes: the output transform is
+//                lane-local (no LDS exchange)
+//   epilogue     MFMA C/D layout: Y pairs as 8-byte stores (32 lanes = 256 contiguous bytes per filter row); + bias, leaky
+//                with conv_f32_mfma.hip's arithmetic, fused [shortcut]
+//
+// Applicability: size 3, stride 1, pad 1, C % 16 == 0, the input tensor library-owned (front pad: the left-edge tile of
+// the first row reads one float in front of the tensor, multiplied out by a select).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <type_traits>
+
+#include "kernels.h"
+#include "../../include/yolo2_hip.h"
+
+namespace yl {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+inline uint16_t bf16_rne_host(float f)
+{
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+inline float bf16_to_float_host(uint16_t h)
+{
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+struct ConvRow3Dev {
+    const float *in;
+    const void *wr;
+    const float *bias;
+    const float *add;       // fused [shortcut]: out_add = act(conv) + add (nullptr = none)
+    float *out_add;
+    float *out;             // may be nullptr when only out_add is wanted
+    int B, C, H, W, M, Mpad;
+    int TW;                 // tiles per image row
+    int HTW;                // tiles per image
+    int Ntiles;             // B * HTW
+    int G;                  // groups = 3 * C / 16
+    int act;
+    int tiles_m;
+};
+
+// two FP32 values -> their three bf16 pieces, packed (low half = x); conv_f32_x3.hip's split
+__device__ __forceinline__ void split3_pair(float x, float y, unsigned &p1, unsigned &p2, unsigned &p3)
+{
+    const f32x2 v = {x, y};
+    p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));          // v_cvt_pk_bf16_f32: RNE
+    const float x1 = __uint_as_float(p1 << 16), y1 = __uint_as_float(p1 & 0xFFFF0000u);
+    const f32x2 r = {x - x1, y - y1};                                               // exact
+    p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+    const float x2 = __uint_as_float(p2 << 16), y2 = __uint_as_float(p2 & 0xFFFF0000u);
+    const f32x2 q = {r[0] - x2, r[1] - y2};                                         // exact
+    p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2));
+}
+
+// BM x BT: filters x tiles of a workgroup; WM x WN waves, each TM x TN blocks of 32 x 32 for all four planes;
+// PP: planes per LDS panel (1 or 2); MFULL: M % BM == 0; WEVEN: W even (Y pairs are 8-byte aligned and always whole)
+// SCHED 0: one barrier at the end of a panel, the fragments of a panel are read after it (conv_f32_x3.hip's loop)
+// SCHED 1 (PP = 2): the barrier sits BETWEEN the two planes of a panel -- first plane: its MFMAs run from fragments that are
+//         already in registers while the next panel is split into the other stage and the second plane's fragments are
+//         read; barrier; second plane: its MFMAs cover the reads of the NEXT panel's first-plane fragments.  No LDS
+//         latency stands in front of an MFMA block, and no wave waits at the barrier with an idle matrix pipe behind it.
+template <int BM, int BT, int WM, int WN, int PP, bool MFULL, bool WEVEN, int SCHED>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) ? 3 : 2) void conv_f32_row3_kernel(ConvRow3Dev p)
+{
+    static_assert(SCHED == 0 || PP == 2, "the mid-panel barrier needs two planes per panel");
+    constexpr int NT = WM * WN * 64;
+    static_assert(NT == 4 * BT, "one thread per (tile, channel quad)");
+    static_assert(PP == 1 || PP == 2, "planes per panel");
+    constexpr int TM = BM / (WM * 32);
+    constexpr int TN = BT / (WN * 32);
+    constexpr int NIT = 4 / PP;                          // panels (loop iterations) per group
+    constexpr int STAGE_A = PP * 6 * BM;                 // 16-byte units
+    constexpr int STAGE_B = PP * 6 * BT;
+    constexpr int APT = (STAGE_A + NT - 1) / NT;
+    constexpr bool A_FULL = (STAGE_A % NT) == 0;
+    static_assert(NT % BM == 0, "A panel mapping");
+    constexpr int A_STEP = NT / BM;                      // (plane, piece, k-octet) rows one pass of the threads covers
+
+    __shared__ __attribute__((aligned(16))) uint4 smem[2 * STAGE_A + 2 * STAGE_B + BM / 4];
+    uint4 *As = smem;
+    uint4 *Bs = smem + 2 * STAGE_A;
+    float *bias_s = reinterpret_cast<float *>(smem + 2 * STAGE_A + 2 * STAGE_B);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+
+    // XCD-aware tile order (blocks b, b+8, ... share an L2): consecutive logical tiles = the filter tiles of one tile range
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int tile_n = __builtin_amdgcn_readfirstlane(logical / p.tiles_m);
+    const int tile_m = logical - tile_n * p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BT;
+
+    if (tid < BM) bias_s[tid] = (m0 + tid < p.M) ? p.bias[m0 + tid] : 0.f;
+
+    // ---- staging role: tile s_tile, channels 4 q .. 4 q + 3 of every group; lane pairs = the two halves of a 16-byte unit ----
+    constexpr int TWAVES = BT / 32;                      // waves along the tiles
+    const int s_tile = (wave % TWAVES) * 32 + (lane >> 1);
+    const int s_oct = wave / TWAVES;                     // k-octet (wave-uniform)
+    const int s_qlo = lane & 1;
+    const int s_q = s_oct * 2 + s_qlo;
+    const int HW = p.H * p.W;
+    const int n_g = n0 + s_tile;
+    const bool n_ok = n_g < p.Ntiles;
+    const int bimg = n_ok ? n_g / p.HTW : 0;
+    const int trem = n_g - bimg * p.HTW;
+    const int oy = trem / p.TW;
+    const int tx = trem - oy * p.TW;
+    const bool cm0 = tx > 0, cm2 = 2 * tx + 1 < p.W, cm3 = 2 * tx + 2 < p.W;
+
+    // buffer descriptor over the input, based at the first image of this workgroup's tiles and shifted back by W + 1 elements:
+    // lane offset (oy * W + 2 tx) = row oy - 1, column 2 tx - 1; rows outside the image -> voffset 0xFFFFFFFF -> 0.0
+    const int b_first = __builtin_amdgcn_readfirstlane(n0 / p.HTW);
+    const size_t img_floats = (size_t)p.C * HW;
+    const float *tile_base = p.in + (size_t)b_first * img_floats - (ptrdiff_t)(p.W + 1);
+    size_t rec = (((size_t)p.B - b_first) * img_floats + (size_t)(p.W + 1)) * sizeof(float);
+    if (rec > 0xFFFFFFFEull) rec = 0xFFFFFFFEull;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)tile_base, 0, (int)(unsigned)rec, 0x00020000);
+    const int voff = (int)(((unsigned)(bimg - b_first) * (unsigned)img_floats + (unsigned)(s_q * 4) * (unsigned)HW +
+                            (unsigned)oy * (unsigned)p.W + (unsigned)(2 * tx)) * 4u);
+    unsigned nrowmask = 7u;                   // inverted row validity, bit ky
+    if (n_ok) {
+        unsigned m = 0;
+        for (int ky = 0; ky < 3; ++ky)
+            if (oy + ky - 1 >= 0 && oy + ky - 1 < p.H) m |= 1u << ky;
+        nrowmask = ~m;
+    }
+
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.wr, 0, (int)((unsigned)p.G * 24u * (unsigned)p.Mpad * 16u), 0x00020000);
+    const int a_voff = ((tid / BM) * p.Mpad + (tid % BM)) * 16;
+    const int b_lds = s_oct * BT * 16 + s_tile * 16 + s_qlo * 8;        // byte offset inside a (plane, piece) slab of a B stage
+
+    v4i a_reg[APT];
+    f32x4 raw[4];
+    float V[4][4];                            // [plane][channel of the quad]
+    int ld_ky = 0, ld_c0 = 0;                 // group of the NEXT raw load
+
+    // (always issued: past the last group the lane offsets are all-ones and the range check answers without touching memory)
+    auto load_raw = [&]() {
+        const int soff = (ld_c0 * HW + ld_ky * p.W) * 4;
+        const int tinv = __builtin_amdgcn_sbfe((int)nrowmask, ld_ky, 1) | (ld_c0 < p.C ? 0 : -1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff | tinv, soff + i * HW * 4, 0));
+        ++ld_ky;
+        if (ld_ky == 3) { ld_ky = 0; ld_c0 += 16; }
+    };
+    auto transform = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float d0 = cm0 ? raw[i][0] : 0.f, d1 = raw[i][1], d2 = cm2 ? raw[i][2] : 0.f, d3 = cm3 ? raw[i][3] : 0.f;
+            V[0][i] = d0 - d2;
+            V[1][i] = d1 + d2;
+            V[2][i] = d2 - d1;
+            V[3][i] = d1 - d3;
+        }
+    };
+    // planes xi0 .. xi0 + PP - 1 of V -> three pieces -> B stage `buf`
+    auto store_b = [&](int buf, int xi0) {
+#pragma unroll
+        for (int pl = 0; pl < PP; ++pl) {
+            unsigned a1, a2, a3, c1, c2, c3;
+            split3_pair(V[xi0 + pl][0], V[xi0 + pl][1], a1, a2, a3);
+            split3_pair(V[xi0 + pl][2], V[xi0 + pl][3], c1, c2, c3);
+            char *dst = reinterpret_cast<char *>(Bs + buf * STAGE_B + pl * 6 * BT) + b_lds;
+            *reinterpret_cast<uint2 *>(dst + 0 * 2 * BT * 16) = make_uint2(a1, c1);
+            *reinterpret_cast<uint2 *>(dst + 1 * 2 * BT * 16) = make_uint2(a2, c2);
+            *reinterpret_cast<uint2 *>(dst + 2 * 2 * BT * 16) = make_uint2(a3, c3);
+        }
+    };
+    // A panel `it` (= group * NIT + panel of the group): rows (plane, piece, k-octet) x BM filters
+    auto load_a = [&](int it) {
+#pragma unroll
+        for (int e = 0; e < APT; ++e)
+            if (A_FULL || tid + e * NT < STAGE_A)
+                a_reg[e] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(
+                    rs_w, a_voff, ((it * PP * 6 + e * A_STEP) * p.Mpad + m0) * 16, 0));
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < APT; ++e) {
+            const int idx = tid + e * NT;
+            if (A_FULL || idx < STAGE_A) As[buf * STAGE_A + idx] = __builtin_bit_cast(uint4, a_reg[e]);
+        }
+    };
+
+    f32x16 acc[4][TM][TN];
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[xi][i][j][e] = 0.f;
+
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int wm0 = wm * TM * 32, wn0 = wn * TN * 32;
+    const int G = p.G;
+
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0};          // pieces of the six products, smallest terms first
+    constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
+    struct Frags { v4i a[3][TM], b[3][TN]; };
+    // fragments of plane `pl` (of the panel) from stage `buf`
+    auto read_frags = [&](Frags &f, int buf, int pl) {
+        int a_off = buf * STAGE_A + half * BM + wm0 + l31;
+        int b_off = buf * STAGE_B + half * BT + wn0 + l31;
+        asm volatile("" : "+v"(a_off), "+v"(b_off));           // one base register each, immediate offsets below
+        const uint4 *Ab = As + a_off;
+        const uint4 *Bb = Bs + b_off;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) f.a[pc][i] = __builtin_bit_cast(v4i, Ab[(pl * 3 + pc) * 2 * BM + i * 32]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) f.b[pc][j] = __builtin_bit_cast(v4i, Bb[(pl * 3 + pc) * 2 * BT + j * 32]);
+        }
+    };
+    auto mfma_plane = [&](const Frags &f, int xi) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[xi][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, f.a[TA[t]][i]), __builtin_bit_cast(bf16x8, f.b[TB[t]][j]), acc[xi][i][j], 0, 0, 0);
+    };
+
+    // ---- prologue: group 0 -> V, its first panel -> LDS[0]; group 1 requested; A panel 1 -> registers ----
+    load_a(0);
+    load_raw();
+    transform();
+    load_raw();                               // group 1 (G >= 3)
+    store_a(0);
+    store_b(0, 0);
+    load_a(1);
+    __syncthreads();
+
+    int g = 0;
+    if constexpr (SCHED == 0) {
+        // One group = NIT panels.  Panel h of group g (iteration it = g * NIT + h) computes from LDS[h & 1] while the NEXT panel
+        // (h + 1 of g, or panel 0 of g + 1 -- then V is re-formed from the raw rows requested one group earlier, and the rows of
+        // group g + 2 are requested) is split into LDS[(h + 1) & 1] and the A panel after that travels to registers.
+#define ROW3_GROUP(LAST)                                                                           \
+        _Pragma("unroll") for (int h = 0; h < NIT; ++h) {                                          \
+            const int it = g * NIT + h;                                                            \
+            if (h + 1 < NIT) {                                                                     \
+                store_a((h + 1) & 1);                                                              \
+                store_b((h + 1) & 1, (h + 1) * PP);                                                \
+                if (!(LAST) || h + 2 < NIT) load_a(it + 2);                                        \
+            } else if (!(LAST)) {                                                                  \
+                store_a(0);                                                                        \
+                transform();                                                                       \
+                load_raw();                                                                        \
+                store_b(0, 0);                                                                     \
+                load_a(it + 2);                                                                    \
+            }                                                                                      \
+            _Pragma("unroll") for (int pl = 0; pl < PP; ++pl) {                                    \
+                Frags f;                                                                           \
+                read_frags(f, h & 1, pl);                                                          \
+                mfma_plane(f, h * PP + pl);                                                        \
+            }                                                                                      \
+            if (!(LAST) || h + 1 < NIT) __syncthreads();                                           \
+        }
+        for (; g + 1 < G; ++g) { ROW3_GROUP(false) }
+        { ROW3_GROUP(true) }
+#undef ROW3_GROUP
+    } else {
+        // PP = 2: panel h of group g = planes 2 h, 2 h + 1, stage h.  f0 always holds the first-plane fragments of the panel
+        // about to be computed (read behind the previous panel's barrier, under its second plane's MFMAs).
+        Frags f0, f1;
+        read_frags(f0, 0, 0);
+#define ROW3_PANEL(H, LASTP, LOADA)                                                                \
+        {                                                                                          \
+            if (!(LASTP)) {                                                                        \
+                store_a(((H) + 1) & 1);                                                            \
+                if (LOADA) load_a(g * 2 + (H) + 2);                                                \
+                if ((H) == 1) transform();                                                         \
+                store_b(((H) + 1) & 1, (((H) + 1) & 1) * 2);                                       \
+            }                                                                                      \
+            read_frags(f1, (H), 1);                                                                \
+            mfma_plane(f0, (H) * 2);                                                               \
+            if (!(LASTP)) {                                                                        \
+                __syncthreads();                                                                   \
+                read_frags(f0, ((H) + 1) & 1, 0);                                                  \
+                if ((H) == 1) load_raw();                                                          \
+            }                                                                                      \
+            mfma_plane(f1, (H) * 2 + 1);                                                           \
+        }
+        for (; g + 1 < G; ++g) {
+            ROW3_PANEL(0, false, true)
+            ROW3_PANEL(1, false, true)
+        }
+        ROW3_PANEL(0, false, false)
+        ROW3_PANEL(1, true, false)
+#undef ROW3_PANEL
+    }
+
+    // ---- epilogue (C/D layout): Y(2t) = (M0 + M1) + M2, Y(2t+1) = (M1 - M2) - M3, + bias, activation, FP32 NCHW ----
+    const int ob_first = __builtin_amdgcn_readfirstlane((n0 + wn0) / p.HTW);
+    int voff_o[TN];
+    bool px1[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + l31;
+        const int ob = n / p.HTW;
+        const int orem = n - ob * p.HTW;
+        const int ooy = orem / p.TW;
+        const int otx = orem - ooy * p.TW;
+        voff_o[j] = n < p.Ntiles ? (int)(((unsigned)(ob - ob_first) * (unsigned)p.M * (unsigned)HW + (unsigned)ooy * (unsigned)p.W +
+                                          (unsigned)(2 * otx) + 4u * (unsigned)half * (unsigned)HW) * 4u) : -1;
+        px1[j] = WEVEN || (2 * otx + 1 < p.W);
+    }
+    const size_t img_out = (size_t)p.M * HW;
+    size_t orec = ((size_t)p.B - ob_first) * img_out * 4;
+    if (orec > 0xFFFFFFFEull) orec = 0xFFFFFFFEull;
+    const bool has_out = p.out != nullptr, has_add = p.add != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(has_out ? p.out + (size_t)ob_first * img_out : (float *)p.bias), 0, has_out ? (int)(unsigned)orec : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(has_add ? p.add + (size_t)ob_first * img_out : p.bias), 0, has_add ? (int)(unsigned)orec : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_oadd = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(has_add ? p.out_add + (size_t)ob_first * img_out : (float *)p.bias), 0, has_add ? (int)(unsigned)orec : 0, 0x00020000);
+    const int row_bytes = HW * 4;
+    const bool leaky = p.act == YL_LEAKY;
+    // one wave-uniform branch picks the output form; inside it the [shortcut] operand of a whole 32 x 32 block is requested
+    // before the block's arithmetic (MODE 0: out, 1: out_add only, 2: both)
+    auto epilogue = [&](auto mode_tag, auto leaky_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool LEAKY = decltype(leaky_tag)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float bias_r[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) bias_r[e] = bias_s[wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int e0 = 0; e0 < 16; e0 += 8) {         // eight accumulator rows at a time: their [shortcut] operands first
+                    int vo[8], vo1[8];
+                    f32x2 addv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int e = e0 + k;
+                        const int mrow = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2);
+                        const bool ok = MFULL || (mrow + 4 * half) < p.M;
+                        vo[k] = ok ? voff_o[j] : -1;
+                        vo1[k] = (ok && px1[j]) ? voff_o[j] + 4 : -1;
+                        if constexpr (MODE >= 1) {
+                            if constexpr (WEVEN)
+                                addv[k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_add, vo[k], mrow * row_bytes, 0));
+                            else {
+                                addv[k][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_add, vo[k], mrow * row_bytes, 0));
+                                addv[k][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_add, vo1[k], mrow * row_bytes, 0));
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int e = e0 + k;
+                        const float q0 = acc[0][i][j][e], q1 = acc[1][i][j][e], q2 = acc[2][i][j][e], q3 = acc[3][i][j][e];
+                        float y0 = ((q0 + q1) + q2) + bias_r[e];
+                        float y1 = ((q1 - q2) - q3) + bias_r[e];
+                        if constexpr (LEAKY) {
+                            // (float)(.1 * (double)x), conv_f32_mfma.hip's arithmetic, as three conversions / multiplies and a select:
+                            // left as a ternary hipcc branches around the double-precision path for every output
+                            float t0 = (float)(.1 * (double)y0), t1 = (float)(.1 * (double)y1);
+                            asm volatile("" : "+v"(t0), "+v"(t1));
+                            y0 = (y0 > 0.f) ? y0 : t0;
+                            y1 = (y1 > 0.f) ? y1 : t1;
+                        }
+                        const int mrow = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2);
+                        if constexpr (MODE != 1) {
+                            if constexpr (WEVEN) {
+                                const f32x2 y = {y0, y1};
+                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, y), rs_out, vo[k], mrow * row_bytes, 0);
+                            } else {
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y0), rs_out, vo[k], mrow * row_bytes, 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y1), rs_out, vo1[k], mrow * row_bytes, 0);
+                            }
+                        }
+                        if constexpr (MODE >= 1) {
+                            const float s0 = __fadd_rn(y0, addv[k][0]), s1 = __fadd_rn(y1, addv[k][1]);
+                            if constexpr (WEVEN) {
+                                const f32x2 y = {s0, s1};
+                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, y), rs_oadd, vo[k], mrow * row_bytes, 0);
+                            } else {
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s0), rs_oadd, vo[k], mrow * row_bytes, 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s1), rs_oadd, vo1[k], mrow * row_bytes, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+    if (leaky) {
+        if (!has_add) epilogue(std::integral_constant<int, 0>{}, std::true_type{});
+        else if (!has_out) epilogue(std::integral_constant<int, 1>{}, std::true_type{});
+        else epilogue(std::integral_constant<int, 2>{}, std::true_type{});
+    } else {
+        if (!has_add) epilogue(std::integral_constant<int, 0>{}, std::false_type{});
+        else if (!has_out) epilogue(std::integral_constant<int, 1>{}, std::false_type{});
+        else epilogue(std::integral_constant<int, 2>{}, std::false_type{});
+    }
+}
+
+template <int BM, int BT, int WM, int WN, int PP, int SCHED>
+int launch_row3_tile(ConvRow3Dev p, hipStream_t s)
+{
+    p.tiles_m = (p.M + BM - 1) / BM;
+    const long long blocks = (long long)p.tiles_m * ((p.Ntiles + BT - 1) / BT);
+    if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks), block(WM * WN * 64);
+    const bool mfull = (p.M % BM) == 0, weven = (p.W & 1) == 0;
+    if (mfull && weven) hipLaunchKernelGGL((conv_f32_row3_kernel<BM, BT, WM, WN, PP, true, true, SCHED>), grid, block, 0, s, p);
+    else if (mfull) hipLaunchKernelGGL((conv_f32_row3_kernel<BM, BT, WM, WN, PP, true, false, SCHED>), grid, block, 0, s, p);
+    else if (weven) hipLaunchKernelGGL((conv_f32_row3_kernel<BM, BT, WM, WN, PP, false, true, SCHED>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv_f32_row3_kernel<BM, BT, WM, WN, PP, false, false, SCHED>), grid, block, 0, s, p);
+    return (int)hipGetLastError();
+}
+
+constexpr int ROW3_MPAD = 128;        // the widest filter tile
+
+}  // namespace
+
+bool row3_applicable(int C, int M, int size, int stride, int pad)
+{
+    return C >= 16 && (C % 16) == 0 && M >= 1 && size == 3 && stride == 1 && pad == 1;
+}
+
+size_t row3_packed_bytes(int C, int M)
+{
+    const size_t mpad = (size_t)(M + ROW3_MPAD - 1) / ROW3_MPAD * ROW3_MPAD;
+    return (size_t)(C / 16) * 3 * 24 * mpad * 16;
+}
+
+// the four row-transform values of one filter row, formed in double and rounded once (pack_row3_kernel does the same)
+static inline void row3_u(const float *g, float u[4])
+{
+    const double g0 = g[0], g1 = g[1], g2 = g[2];
+    u[0] = g[0];
+    u[1] = (float)((.5 * g0 + .5 * g1) + .5 * g2);
+    u[2] = (float)((.5 * g0 - .5 * g1) + .5 * g2);
+    u[3] = g[2];
+}
+
+// w: [M][C][3][3] (the reference's l.weights).  dst: [group = (c / 16) * 3 + ky][plane 4][piece 3][k-octet 2][Mpad][8] bf16
+void row3_pack_weights(const float *w, int C, int M, void *dst)
+{
+    const size_t mpad = (size_t)(M + ROW3_MPAD - 1) / ROW3_MPAD * ROW3_MPAD;
+    uint16_t *d = static_cast<uint16_t *>(dst);
+    memset(d, 0, row3_packed_bytes(C, M));
+    for (int m = 0; m < M; ++m)
+        for (int c = 0; c < C; ++c)
+            for (int ky = 0; ky < 3; ++ky) {
+                float u[4];
+                row3_u(w + ((size_t)m * C + c) * 9 + ky * 3, u);
+                const size_t group = (size_t)(c / 16) * 3 + ky;
+                const int oct = (c % 16) / 8, e = c % 8;
+                for (int xi = 0; xi < 4; ++xi) {
+                    const float a = u[xi];
+                    const uint16_t h1 = bf16_rne_host(a);
+                    const float r1 = a - bf16_to_float_host(h1);
+                    const uint16_t h2 = bf16_rne_host(r1);
+                    const float r2 = r1 - bf16_to_float_host(h2);
+                    const uint16_t h3 = bf16_rne_host(r2);
+                    const uint16_t hs[3] = {h1, h2, h3};
+                    for (int pc = 0; pc < 3; ++pc)
+                        d[((((group * 4 + xi) * 3 + pc) * 2 + oct) * mpad + m) * 8 + e] = hs[pc];
+                }
+            }
+}
+
+// tile: 0 = heuristic; 1 = 128x128 tiles, 8 waves, mid-panel barrier; 2 = the same with the barrier at the panel's end;
+// 3 = 128x128, one plane per panel; 4 / 5 = 128x64, 4 waves (two workgroups per CU), mid-panel barrier / one plane per panel;
+// 6 / 7 = 64x128, 8 waves;
+// 8 / 9 = 64x64, 4 waves
+int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len)
+{
+    if (!a.row3_w || !row3_applicable(a.C, a.M, a.size, a.stride, a.pad) || a.OH != a.H || a.OW != a.W || !a.in_front_pad ||
+        (!a.out && !a.add) || (a.add && !a.out_add) || a.q_out || a.bits_out || a.pool_out || a.yolo_entries > 0)
+        return (int)hipErrorInvalidValue;
+    ConvRow3Dev d;
+    d.in = a.in; d.wr = a.row3_w; d.bias = a.bias; d.out = a.out; d.add = a.add; d.out_add = a.out_add;
+    d.B = a.B; d.C = a.C; d.H = a.H; d.W = a.W; d.M = a.M;
+    d.Mpad = (a.M + ROW3_MPAD - 1) / ROW3_MPAD * ROW3_MPAD;
+    d.TW = (a.W + 1) / 2;
+    d.HTW = a.H * d.TW;
+    d.G = (a.C / 16) * 3;
+    d.act = a.act;
+    const long long nt = (long long)a.B * d.HTW;
+    // lane offsets are 32-bit byte offsets from the first image of a workgroup's tiles: 128 tiles span 128 / HTW + 2 images
+    if (nt > 0x7fffffffLL || (long long)a.C * a.H * a.W * 4 * (128 / d.HTW + 2) >= 0xFFFFFFF0LL ||
+        (long long)a.M * a.H * a.W * 4 * (128 / d.HTW + 2) >= 0xFFFFFFF0LL)
+        return (int)hipErrorInvalidValue;
+    d.Ntiles = (int)nt;
+    d.tiles_m = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (tile == 0) tile = a.M <= 64 ? 6 : 1;
+    const char *t = "?";
+    int rc;
+    switch (tile) {
+    case 1: t = "128x128t,mid"; rc = launch_row3_tile<128, 128, 2, 4, 2, 1>(d, s); break;
+    case 2: t = "128x128t,end"; rc = launch_row3_tile<128, 128, 2, 4, 2, 0>(d, s); break;
+    case 3: t = "128x128t,pp1"; rc = launch_row3_tile<128, 128, 2, 4, 1, 0>(d, s); break;
+    case 4: t = "128x64t,mid"; rc = launch_row3_tile<128, 64, 2, 2, 2, 1>(d, s); break;
+    case 5: t = "128x64t,pp1"; rc = launch_row3_tile<128, 64, 2, 2, 1, 0>(d, s); break;
+    case 6: t = "64x128t,mid"; rc = launch_row3_tile<64, 128, 2, 4, 2, 1>(d, s); break;
+    case 7: t = "64x128t,end"; rc = launch_row3_tile<64, 128, 2, 4, 2, 0>(d, s); break;
+    case 8: t = "64x64t,mid"; rc = launch_row3_tile<64, 64, 2, 2, 2, 1>(d, s); break;
+    case 9: t = "64x64t,end"; rc = launch_row3_tile<64, 64, 2, 2, 2, 0>(d, s); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+    if (name) snprintf(name, name_len, "conv_f32_row3<%s>", t);
+    return rc;
+}
+
+}  // namespace yl

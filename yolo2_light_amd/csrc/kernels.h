@@ -14,7 +14,9 @@ namespace yl {
 // tile + 0.063 ms of [maxpool] -> 0.119 ms with the pooling folded into the Winograd epilogue; config 2 +7.8 %)
 // bit 10 (round 4): the direct FP32 layers on the BF16 matrix pipe with three-piece operands (K1x, conv_f32_x3.hip): +1.8 ... +7 %
 // on the step depending on the box (the kernel drives the chip into its power cap), same accuracy against float64
-constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8 | 16 | 32 | 1024;
+// bit 11 (round 5): the 3x3 / stride-1 layers as row-wise Winograd F(2,3) on the BF16 matrix pipe with three-piece operands (K1r,
+// conv_f32_row3.hip) instead of F(2x2,3x3) on the FP32 matrix instruction
+constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8 | 16 | 32 | 1024 | 2048;
 
 // ---- K1: FP32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 ----
 struct ConvF32Args {
@@ -41,6 +43,8 @@ struct ConvF32Args {
     int tapmajor;         // K order of `wt`: 0 = (c,ky,kx) like im2col_cpu, 1 = (ky,kx,c) (needs C % 16 == 0)
     const float *wino32_u; // Winograd-packed weights (wino32_pack_weights) or nullptr: 3x3/1/1 layers only
     const void *x3_w = nullptr; // the weights as three bf16 pieces (x3_pack_weights, conv_f32_x3.hip) or nullptr
+    const void *row3_w = nullptr; // 3x3 / 1 / 1 layers: the row-transformed weights U = G g as three bf16 pieces (row3_pack_weights,
+                          // conv_f32_row3.hip) or nullptr
     bool in_front_pad = false;     // `in` has >= 4 readable bytes in front of it holding a FINITE value (library-owned tensors:
                            // yl_internal.h ACT_FRONT_PAD); the Winograd kernel then fetches left-edge patches one column early
                            // and folds the column masks into the transform instead of shifting registers
@@ -50,7 +54,8 @@ struct ConvF32Args {
 // per-network kernel-selection knobs (snapshotted in Network: two networks driven from two host
 // threads, one per GPU, share no mutable launch state)
 struct ConvF32Opts {
-    int force_tile = 0;   // 0 = heuristic, 11..22 = direct tile 1..12, 31 = Winograd, 41 = small-K first-layer kernel (tuning / tests)
+    int force_tile = 0;   // 0 = heuristic, 11..22 = direct tile 1..12, 31 = Winograd, 41 = small-K first-layer kernel, 51..53 = K1x tiles,
+                          // 61..69 = K1r tiles (tuning / tests)
     int winograd = 1;     // Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 layers with C >= 64
     // schedule variants kept switchable for same-box A/B runs (yl_network_set_variant): bit 0 Winograd U panels by
     // LDS-DMA, bit 1 Winograd epilogue requests the [shortcut] operand ahead of its LDS exchange, bit 2 1x1 direct
@@ -77,6 +82,12 @@ bool x3_applicable(int C, int M, int size, int stride, int pad);
 size_t x3_packed_bytes(int C, int M, int size);
 void x3_pack_weights(const float *w, int C, int M, int size, void *dst);
 int launch_conv_f32_x3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len);
+// K1r (conv_f32_row3.hip): 3x3 / stride 1 / pad 1 as row-wise Winograd F(2,3) on the BF16 matrix pipe, three-piece operands
+bool row3_applicable(int C, int M, int size, int stride, int pad);
+size_t row3_packed_bytes(int C, int M);
+void row3_pack_weights(const float *w, int C, int M, void *dst);
+// tile: 0 = heuristic, 1..5 see conv_f32_row3.hip
+int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len);
 size_t wino32_packed_floats(int C, int M);
 void wino32_pack_weights(const float *w, int C, int M, float *dst);
 // K1s (conv_f32_smallk.hip): LDS-free kernel for first layers (C*size^2 <= 32, filters <= 32)

@@ -138,6 +138,40 @@ __global__ __launch_bounds__(256) void pack_x3_kernel(const float *__restrict__ 
     }
 }
 
+// K1r weights (conv_f32_row3.hip): the row transform U = G g of every filter row (U0 = g0, U1 = (g0 + g1 + g2) / 2,
+// U2 = (g0 - g1 + g2) / 2, U3 = g2; formed in double, rounded once) as three bf16 pieces,
+// wr[group = (c / 16) * 3 + ky][plane 4][piece 3][k-octet 2][Mpad][8] (pre-zeroed); the arithmetic of row3_pack_weights on the host
+__global__ __launch_bounds__(256) void pack_row3_kernel(const float *__restrict__ w, uint16_t *__restrict__ dst, int M, int C, int Mpad)
+{
+    const size_t total = (size_t)M * C * 3;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ky = (int)(idx % 3);
+        const int c = (int)((idx / 3) % C);
+        const int m = (int)(idx / ((size_t)3 * C));
+        const float *g = w + ((size_t)m * C + c) * 9 + ky * 3;
+        const double g0 = g[0], g1 = g[1], g2 = g[2];
+        float u[4];
+        u[0] = g[0];
+        u[1] = (float)__dadd_rn(__dadd_rn(__dmul_rn(.5, g0), __dmul_rn(.5, g1)), __dmul_rn(.5, g2));
+        u[2] = (float)__dadd_rn(__dsub_rn(__dmul_rn(.5, g0), __dmul_rn(.5, g1)), __dmul_rn(.5, g2));
+        u[3] = g[2];
+        const size_t group = (size_t)(c / 16) * 3 + ky;
+        const int oct = (c % 16) / 8, e = c % 8;
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            float r = u[xi];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                unsigned b = __float_as_uint(r);
+                b += 0x7fffu + ((b >> 16) & 1u);
+                const uint16_t h = (uint16_t)(b >> 16);
+                r = __fsub_rn(r, __uint_as_float((unsigned)h << 16));
+                dst[((((group * 4 + xi) * 3 + pc) * 2 + oct) * Mpad + m) * 8 + e] = h;
+            }
+        }
+    }
+}
+
 // XNOR sign words [Mpad/2][Cw][2][9] (pre-set to all ones: channel-pad bits and pad filters never match);
 // bit = (w > 0) (src/additionally.c:123,1544); one lane per (m, tap, channel word)
 __global__ __launch_bounds__(256) void pack_xnor_words_kernel(const float *__restrict__ w, uint64_t *__restrict__ dst, int M, int C, int Cw)
@@ -193,6 +227,13 @@ int dev_pack_x3(const float *d_w, void *d_dst, int M, int C, int taps, int Mpad,
 {
     hipLaunchKernelGGL(pack_x3_kernel, dim3(pack_blocks((size_t)M * C * taps)), dim3(256), 0, (hipStream_t)stream,
                        d_w, (uint16_t *)d_dst, M, C, taps, Mpad);
+    return (int)hipGetLastError();
+}
+
+int dev_pack_row3(const float *d_w, void *d_dst, int M, int C, int Mpad, void *stream)
+{
+    hipLaunchKernelGGL(pack_row3_kernel, dim3(pack_blocks((size_t)M * C * 3)), dim3(256), 0, (hipStream_t)stream,
+                       d_w, (uint16_t *)d_dst, M, C, Mpad);
     return (int)hipGetLastError();
 }
 

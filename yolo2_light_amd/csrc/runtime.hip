@@ -19,6 +19,7 @@
 
 #include "kernels.h"
 #include "yl_internal.h"
+#include "../../include/yolo2_hip_lab.h"
 
 namespace yl {
 
@@ -95,6 +96,8 @@ static void free_device(Network &net)
         l.d_wino32_u = nullptr;
         if (l.d_weights_x3) (void)hipFree(l.d_weights_x3);
         l.d_weights_x3 = nullptr;
+        if (l.d_weights_r3) (void)hipFree(l.d_weights_r3);
+        l.d_weights_r3 = nullptr;
         if (l.d_tile_ctr) (void)hipFree(l.d_tile_ctr);
         l.d_tile_ctr = nullptr;
         if (l.d_biases) (void)hipFree(l.d_biases);
@@ -251,6 +254,20 @@ static int upload_conv(Network &net, Layer &l)
                 YL_STAGE(stage_h2d(net.device, l.d_weights_x3, w3.data(), xb));
             }
         }
+        // 3x3 / stride 1 / pad 1: the row-transformed weights U = G g as three bf16 pieces for K1r (conv_f32_row3.hip)
+        if (wino && row3_applicable(l.c, M, l.size, l.stride, l.pad)) {
+            const size_t rb = row3_packed_bytes(l.c, M);
+            YL_HIP(hipMalloc(&l.d_weights_r3, rb));
+            l.packed_bytes[5] = rb;
+            if (net.device_pack) {
+                YL_HIP(hipMemsetAsync(l.d_weights_r3, 0, rb, (hipStream_t)s));
+                YL_LAUNCH(dev_pack_row3(reinterpret_cast<const float *>(net.d_pack_src), l.d_weights_r3, M, l.c, (int)(rb / ((size_t)(l.c / 16) * 3 * 24 * 16)), s), "pack_row3");
+            } else {
+                std::vector<unsigned char> wr(rb);
+                row3_pack_weights(l.weights.data(), l.c, M, wr.data());
+                YL_STAGE(stage_h2d(net.device, l.d_weights_r3, wr.data(), rb));
+            }
+        }
     } else if (l.conv_mode == CONV_INT8) {
         if (!l.quant_ready) { set_error("INT8 layer without yl_network_quantize()"); return YL_ERR_STATE; }
         // k-major panels of 16-byte units [K16pad][Mpad][16], K16 index = tap*G + cg, zero padded;
@@ -390,7 +407,7 @@ static int to_device(Network &net, int device)
     const size_t in_elems = (size_t)net.batch * net.c * net.h * net.w;
     // every activation tensor the library owns has ACT_FRONT_PAD readable floats in front of it: the Winograd kernel reads
     // ONE float before a tensor (column -1 of the first patch row of the first image, masked to zero in the transform)
-    YL_HIP(hipMalloc((void **)&net.d_input, (in_elems + ACT_FRONT_PAD) * sizeof(float)));
+    YL_HIP(hipMalloc((void **)&net.d_input, (in_elems + ACT_FRONT_PAD + ACT_TAIL_PAD) * sizeof(float)));
     YL_HIP(hipMemsetAsync(net.d_input, 0, ACT_FRONT_PAD * sizeof(float), (hipStream_t)net.stream));
     net.d_input += ACT_FRONT_PAD;
     net.pinned_bytes = in_elems * sizeof(float);
@@ -404,7 +421,7 @@ static int to_device(Network &net, int device)
             l.d_output_alias = true;
         } else {
             l.d_output_alias = false;
-            YL_HIP(hipMalloc((void **)&l.d_output, (out_elems + ACT_FRONT_PAD) * sizeof(float)));
+            YL_HIP(hipMalloc((void **)&l.d_output, (out_elems + ACT_FRONT_PAD + ACT_TAIL_PAD) * sizeof(float)));
             YL_HIP(hipMemsetAsync(l.d_output, 0, ACT_FRONT_PAD * sizeof(float), (hipStream_t)net.stream));      // finite: it is multiplied by 0
             l.d_output += ACT_FRONT_PAD;
         }
@@ -697,6 +714,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.tapmajor = l.tapmajor;
             a.wino32_u = l.d_wino32_u;
             a.x3_w = l.d_weights_x3;
+            a.row3_w = l.d_weights_r3;
             a.tile_ctr = l.d_tile_ctr;
             // the input tensor is library memory with the front pad (a caller's device pointer as the network input is not)
             a.in_front_pad = conv_in != net.d_binbuf && !(i == 0 && conv_in != net.d_input);
@@ -1530,7 +1548,7 @@ int yl_network_get_boxes(yl_network *net, int image, int w, int h, float thresh,
 int yl_network_set_conv_tile(yl_network *net, int cfg)
 {
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }
-    if (!(cfg == 0 || (cfg >= 11 && cfg <= 22) || cfg == 31 || cfg == 41 || (cfg >= 51 && cfg <= 53))) { set_error("unknown tile id"); return YL_ERR_ARG; }
+    if (!(cfg == 0 || (cfg >= 11 && cfg <= 22) || cfg == 31 || cfg == 41 || (cfg >= 51 && cfg <= 53) || (cfg >= 61 && cfg <= 69))) { set_error("unknown tile id"); return YL_ERR_ARG; }
     net->net.conv_opts.force_tile = cfg;
     return YL_OK;
 }
@@ -1538,7 +1556,7 @@ int yl_network_set_conv_tile(yl_network *net, int cfg)
 int yl_network_set_variant(yl_network *net, int bits)
 {
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }
-    if (bits < -1 || bits > 2047) { set_error("unknown variant bits"); return YL_ERR_ARG; }
+    if (bits < -1 || bits > 4095) { set_error("unknown variant bits"); return YL_ERR_ARG; }
     net->net.conv_opts.variant = bits < 0 ? YL_VARIANT_DEFAULT : bits;
     return YL_OK;
 }
@@ -1579,7 +1597,7 @@ int yl_network_set_device_pack(yl_network *net, int on)
 long long yl_debug_layer_packed(yl_network *net, int i, int which, void *dst_host, long long dst_bytes)
 {
     YL_LAYER_OR(YL_ERR_ARG)
-    if (!net->net.on_device || which < 0 || which > 7) { set_error("bad argument / not on device"); return YL_ERR_STATE; }
+    if (!net->net.on_device || which < 0 || which > 8) { set_error("bad argument / not on device"); return YL_ERR_STATE; }
     const void *src = nullptr;
     long long need = 0;
     if (which <= 3) {
@@ -1589,6 +1607,9 @@ long long yl_debug_layer_packed(yl_network *net, int i, int which, void *dst_hos
     } else if (which == 7) {                                  // K1x: the weights as three bf16 pieces
         src = l.d_weights_x3;
         need = src ? (long long)l.packed_bytes[4] : 0;
+    } else if (which == 8) {                                  // K1r: the row-transformed weights as three bf16 pieces
+        src = l.d_weights_r3;
+        need = src ? (long long)l.packed_bytes[5] : 0;
     } else if (l.type == YL_CONVOLUTIONAL && l.d_thr) {       // XNOR layers: thresholds (+ the not-a-step count), mean, bias
         src = which == 4 ? (const void *)l.d_thr : which == 5 ? (const void *)l.d_mean : (const void *)l.d_biases;
         need = which == 4 ? (long long)sizeof(int) * (l.Mpad + 1) : (long long)sizeof(float) * l.n;
@@ -1659,6 +1680,16 @@ long long yl_debug_x3_pack(const float *weights, int c, int m, int size, void *d
     if (!dst) return (long long)need;
     if (dst_bytes < (long long)need) { set_error("dst too small"); return YL_ERR_ARG; }
     x3_pack_weights(weights, c, m, size, dst);
+    return (long long)need;
+}
+
+long long yl_debug_row3_pack(const float *weights, int c, int m, void *dst, long long dst_bytes)
+{
+    if (!weights || m <= 0 || !row3_applicable(c, m, 3, 1, 1)) { set_error("bad argument"); return YL_ERR_ARG; }
+    const size_t need = row3_packed_bytes(c, m);
+    if (!dst) return (long long)need;
+    if (dst_bytes < (long long)need) { set_error("dst too small"); return YL_ERR_ARG; }
+    row3_pack_weights(weights, c, m, dst);
     return (long long)need;
 }
 

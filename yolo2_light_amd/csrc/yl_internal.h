@@ -17,6 +17,8 @@ enum ConvMode { CONV_F32 = 0, CONV_INT8 = 1, CONV_XNOR = 2, CONV_BF16 = 3 };
 enum HostKind { HOST_NONE = 0, HOST_CALLER = 1, HOST_PINNED = 2 };
 
 constexpr int ACT_FRONT_PAD = 64;      // floats (256 B) of readable, zeroed memory in front of every library-owned activation tensor
+constexpr int ACT_TAIL_PAD = 16;       // floats of readable memory behind it: the 16-byte row loads of the Winograd kernels end up to two
+                                       // columns beyond the last row of the last image (selected away, but the bytes must be mapped)
 
 struct Layer {
     int type = YL_BLANK;
@@ -62,8 +64,9 @@ struct Layer {
     int   tapmajor = 0;                  // K order of d_weights_t (see conv_f32_mfma.hip)
     float *d_wino32_u = nullptr;         // FP32 3x3/1/1: Winograd-packed U (conv_f32_wino32.hip), else nullptr
     void *d_weights_x3 = nullptr;        // FP32, C % 16 == 0: the weights as three bf16 pieces (conv_f32_x3.hip), else nullptr
+    void *d_weights_r3 = nullptr;        // FP32 3x3/1/1, C % 16 == 0: the row-transformed weights as three bf16 pieces (conv_f32_row3.hip), else nullptr
     unsigned *d_tile_ctr = nullptr;      //       8 work counters (one per XCD) of the persistent Winograd form, zero between launches
-    size_t packed_bytes[5] = {0, 0, 0, 0, 0};   // bytes of d_weights_t, d_wino32_u, d_weights_i8, d_weights_bits, d_weights_x3 (yl_debug_layer_packed)
+    size_t packed_bytes[6] = {0, 0, 0, 0, 0, 0};   // bytes of d_weights_t, d_wino32_u, d_weights_i8, d_weights_bits, d_weights_x3, d_weights_r3 (yl_debug_layer_packed)
     int8_t *d_weights_i8 = nullptr;      // INT8: [K16pad][Mpad][16] int8 units; BF16: [K8pad][Mpad][8] bf16 units
     int   Cpad = 0;                      // channels of the 16-byte-unit activation tensor (INT8: 16 per unit, BF16: 8)
     float bias_abs_max = 0.f;            // INT8: max |bias| and the smallest non-zero |bias| (-1 = a bias is not finite):
@@ -179,6 +182,7 @@ int dev_pack_wino(const float *d_w, float *d_dst, int C, int M, void *stream);
 int dev_pack_i8_units(const int8_t *d_wq, int8_t *d_dst, int M, int C, int taps, int G, int Mpad, void *stream);
 int dev_pack_bf16_units(const float *d_w, uint16_t *d_dst, int M, int C, int taps, int G, int Mpad, void *stream);
 int dev_pack_x3(const float *d_w, void *d_dst, int M, int C, int taps, int Mpad, void *stream);
+int dev_pack_row3(const float *d_w, void *d_dst, int M, int C, int Mpad, void *stream);
 int dev_pack_xnor_words(const float *d_w, uint64_t *d_dst, int M, int C, int Cw, void *stream);
 // host_calib.cpp
 float entropy_from_counts(const uint32_t *counts, int max_bin, float bin_width);
