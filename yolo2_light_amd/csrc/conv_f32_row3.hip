@@ -44,6 +44,13 @@
 #include "kernels.h"
 #include "../../include/yolo2_hip.h"
 
+// Lab builds only (tools/ab_builds.sh, ABFILE=conv_f32_row3: -DX_DBG=<bits>; results are garbage by design): 1 no global loads in
+// the K loop, 2 no split / B stores, 4 no A stores, 8 no MFMAs, 16 no fragment reads, 32 no epilogue stores, 64 no barriers in
+// the K loop.  The shipped library is built with X_DBG undefined: every guard below folds away.
+#ifndef X_DBG
+#define X_DBG 0
+#endif
+
 namespace yl {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -186,10 +193,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
     v4i a_reg[APT];
     f32x4 raw[4];
     float V[4][4];                            // [plane][channel of the quad]
+    if constexpr (X_DBG != 0) {               // lab builds skip producers: give every consumer a defined value
+#pragma unroll
+        for (int e = 0; e < APT; ++e) a_reg[e] = v4i{0x3f803f80, 0x3f803f80, 0x3f803f80, 0x3f803f80};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) raw[i] = f32x4{1.f, 2.f, 3.f, 4.f};
+    }
     int ld_ky = 0, ld_c0 = 0;                 // group of the NEXT raw load
 
     // (always issued: past the last group the lane offsets are all-ones and the range check answers without touching memory)
     auto load_raw = [&]() {
+        if constexpr ((X_DBG & 1) != 0) return;
         const int soff = (ld_c0 * HW + ld_ky * p.W) * 4;
         const int tinv = __builtin_amdgcn_sbfe((int)nrowmask, ld_ky, 1) | (ld_c0 < p.C ? 0 : -1);
 #pragma unroll
@@ -210,6 +224,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
     };
     // planes xi0 .. xi0 + PP - 1 of V -> three pieces -> B stage `buf`
     auto store_b = [&](int buf, int xi0) {
+        if constexpr ((X_DBG & 2) != 0) return;
 #pragma unroll
         for (int pl = 0; pl < PP; ++pl) {
             unsigned a1, a2, a3, c1, c2, c3;
@@ -223,6 +238,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
     };
     // A panel `it` (= group * NIT + panel of the group): rows (plane, piece, k-octet) x BM filters
     auto load_a = [&](int it) {
+        if constexpr ((X_DBG & 1) != 0) return;
 #pragma unroll
         for (int e = 0; e < APT; ++e)
             if (A_FULL || tid + e * NT < STAGE_A)
@@ -230,6 +246,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
                     rs_w, a_voff, ((it * PP * 6 + e * A_STEP) * p.Mpad + m0) * 16, 0));
     };
     auto store_a = [&](int buf) {
+        if constexpr ((X_DBG & 4) != 0) return;
 #pragma unroll
         for (int e = 0; e < APT; ++e) {
             const int idx = tid + e * NT;
@@ -256,6 +273,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
     struct Frags { v4i a[3][TM], b[3][TN]; };
     // fragments of plane `pl` (of the panel) from stage `buf`
     auto read_frags = [&](Frags &f, int buf, int pl) {
+        if constexpr ((X_DBG & 16) != 0) return;
         int a_off = buf * STAGE_A + half * BM + wm0 + l31;
         int b_off = buf * STAGE_B + half * BT + wn0 + l31;
         asm volatile("" : "+v"(a_off), "+v"(b_off));           // one base register each, immediate offsets below
@@ -270,6 +288,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
         }
     };
     auto mfma_plane = [&](const Frags &f, int xi) {
+        if constexpr ((X_DBG & 8) != 0) return;
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
@@ -311,10 +330,11 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
             }                                                                                      \
             _Pragma("unroll") for (int pl = 0; pl < PP; ++pl) {                                    \
                 Frags f;                                                                           \
+                if constexpr ((X_DBG & 16) != 0) memset(&f, 0x3f, sizeof(f));                      \
                 read_frags(f, h & 1, pl);                                                          \
                 mfma_plane(f, h * PP + pl);                                                        \
             }                                                                                      \
-            if (!(LAST) || h + 1 < NIT) __syncthreads();                                           \
+            if ((X_DBG & 64) == 0 && (!(LAST) || h + 1 < NIT)) __syncthreads();                    \
         }
         for (; g + 1 < G; ++g) { ROW3_GROUP(false) }
         { ROW3_GROUP(true) }
@@ -323,6 +343,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
         // PP = 2: panel h of group g = planes 2 h, 2 h + 1, stage h.  f0 always holds the first-plane fragments of the panel
         // about to be computed (read behind the previous panel's barrier, under its second plane's MFMAs).
         Frags f0, f1;
+        if constexpr ((X_DBG & 16) != 0) { memset(&f0, 0x3f, sizeof(f0)); memset(&f1, 0x3f, sizeof(f1)); }
         read_frags(f0, 0, 0);
 #define ROW3_PANEL(H, LASTP, LOADA)                                                                \
         {                                                                                          \
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
             read_frags(f1, (H), 1);                                                                \
             mfma_plane(f0, (H) * 2);                                                               \
             if (!(LASTP)) {                                                                        \
-                __syncthreads();                                                                   \
+                if ((X_DBG & 64) == 0) __syncthreads();                                            \
                 read_frags(f0, ((H) + 1) & 1, 0);                                                  \
                 if ((H) == 1) load_raw();                                                          \
             }                                                                                      \
@@ -363,12 +384,12 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
         const int otx = orem - ooy * p.TW;
         voff_o[j] = n < p.Ntiles ? (int)(((unsigned)(ob - ob_first) * (unsigned)p.M * (unsigned)HW + (unsigned)ooy * (unsigned)p.W +
                                           (unsigned)(2 * otx) + 4u * (unsigned)half * (unsigned)HW) * 4u) : -1;
-        px1[j] = WEVEN || (2 * otx + 1 < p.W);
+        px1[j] = n < p.Ntiles && (WEVEN || (2 * otx + 1 < p.W));      // (a tile past the end has voff_o = -1: -1 + 4 would be a valid offset)
     }
     const size_t img_out = (size_t)p.M * HW;
     size_t orec = ((size_t)p.B - ob_first) * img_out * 4;
     if (orec > 0xFFFFFFFEull) orec = 0xFFFFFFFEull;
-    const bool has_out = p.out != nullptr, has_add = p.add != nullptr;
+    const bool has_out = p.out != nullptr && (X_DBG & 32) == 0, has_add = p.add != nullptr && (X_DBG & 32) == 0;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(has_out ? p.out + (size_t)ob_first * img_out : (float *)p.bias), 0, has_out ? (int)(unsigned)orec : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(
