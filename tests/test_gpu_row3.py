@@ -155,7 +155,7 @@ def test_row3_whole_network_yolov3():
     b = Network.load(cfg, wts, batch, 0, device=0, fuse=False)
     ref.predict(x); a.predict(x); b.predict(x)
     kernels = [a.layer_kernel(i) for i in range(a.n)]
-    assert sum("conv_f32_row3<" in k for k in kernels) >= 30, kernels
+    assert sum("conv_f32_row3<" in k for k in kernels) >= 20, kernels       # (the 5 x 3 maps of the last scale are below the kernel's 4 x 4)
     assert not any("conv_f32_row3<" in ref.layer_kernel(i) for i in range(ref.n))
     for i in range(a.n):
         if not a.layer_materialised(i):

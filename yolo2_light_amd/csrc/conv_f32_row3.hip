@@ -46,7 +46,8 @@
 
 // Lab builds only (tools/ab_builds.sh, ABFILE=conv_f32_row3: -DX_DBG=<bits>; results are garbage by design): 1 no global loads in
 // the K loop, 2 no split / B stores, 4 no A stores, 8 no MFMAs, 16 no fragment reads, 32 no epilogue stores, 64 no barriers in
-// the K loop.  The shipped library is built with X_DBG undefined: every guard below folds away.
+// the K loop, 128 no A (weight) loads, 256 no input-row loads.  The shipped library is built with X_DBG undefined: every guard
+// below folds away.
 #ifndef X_DBG
 #define X_DBG 0
 #endif
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
 
     // (always issued: past the last group the lane offsets are all-ones and the range check answers without touching memory)
     auto load_raw = [&]() {
-        if constexpr ((X_DBG & 1) != 0) return;
+        if constexpr ((X_DBG & (1 | 256)) != 0) return;
         const int soff = (ld_c0 * HW + ld_ky * p.W) * 4;
         const int tinv = __builtin_amdgcn_sbfe((int)nrowmask, ld_ky, 1) | (ld_c0 < p.C ? 0 : -1);
 #pragma unroll
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
     };
     // A panel `it` (= group * NIT + panel of the group): rows (plane, piece, k-octet) x BM filters
     auto load_a = [&](int it) {
-        if constexpr ((X_DBG & 1) != 0) return;
+        if constexpr ((X_DBG & (1 | 128)) != 0) return;
 #pragma unroll
         for (int e = 0; e < APT; ++e)
             if (A_FULL || tid + e * NT < STAGE_A)
@@ -572,7 +573,28 @@ int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *nam
     d.Ntiles = (int)nt;
     d.tiles_m = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (tile == 0) tile = a.M <= 64 ? 6 : 1;
+    if (tile == 0) {
+        // measured on MI355X at batch 64 (profiles/r5_sweep_row3_tiles_b64.txt, ms for [256,128,76^2] | [512,256,38^2] | [1024,512,19^2]):
+        // 128x128 end-barrier 0.797 | 0.752 | 0.771, mid-barrier 0.837 | 0.773 | 0.809, one plane per panel 0.883 | 0.811 | 0.835,
+        // 128x64 0.850 | 0.831 | 0.859, 64x64 0.954 | 0.928 | 1.009; with 64 filters ([64,32,304^2]) 64x64 1.178, 64x128 1.287.
+        // On grids that do not fill the chip the work of the busiest CU decides: workgroups per CU x tile area x the tile's
+        // relative cost above.
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+            n_cu = v;
+        }
+        auto per_cu = [&](int bm, int bt) {
+            const long long nwg = (long long)((a.M + bm - 1) / bm) * ((nt + bt - 1) / bt);
+            return (double)((nwg + n_cu - 1) / n_cu);
+        };
+        if (a.M <= 64) tile = 8;
+        else {
+            const double c128 = per_cu(128, 128) * 1.0, c64t = per_cu(128, 64) * 0.5 * 1.09, c64 = per_cu(64, 64) * 0.25 * 1.23;
+            tile = (c128 <= c64t && c128 <= c64) ? 2 : (c64t <= c64 ? 4 : 8);
+        }
+    }
     const char *t = "?";
     int rc;
     switch (tile) {

@@ -33,12 +33,13 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 
 #include "kernels.h"
 #include "../../include/yolo2_hip.h"
 
-// X_DBG (build-time timing experiments, results are garbage): 1 no global loads in the K loop, 2 no split / LDS stores,
-// 4 no MFMAs, 8 no epilogue stores
+// Lab builds only (tools/ab_builds.sh, ABFILE=conv_f32_x3: -DX_DBG=<bits>; results are garbage by design): 1 no global loads in the
+// K loop, 2 no split / LDS stores, 4 no MFMAs, 8 no epilogue stores.  The shipped library is built with X_DBG undefined.
 #ifndef X_DBG
 #define X_DBG 0
 #endif
@@ -100,7 +101,9 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned &p1, unsi
 // YOLO: rows m with m % yolo_entries not in {2, 3} get logistic_activate (forward_yolo_layer_cpu; the expression of
 // yolo_kernel in layers.hip, so the tensor is bit-identical to the unfused pair of layers)
 template <int BM, int BN, int WM, int WN, int KS, bool MFULL, bool YOLO = false>
-__global__ __launch_bounds__(WM * WN * 64) void conv_f32_x3_kernel(ConvX3Dev p)
+// (occupancy as before the straight-line epilogue: 148 VGPRs = three waves per SIMD at 128 x 128, four at 64 x 128 -- hipcc otherwise
+// computes all 64 outputs of a block at once and takes 192-244 registers)
+__global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : (BM == 64 ? 4 : 2)) void conv_f32_x3_kernel(ConvX3Dev p)
 {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32);
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_f32_x3_kernel(ConvX3Dev p)
     const size_t img_out = (size_t)p.M * OHW;
     size_t orec = ((size_t)p.B - ob_first) * img_out * 4;
     if (orec > 0xFFFFFFFEull) orec = 0xFFFFFFFEull;
-    const bool has_out = p.out != nullptr, has_add = p.add != nullptr;
+    const bool has_out = p.out != nullptr && (X_DBG & 8) == 0, has_add = p.add != nullptr && (X_DBG & 8) == 0;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(has_out ? p.out + (size_t)ob_first * img_out : (float *)p.bias), 0, has_out ? (int)(unsigned)orec : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(
@@ -327,32 +330,64 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_f32_x3_kernel(ConvX3Dev p)
         (void *)(has_add ? p.out_add + (size_t)ob_first * img_out : (float *)p.bias), 0, has_add ? (int)(unsigned)orec : 0, 0x00020000);
     const int row_bytes = OHW * 4;
     const bool leaky = p.act == YL_LEAKY;
+    // One wave-uniform branch picks the output form (MODE 0: out, 1: out_add only, 2: both) and the activation; inside it the code is
+    // straight-line: the [shortcut] operands of eight accumulator rows are requested before their arithmetic, and leaky is
+    // three conversions / multiplies and a select (left as a ternary hipcc branches around the double-precision path for every
+    // output, and a run-time `has_add` / `leaky` inside the loops became a branch per store).  Same arithmetic as before.
+    auto epilogue = [&](auto mode_tag, auto leaky_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool LEAKY = decltype(leaky_tag)::value;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        float bias_r[16];
+        for (int i = 0; i < TM; ++i) {
+            float bias_r[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) bias_r[e] = bias_s[wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half];
+            for (int e = 0; e < 16; ++e) bias_r[e] = bias_s[wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+            for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = acc[i][j][e] + bias_r[e];
-                if (leaky) v = (v > 0.f) ? v : (float)(.1 * (double)v);
-                const int mrow = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2);
-                if constexpr (YOLO) {
-                    const int entry = (mrow + 4 * half) % p.yolo_entries;
-                    if (entry != 2 && entry != 3) v = (float)(1. / (1. + exp((double)(-v))));
-                }
-                const bool ok = MFULL || (mrow + 4 * half) < p.M;
-                const int vo = ok ? voff_o[j] : -1;
-                if (has_out && (!(X_DBG & 8) || v == 12345.678f))
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, vo, mrow * row_bytes, 0);
-                if (has_add) {
-                    const float av = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_add, vo, mrow * row_bytes, 0));
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __fadd_rn(v, av)), rs_oadd, vo, mrow * row_bytes, 0);
+                for (int e0 = 0; e0 < 16; e0 += 8) {
+                    int vo[8];
+                    float addv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int e = e0 + k;
+                        const int mrow = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2);
+                        const bool ok = MFULL || (mrow + 4 * half) < p.M;
+                        vo[k] = ok ? voff_o[j] : -1;
+                        if constexpr (MODE >= 1)
+                            addv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_add, vo[k], mrow * row_bytes, 0));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int e = e0 + k;
+                        float v = acc[i][j][e] + bias_r[e];
+                        if constexpr (LEAKY) {
+                            float t = (float)(.1 * (double)v);
+                            asm volatile("" : "+v"(t));
+                            v = (v > 0.f) ? v : t;
+                        }
+                        const int mrow = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2);
+                        if constexpr (YOLO) {
+                            const int entry = (mrow + 4 * half) % p.yolo_entries;
+                            if (entry != 2 && entry != 3) v = (float)(1. / (1. + exp((double)(-v))));
+                        }
+                        if constexpr (MODE != 1)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, vo[k], mrow * row_bytes, 0);
+                        if constexpr (MODE >= 1)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __fadd_rn(v, addv[k])), rs_oadd, vo[k], mrow * row_bytes, 0);
+                    }
                 }
             }
         }
+    };
+    if (leaky) {
+        if (!has_add) epilogue(std::integral_constant<int, 0>{}, std::true_type{});
+        else if (!has_out) epilogue(std::integral_constant<int, 1>{}, std::true_type{});
+        else epilogue(std::integral_constant<int, 2>{}, std::true_type{});
+    } else {
+        if (!has_add) epilogue(std::integral_constant<int, 0>{}, std::false_type{});
+        else if (!has_out) epilogue(std::integral_constant<int, 1>{}, std::false_type{});
+        else epilogue(std::integral_constant<int, 2>{}, std::false_type{});
     }
 }
 

@@ -540,6 +540,25 @@ static int to_device(Network &net, int device)
         l.q_from_producer = false; l.q_out_layer = -1; l.skip_f32_out = false; l.q_from_route = false;
         l.bits_from_producer = false; l.bits_out_slot = -1; l.pool_bits_mode = 0;
     }
+    // a convolution in front of a 2x2 / stride-2 [maxpool] its kernel could fold in keeps that kernel whether or not fusion is on
+    // (fused == unfused bit for bit needs the same summation order on both sides): K1r does not take it
+    for (size_t j = 1; j < net.layers.size(); ++j) {
+        const Layer &pl = net.layers[j];
+        Layer &cv = net.layers[j - 1];
+        cv.pool_follows = false;
+        if (pl.type != YL_MAXPOOL || pl.size != 2 || pl.stride != 2 || pl.pad < 0 || pl.pad > 1) continue;
+        if ((pl.h | pl.w) & 1 || pl.out_h != pl.h / 2 || pl.out_w != pl.w / 2) continue;
+        if (cv.type != YL_CONVOLUTIONAL || cv.conv_mode != CONV_F32 || cv.xnor || cv.binarize_input || !hot_activation(cv.activation)) continue;
+        ConvF32Args a;
+        a.in = nullptr; a.wt = cv.d_weights_t; a.bias = cv.d_biases; a.add = nullptr; a.out_add = nullptr; a.out = nullptr;
+        a.B = net.batch; a.C = cv.c; a.H = cv.h; a.W = cv.w; a.M = cv.n; a.OH = cv.out_h; a.OW = cv.out_w;
+        a.K = cv.size * cv.size * cv.c; a.Kpad = cv.Kpad; a.Mpad = cv.Mpad;
+        a.size = cv.size; a.stride = cv.stride; a.pad = cv.pad; a.act = cv.activation; a.tapmajor = cv.tapmajor;
+        a.wino32_u = cv.d_wino32_u;
+        ConvF32Opts o = net.conv_opts;
+        o.force_tile = 0;
+        cv.pool_follows = conv_f32_pool_fusable(a, o);
+    }
     if (net.fuse && !net.debug) {
         const int nl = (int)net.layers.size();
         auto referenced_elsewhere = [&](int t, int consumer) {
@@ -714,7 +733,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
             a.tapmajor = l.tapmajor;
             a.wino32_u = l.d_wino32_u;
             a.x3_w = l.d_weights_x3;
-            a.row3_w = l.d_weights_r3;
+            a.row3_w = l.pool_follows ? nullptr : l.d_weights_r3;
             a.tile_ctr = l.d_tile_ctr;
             // the input tensor is library memory with the front pad (a caller's device pointer as the network input is not)
             a.in_front_pad = conv_in != net.d_binbuf && !(i == 0 && conv_in != net.d_input);

@@ -82,6 +82,7 @@ struct Layer {
     int   fused_shortcut = -1;           // conv: index of the [shortcut] layer folded into its epilogue
     int   fused_yolo = -1;               // FP32 1x1 head conv: index of the [yolo] layer folded into its epilogue
     int   fused_pool = -1;               // FP32 conv (K1f / K1w): index of the 2x2 / stride-2 [maxpool] layer its epilogue also writes
+    bool  pool_follows = false;          // FP32 conv in front of a 2x2 / stride-2 [maxpool] its kernel can fold in: keeps that kernel (K1f / K1w)
     bool  fused_into_conv = false;       // shortcut: produced by the preceding conv's epilogue
     bool  q_from_producer = false;       // INT8 conv: its quantised input is written by the producing conv
     bool  q_from_route = false;          // INT8 conv: its input is a multi-input [route], quantised source by source
