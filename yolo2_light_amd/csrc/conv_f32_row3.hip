@@ -119,6 +119,9 @@ template <int BM, int BT, int WM, int WN, int PP, bool MFULL, bool WEVEN, int SC
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) ? 3 : 2) void conv_f32_row3_kernel(ConvRow3Dev p)
 {
     static_assert(SCHED == 0 || PP == 2, "the mid-panel barrier needs two planes per panel");
+    // SCHED 2: SCHED 1 with the staging work pinned into the shadows of the wave's own MFMAs (sched_group_barrier): left to itself
+    //          hipcc issues the ~60 VALU + 9 LDS stores of a panel as one block in front of the MFMAs, and the two waves of a SIMD
+    //          -- same workgroup, same barrier -- stage at the same time while the matrix pipe waits
     constexpr int NT = WM * WN * 64;
     static_assert(NT == 4 * BT, "one thread per (tile, channel quad)");
     static_assert(PP == 1 || PP == 2, "planes per panel");
@@ -323,11 +326,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
                 store_b((h + 1) & 1, (h + 1) * PP);                                                \
                 if (!(LAST) || h + 2 < NIT) load_a(it + 2);                                        \
             } else if (!(LAST)) {                                                                  \
+                /* the A panel is requested BEFORE the input rows: vmcnt retires in order, so the next panel's wait for */ \
+                /* its A units leaves the four row loads in flight for a whole group */                \
                 store_a(0);                                                                        \
+                load_a(it + 2);                                                                    \
+                __builtin_amdgcn_sched_barrier(0);                                                 \
                 transform();                                                                       \
                 load_raw();                                                                        \
                 store_b(0, 0);                                                                     \
-                load_a(it + 2);                                                                    \
             }                                                                                      \
             _Pragma("unroll") for (int pl = 0; pl < PP; ++pl) {                                    \
                 Frags f;                                                                           \
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
         { ROW3_GROUP(true) }
 #undef ROW3_GROUP
     } else {
-        // PP = 2: panel h of group g = planes 2 h, 2 h + 1, stage h.  f0 always holds the first-plane fragments of the panel
+        // SCHED 1 / 2, PP = 2: panel h of group g = planes 2 h, 2 h + 1, stage h.  f0 always holds the first-plane fragments of the panel
         // about to be computed (read behind the previous panel's barrier, under its second plane's MFMAs).
         Frags f0, f1;
         if constexpr ((X_DBG & 16) != 0) { memset(&f0, 0x3f, sizeof(f0)); memset(&f1, 0x3f, sizeof(f1)); }
@@ -356,12 +362,31 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
             }                                                                                      \
             read_frags(f1, (H), 1);                                                                \
             mfma_plane(f0, (H) * 2);                                                               \
+            if (SCHED == 2 && X_DBG == 0) {                                                        \
+                /* masks: 0x008 MFMA, 0x002 VALU, 0x020 VMEM read, 0x100 DS read, 0x200 DS write */      \
+                _Pragma("unroll") for (int i_ = 0; i_ < 6 * TM * TN; ++i_) {                       \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
+                    __builtin_amdgcn_sched_group_barrier(0x002, (H) == 1 ? 8 : 5, 0);              \
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                             \
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                             \
+                    if (i_ < APT) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);               \
+                }                                                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                 \
+            }                                                                                      \
             if (!(LASTP)) {                                                                        \
                 if ((X_DBG & 64) == 0) __syncthreads();                                            \
                 read_frags(f0, ((H) + 1) & 1, 0);                                                  \
                 if ((H) == 1) load_raw();                                                          \
             }                                                                                      \
             mfma_plane(f1, (H) * 2 + 1);                                                           \
+            if (SCHED == 2 && X_DBG == 0) {                                                        \
+                _Pragma("unroll") for (int i_ = 0; i_ < 6 * TM * TN; ++i_) {                       \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                             \
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                             \
+                    if (i_ < 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                 \
+                }                                                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                 \
+            }                                                                                      \
         }
         for (; g + 1 < G; ++g) {
             ROW3_PANEL(0, false, true)
@@ -548,10 +573,9 @@ void row3_pack_weights(const float *w, int C, int M, void *dst)
             }
 }
 
-// tile: 0 = heuristic; 1 = 128x128 tiles, 8 waves, mid-panel barrier; 2 = the same with the barrier at the panel's end;
-// 3 = 128x128, one plane per panel; 4 / 5 = 128x64, 4 waves (two workgroups per CU), mid-panel barrier / one plane per panel;
-// 6 / 7 = 64x128, 8 waves;
-// 8 / 9 = 64x64, 4 waves
+// tile: 0 = heuristic; 128x128 tiles, 8 waves: 1 = mid-panel barrier, 2 = barrier at the panel's end, 3 = mid-panel barrier with
+// the staging work pinned between the MFMAs; 128x64, 4 waves (two workgroups per CU): 4 = mid-panel barrier, 5 = one plane per
+// panel; 6 = 64x128, 8 waves; 64x64, 4 waves (three workgroups per CU): 7 = pinned, 8 = mid-panel barrier, 9 = end barrier
 int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len)
 {
     if (!a.row3_w || !row3_applicable(a.C, a.M, a.size, a.stride, a.pad) || a.OH != a.H || a.OW != a.W || !a.in_front_pad ||
@@ -600,11 +624,11 @@ int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *nam
     switch (tile) {
     case 1: t = "128x128t,mid"; rc = launch_row3_tile<128, 128, 2, 4, 2, 1>(d, s); break;
     case 2: t = "128x128t,end"; rc = launch_row3_tile<128, 128, 2, 4, 2, 0>(d, s); break;
-    case 3: t = "128x128t,pp1"; rc = launch_row3_tile<128, 128, 2, 4, 1, 0>(d, s); break;
+    case 3: t = "128x128t,pipe"; rc = launch_row3_tile<128, 128, 2, 4, 2, 2>(d, s); break;
     case 4: t = "128x64t,mid"; rc = launch_row3_tile<128, 64, 2, 2, 2, 1>(d, s); break;
     case 5: t = "128x64t,pp1"; rc = launch_row3_tile<128, 64, 2, 2, 1, 0>(d, s); break;
     case 6: t = "64x128t,mid"; rc = launch_row3_tile<64, 128, 2, 4, 2, 1>(d, s); break;
-    case 7: t = "64x128t,end"; rc = launch_row3_tile<64, 128, 2, 4, 2, 0>(d, s); break;
+    case 7: t = "64x64t,pipe"; rc = launch_row3_tile<64, 64, 2, 2, 2, 2>(d, s); break;
     case 8: t = "64x64t,mid"; rc = launch_row3_tile<64, 64, 2, 2, 2, 1>(d, s); break;
     case 9: t = "64x64t,end"; rc = launch_row3_tile<64, 64, 2, 2, 2, 0>(d, s); break;
     default: return (int)hipErrorInvalidValue;
