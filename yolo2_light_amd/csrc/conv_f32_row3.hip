@@ -115,7 +115,11 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned &p1, unsi
 //         already in registers while the next panel is split into the other stage and the second plane's fragments are
 //         read; barrier; second plane: its MFMAs cover the reads of the NEXT panel's first-plane fragments.  No LDS
 //         latency stands in front of an MFMA block, and no wave waits at the barrier with an idle matrix pipe behind it.
-template <int BM, int BT, int WM, int WN, int PP, bool MFULL, bool WEVEN, int SCHED>
+// LOADX2: the input rows as ONE 8-byte load per (tile, channel) -- lane = tile, a wave reads 512 contiguous bytes of a channel row --
+//         and the two outer columns (2t - 1, 2t + 2) from the neighbour lanes by DPP wave_shr:1 / wave_shl:1 (lanes 0 / 63: a
+//         two-lane dword load); false: one 16-byte load per (tile, channel) at an 8-byte lane stride (the first version: every
+//         element fetched twice, two channels per instruction)
+template <int BM, int BT, int WM, int WN, int PP, bool MFULL, bool WEVEN, int SCHED, bool LOADX2>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) ? 3 : 2) void conv_f32_row3_kernel(ConvRow3Dev p)
 {
     static_assert(SCHED == 0 || PP == 2, "the mid-panel barrier needs two planes per panel");
@@ -124,6 +128,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
     //          -- same workgroup, same barrier -- stage at the same time while the matrix pipe waits
     constexpr int NT = WM * WN * 64;
     static_assert(NT == 4 * BT, "one thread per (tile, channel quad)");
+    static_assert(!LOADX2 || BT % 64 == 0, "a wave stages 64 consecutive tiles");
     static_assert(PP == 1 || PP == 2, "planes per panel");
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BT / (WN * 32);
@@ -156,12 +161,14 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
 
     if (tid < BM) bias_s[tid] = (m0 + tid < p.M) ? p.bias[m0 + tid] : 0.f;
 
-    // ---- staging role: tile s_tile, channels 4 q .. 4 q + 3 of every group; lane pairs = the two halves of a 16-byte unit ----
-    constexpr int TWAVES = BT / 32;                      // waves along the tiles
-    const int s_tile = (wave % TWAVES) * 32 + (lane >> 1);
-    const int s_oct = wave / TWAVES;                     // k-octet (wave-uniform)
-    const int s_qlo = lane & 1;
-    const int s_q = s_oct * 2 + s_qlo;
+    // ---- staging role: tile s_tile, channels 4 q .. 4 q + 3 of every group ----
+    // LOADX2: lane = tile (64 consecutive tiles per wave), the channel quad is wave-uniform; otherwise lane pairs = the two
+    // channel quads of a k-octet (the two halves of a 16-byte LDS unit)
+    constexpr int TWAVES = LOADX2 ? BT / 64 : BT / 32;   // waves along the tiles
+    const int s_tile = LOADX2 ? (wave % TWAVES) * 64 + lane : (wave % TWAVES) * 32 + (lane >> 1);
+    const int s_q = LOADX2 ? wave / TWAVES : (wave / TWAVES) * 2 + (lane & 1);
+    const int s_oct = s_q >> 1;                          // k-octet
+    const int s_qlo = s_q & 1;
     const int HW = p.H * p.W;
     const int n_g = n0 + s_tile;
     const bool n_ok = n_g < p.Ntiles;
@@ -171,16 +178,21 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
     const int tx = trem - oy * p.TW;
     const bool cm0 = tx > 0, cm2 = 2 * tx + 1 < p.W, cm3 = 2 * tx + 2 < p.W;
 
-    // buffer descriptor over the input, based at the first image of this workgroup's tiles and shifted back by W + 1 elements:
-    // lane offset (oy * W + 2 tx) = row oy - 1, column 2 tx - 1; rows outside the image -> voffset 0xFFFFFFFF -> 0.0
+    // buffer descriptor over the input, based at the first image of this workgroup's tiles and shifted back by one row (LOADX2)
+    // or one row and one column: lane offset (oy * W + 2 tx) = row oy - 1, column 2 tx (LOADX2) / 2 tx - 1; rows outside the
+    // image -> voffset 0xFFFFFFFF -> 0.0
+    constexpr int COL0 = LOADX2 ? 0 : 1;
     const int b_first = __builtin_amdgcn_readfirstlane(n0 / p.HTW);
     const size_t img_floats = (size_t)p.C * HW;
-    const float *tile_base = p.in + (size_t)b_first * img_floats - (ptrdiff_t)(p.W + 1);
-    size_t rec = (((size_t)p.B - b_first) * img_floats + (size_t)(p.W + 1)) * sizeof(float);
+    const float *tile_base = p.in + (size_t)b_first * img_floats - (ptrdiff_t)(p.W + COL0);
+    size_t rec = (((size_t)p.B - b_first) * img_floats + (size_t)(p.W + COL0)) * sizeof(float);
     if (rec > 0xFFFFFFFEull) rec = 0xFFFFFFFEull;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)tile_base, 0, (int)(unsigned)rec, 0x00020000);
     const int voff = (int)(((unsigned)(bimg - b_first) * (unsigned)img_floats + (unsigned)(s_q * 4) * (unsigned)HW +
                             (unsigned)oy * (unsigned)p.W + (unsigned)(2 * tx)) * 4u);
+    // LOADX2: the outer column only the first / last lane of a wave cannot get from a neighbour (column 2 tx - 1 / 2 tx + 2);
+    // every other lane, and a column outside the image, asks for nothing (offset -1)
+    const int hvoff = !LOADX2 ? -1 : (lane == 0 ? (cm0 ? voff - 4 : -1) : (lane == 63 ? (cm3 ? voff + 8 : -1) : -1));
     unsigned nrowmask = 7u;                   // inverted row validity, bit ky
     if (n_ok) {
         unsigned m = 0;
@@ -195,13 +207,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
     const int b_lds = s_oct * BT * 16 + s_tile * 16 + s_qlo * 8;        // byte offset inside a (plane, piece) slab of a B stage
 
     v4i a_reg[APT];
-    f32x4 raw[4];
+    f32x4 raw[LOADX2 ? 1 : 4];                // x4 form: columns 2t-1 .. 2t+2 of the quad's four channels
+    f32x2 rw2[LOADX2 ? 4 : 1];                // x2 form: columns 2t, 2t+1
+    float rwh[LOADX2 ? 4 : 1];                //          + the outer column of lanes 0 / 63
     float V[4][4];                            // [plane][channel of the quad]
     if constexpr (X_DBG != 0) {               // lab builds skip producers: give every consumer a defined value
 #pragma unroll
         for (int e = 0; e < APT; ++e) a_reg[e] = v4i{0x3f803f80, 0x3f803f80, 0x3f803f80, 0x3f803f80};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) raw[i] = f32x4{1.f, 2.f, 3.f, 4.f};
+        for (int i = 0; i < (LOADX2 ? 1 : 4); ++i) raw[i] = f32x4{1.f, 2.f, 3.f, 4.f};
+#pragma unroll
+        for (int i = 0; i < (LOADX2 ? 4 : 1); ++i) { rw2[i] = f32x2{1.f, 2.f}; rwh[i] = 3.f; }
     }
     int ld_ky = 0, ld_c0 = 0;                 // group of the NEXT raw load
 
@@ -210,16 +226,35 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
         if constexpr ((X_DBG & (1 | 256)) != 0) return;
         const int soff = (ld_c0 * HW + ld_ky * p.W) * 4;
         const int tinv = __builtin_amdgcn_sbfe((int)nrowmask, ld_ky, 1) | (ld_c0 < p.C ? 0 : -1);
+        if constexpr (LOADX2) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff | tinv, soff + i * HW * 4, 0));
+            for (int i = 0; i < 4; ++i)
+                rw2[i] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff | tinv, soff + i * HW * 4, 0));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                rwh[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, hvoff | tinv, soff + i * HW * 4, 0));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                raw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff | tinv, soff + i * HW * 4, 0));
+        }
         ++ld_ky;
         if (ld_ky == 3) { ld_ky = 0; ld_c0 += 16; }
     };
     auto transform = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float d0 = cm0 ? raw[i][0] : 0.f, d1 = raw[i][1], d2 = cm2 ? raw[i][2] : 0.f, d3 = cm3 ? raw[i][3] : 0.f;
+            float d0, d1, d2, d3;
+            if constexpr (LOADX2) {
+                const float x = rw2[i][0], y = rw2[i][1], h = rwh[i];
+                // wave_shr:1 -- lane l takes lane l-1's y (column 2t-1), lane 0 keeps h; wave_shl:1 -- lane l takes lane l+1's x
+                // (column 2t+2), lane 63 keeps h.  A neighbour in another row or image delivers a value the masks drop.
+                const float l = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, h), __builtin_bit_cast(int, y), 0x138, 0xf, 0xf, false));
+                const float r = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, h), __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+                d0 = cm0 ? l : 0.f; d1 = x; d2 = cm2 ? y : 0.f; d3 = cm3 ? r : 0.f;
+            } else {
+                d0 = cm0 ? raw[i][0] : 0.f; d1 = raw[i][1]; d2 = cm2 ? raw[i][2] : 0.f; d3 = cm3 ? raw[i][3] : 0.f;
+            }
             V[0][i] = d0 - d2;
             V[1][i] = d1 + d2;
             V[2][i] = d2 - d1;
@@ -506,7 +541,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
     }
 }
 
-template <int BM, int BT, int WM, int WN, int PP, int SCHED>
+template <int BM, int BT, int WM, int WN, int PP, int SCHED, bool LOADX2 = true>
 int launch_row3_tile(ConvRow3Dev p, hipStream_t s)
 {
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -514,10 +549,10 @@ int launch_row3_tile(ConvRow3Dev p, hipStream_t s)
     if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks), block(WM * WN * 64);
     const bool mfull = (p.M % BM) == 0, weven = (p.W & 1) == 0;
-    if (mfull && weven) hipLaunchKernelGGL((conv_f32_row3_kernel<BM, BT, WM, WN, PP, true, true, SCHED>), grid, block, 0, s, p);
-    else if (mfull) hipLaunchKernelGGL((conv_f32_row3_kernel<BM, BT, WM, WN, PP, true, false, SCHED>), grid, block, 0, s, p);
-    else if (weven) hipLaunchKernelGGL((conv_f32_row3_kernel<BM, BT, WM, WN, PP, false, true, SCHED>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((conv_f32_row3_kernel<BM, BT, WM, WN, PP, false, false, SCHED>), grid, block, 0, s, p);
+    if (mfull && weven) hipLaunchKernelGGL((conv_f32_row3_kernel<BM, BT, WM, WN, PP, true, true, SCHED, LOADX2>), grid, block, 0, s, p);
+    else if (mfull) hipLaunchKernelGGL((conv_f32_row3_kernel<BM, BT, WM, WN, PP, true, false, SCHED, LOADX2>), grid, block, 0, s, p);
+    else if (weven) hipLaunchKernelGGL((conv_f32_row3_kernel<BM, BT, WM, WN, PP, false, true, SCHED, LOADX2>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv_f32_row3_kernel<BM, BT, WM, WN, PP, false, false, SCHED, LOADX2>), grid, block, 0, s, p);
     return (int)hipGetLastError();
 }
 
@@ -573,9 +608,10 @@ void row3_pack_weights(const float *w, int C, int M, void *dst)
             }
 }
 
-// tile: 0 = heuristic; 128x128 tiles, 8 waves: 1 = mid-panel barrier, 2 = barrier at the panel's end, 3 = mid-panel barrier with
-// the staging work pinned between the MFMAs; 128x64, 4 waves (two workgroups per CU): 4 = mid-panel barrier, 5 = one plane per
-// panel; 6 = 64x128, 8 waves; 64x64, 4 waves (three workgroups per CU): 7 = pinned, 8 = mid-panel barrier, 9 = end barrier
+// tile: 0 = heuristic; 128x128 tiles, 8 waves: 2 = barrier at the panel's end, 3 = mid-panel barrier with the staging work pinned
+// between the MFMAs (1 / 6: 3 / 2 with the 16-byte row loads of the first version, A/B); 128x64, 4 waves (two workgroups per CU):
+// 4 = mid-panel barrier, 5 = one plane per panel; 64x64, 4 waves (three workgroups per CU): 7 = pinned, 9 = end barrier;
+// 8 = 64x128, 8 waves, pinned
 int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len)
 {
     if (!a.row3_w || !row3_applicable(a.C, a.M, a.size, a.stride, a.pad) || a.OH != a.H || a.OW != a.W || !a.in_front_pad ||
@@ -613,23 +649,23 @@ int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *nam
             const long long nwg = (long long)((a.M + bm - 1) / bm) * ((nt + bt - 1) / bt);
             return (double)((nwg + n_cu - 1) / n_cu);
         };
-        if (a.M <= 64) tile = 8;
+        if (a.M <= 64) tile = 7;
         else {
             const double c128 = per_cu(128, 128) * 1.0, c64t = per_cu(128, 64) * 0.5 * 1.09, c64 = per_cu(64, 64) * 0.25 * 1.23;
-            tile = (c128 <= c64t && c128 <= c64) ? 2 : (c64t <= c64 ? 4 : 8);
+            tile = (c128 <= c64t && c128 <= c64) ? 3 : (c64t <= c64 ? 4 : 7);
         }
     }
     const char *t = "?";
     int rc;
     switch (tile) {
-    case 1: t = "128x128t,mid"; rc = launch_row3_tile<128, 128, 2, 4, 2, 1>(d, s); break;
+    case 1: t = "128x128t,pipe,x4"; rc = launch_row3_tile<128, 128, 2, 4, 2, 2, false>(d, s); break;
     case 2: t = "128x128t,end"; rc = launch_row3_tile<128, 128, 2, 4, 2, 0>(d, s); break;
     case 3: t = "128x128t,pipe"; rc = launch_row3_tile<128, 128, 2, 4, 2, 2>(d, s); break;
     case 4: t = "128x64t,mid"; rc = launch_row3_tile<128, 64, 2, 2, 2, 1>(d, s); break;
     case 5: t = "128x64t,pp1"; rc = launch_row3_tile<128, 64, 2, 2, 1, 0>(d, s); break;
-    case 6: t = "64x128t,mid"; rc = launch_row3_tile<64, 128, 2, 4, 2, 1>(d, s); break;
+    case 6: t = "128x128t,end,x4"; rc = launch_row3_tile<128, 128, 2, 4, 2, 0, false>(d, s); break;
     case 7: t = "64x64t,pipe"; rc = launch_row3_tile<64, 64, 2, 2, 2, 2>(d, s); break;
-    case 8: t = "64x64t,mid"; rc = launch_row3_tile<64, 64, 2, 2, 2, 1>(d, s); break;
+    case 8: t = "64x128t,pipe"; rc = launch_row3_tile<64, 128, 2, 4, 2, 2>(d, s); break;
     case 9: t = "64x64t,end"; rc = launch_row3_tile<64, 64, 2, 2, 2, 0>(d, s); break;
     default: return (int)hipErrorInvalidValue;
     }
