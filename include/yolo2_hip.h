@@ -299,7 +299,7 @@ int yl_network_pull_heads(yl_network *net);
  *   0 = built-in heuristic (default), 11..22 = direct implicit-GEMM tile 1..12 (conv_f32_mfma.hip),
  *   31 = Winograd F(2x2,3x3) (conv_f32_wino32.hip; a launch fails on layers it does not apply to),
  *   41 = LDS-free first-layer kernel (conv_f32_smallk.hip; C*size^2 <= 32 and filters <= 32 only),
- *   51..53 = the three-piece BF16 kernel's tiles (conv_f32_x3.hip), 61..69 = the row-wise Winograd kernel's tiles and
+ *   51..54 = the three-piece BF16 kernel's tiles (conv_f32_x3.hip), 61..69 = the row-wise Winograd kernel's tiles and
  *   schedules (conv_f32_row3.hip; 3x3 / stride 1 / pad 1 layers with C % 16 == 0 only).
  * yl_network_set_winograd: 0 = never pick Winograd heuristically and do not pack its weights, 1 = default;
  *   BEFORE yl_network_to_device.

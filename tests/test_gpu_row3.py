@@ -50,7 +50,7 @@ def _single(shape, wts, bias, variant=0):
 
 
 @pytest.mark.parametrize("shape", ROW3_SHAPES)
-@pytest.mark.parametrize("tile", [61, 62, 63, 64, 65, 67, 68])
+@pytest.mark.parametrize("tile", [61, 62, 63, 64, 65, 66, 67, 68])
 def test_conv_row3_vs_oracle(olib, shape, tile):
     B, Cc, H, W, M, act = shape
     wts, bias, x = _layer(shape, 2718)

@@ -567,7 +567,7 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o_in, void *stream,
         return launch_conv_f32_first(a, stream, name, name_len);
     if (a.bits_out)                                                   // sign-word side output: only the first-layer kernels have it
         return smallk_applicable(a) ? launch_conv_f32_smallk(a, stream, name, name_len) : (int)hipErrorInvalidValue;
-    // K1x: the layer on the BF16 matrix pipe with three-piece operands (variant bit 10; force_tile 51..53 = its tiles)
+    // K1x: the layer on the BF16 matrix pipe with three-piece operands (variant bit 10; force_tile 51..54 = its tiles)
     // (measured in yolov3-608: 0.60-0.72 of the FP32-MFMA kernel's time from 64 filters up, 1.13 at 32 filters, where the
     //  layer is bound by its tensors and the split's extra instructions only cost; profiles/r4_x3_per_layer.txt)
     const bool wino_takes = a.wino32_u && (o.force_tile == 31 || (o.force_tile == 0 && o.winograd &&
@@ -578,9 +578,9 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o_in, void *stream,
         ((wino_takes && (o.variant & 2048)) || row3_tile))
         return launch_conv_f32_row3(a, row3_tile, stream, name, name_len);
     if (!wino_takes && a.x3_w && (a.out || a.add) && !a.q_out && !a.pool_out && !a.bits_out && (a.yolo_entries == 0 || (a.size == 1 && !a.add)) &&
-        ((o.force_tile == 0 && (o.variant & 1024) && a.M > 32) || (o.force_tile >= 51 && o.force_tile <= 53)))
+        ((o.force_tile == 0 && (o.variant & 1024) && a.M > 32) || (o.force_tile >= 51 && o.force_tile <= 54)))
         return launch_conv_f32_x3(a, o.force_tile >= 51 ? o.force_tile - 50 : 0, stream, name, name_len);
-    if (o.force_tile >= 51 && o.force_tile <= 53) return (int)hipErrorInvalidValue;
+    if (o.force_tile >= 51 && o.force_tile <= 54) return (int)hipErrorInvalidValue;
     if (a.yolo_entries > 0)                                           // folded [yolo]: 1x1 direct kernel, two tiles
         return launch_conv_f32_direct(a, (o.force_tile == 14 || o.force_tile == 22 || o.force_tile == 20) ? o.force_tile - 10 :
                                       (((long long)((a.M + 127) / 128) * (((long long)a.B * a.OH * a.OW + 255) / 256) >= 384) ? 10 :

@@ -103,7 +103,7 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned &p1, unsi
 template <int BM, int BN, int WM, int WN, int KS, bool MFULL, bool YOLO = false>
 // (occupancy as before the straight-line epilogue: 148 VGPRs = three waves per SIMD at 128 x 128, four at 64 x 128 -- hipcc otherwise
 // computes all 64 outputs of a block at once and takes 192-244 registers)
-__global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : (BM == 64 ? 4 : 2)) void conv_f32_x3_kernel(ConvX3Dev p)
+__global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : (BM == 64 ? (BN == 64 ? 3 : 4) : 2)) void conv_f32_x3_kernel(ConvX3Dev p)
 {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32);
@@ -455,7 +455,7 @@ void x3_pack_weights(const float *w, int C, int M, int size, void *dst)
             }
 }
 
-// tile: 0 = heuristic, 1 = 128x128 (wave tile 64x64), 2 = 64x128 (32x64), 3 = 32x256 (32x64)
+// tile: 0 = heuristic, 1 = 128x128 (wave tile 64x64), 2 = 64x128 (32x64), 3 = 32x256 (32x64), 4 = 64x64 (two waves of 32x64: small grids)
 int launch_conv_f32_x3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len)
 {
     if (!a.x3_w || !x3_applicable(a.C, a.M, a.size, a.stride, a.pad) || (!a.out && !a.add) || (a.add && !a.out_add) || a.q_out ||
@@ -478,13 +478,24 @@ int launch_conv_f32_x3(const ConvF32Args &a, int tile, void *stream, char *name,
     d.Ntotal = (int)nt;
     d.tiles_m = 0;
     hipStream_t s = (hipStream_t)stream;
-    if (tile == 0) tile = a.M <= 32 ? 3 : (a.M <= 64 ? 2 : 1);
+    if (tile == 0) {
+        tile = a.M <= 32 ? 3 : (a.M <= 64 ? 2 : 1);
+        // grids far below the chip (8 images per GPU at 19 x 19: 92 workgroups of 128 x 128 for 256 CUs): 64 x 64 tiles
+        static int n_cu = 0;
+        if (n_cu == 0) {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+            n_cu = v;
+        }
+        if (tile == 1 && (long long)((a.M + 127) / 128) * ((nt + 127) / 128) < (long long)n_cu) tile = 4;
+    }
     const char *t = "?";
     int rc;
     switch (tile) {
     case 1: t = "128x128"; rc = launch_x3_tile<128, 128, 2, 2>(d, s); break;
     case 2: t = "64x128"; rc = launch_x3_tile<64, 128, 2, 2>(d, s); break;
     case 3: t = "32x256"; rc = launch_x3_tile<32, 256, 1, 4>(d, s); break;
+    case 4: t = "64x64"; rc = launch_x3_tile<64, 64, 2, 1>(d, s); break;
     default: return (int)hipErrorInvalidValue;
     }
     if (name) snprintf(name, name_len, "conv_f32_x3<%s,ks%d%s>", t, a.size, a.yolo_entries > 0 ? ",yolo" : "");

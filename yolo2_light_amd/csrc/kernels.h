@@ -54,7 +54,7 @@ struct ConvF32Args {
 // per-network kernel-selection knobs (snapshotted in Network: two networks driven from two host
 // threads, one per GPU, share no mutable launch state)
 struct ConvF32Opts {
-    int force_tile = 0;   // 0 = heuristic, 11..22 = direct tile 1..12, 31 = Winograd, 41 = small-K first-layer kernel, 51..53 = K1x tiles,
+    int force_tile = 0;   // 0 = heuristic, 11..22 = direct tile 1..12, 31 = Winograd, 41 = small-K first-layer kernel, 51..54 = K1x tiles,
                           // 61..69 = K1r tiles (tuning / tests)
     int winograd = 1;     // Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 layers with C >= 64
     // schedule variants kept switchable for same-box A/B runs (yl_network_set_variant): bit 0 Winograd U panels by

@@ -1567,7 +1567,7 @@ int yl_network_get_boxes(yl_network *net, int image, int w, int h, float thresh,
 int yl_network_set_conv_tile(yl_network *net, int cfg)
 {
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }
-    if (!(cfg == 0 || (cfg >= 11 && cfg <= 22) || cfg == 31 || cfg == 41 || (cfg >= 51 && cfg <= 53) || (cfg >= 61 && cfg <= 69))) { set_error("unknown tile id"); return YL_ERR_ARG; }
+    if (!(cfg == 0 || (cfg >= 11 && cfg <= 22) || cfg == 31 || cfg == 41 || (cfg >= 51 && cfg <= 54) || (cfg >= 61 && cfg <= 69))) { set_error("unknown tile id"); return YL_ERR_ARG; }
     net->net.conv_opts.force_tile = cfg;
     return YL_OK;
 }
