@@ -610,8 +610,8 @@ void row3_pack_weights(const float *w, int C, int M, void *dst)
 
 // tile: 0 = heuristic; 128x128 tiles, 8 waves: 1 = mid-panel barrier with the staging work pinned between the MFMAs, 2 = barrier at
 // the panel's end, 3 = 1 with the 8-byte + DPP row loads (A/B); 128x64, 4 waves (two workgroups per CU): 4 = mid-panel barrier,
-// 5 = one plane per panel; 64x64, 4 waves (three workgroups per CU): 7 = pinned, 9 = end barrier; 8 = 64x128, 8 waves, pinned;
-// 6 = 64x32, 2 waves, pinned (grids far below the chip: 8 images at 19 x 19)
+// 5 = one plane per panel; 64x64, 4 waves (three workgroups per CU): 7 = pinned, 9 = end barrier, 6 = 7 with the 8-byte + DPP row
+// loads; 8 = 64x128, 8 waves, pinned
 int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len)
 {
     if (!a.row3_w || !row3_applicable(a.C, a.M, a.size, a.stride, a.pad) || a.OH != a.H || a.OW != a.W || !a.in_front_pad ||
@@ -653,8 +653,8 @@ int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *nam
         else {
             const double c128 = per_cu(128, 128) * 1.0, c64t = per_cu(128, 64) * 0.5 * 1.09, c64 = per_cu(64, 64) * 0.25 * 1.23;
             tile = (c128 <= c64t && c128 <= c64) ? 1 : (c64t <= c64 ? 4 : 7);
-            // fewer 64x64 workgroups than two per CU: the finest tile puts three times as many waves to work
-            if (tile != 1 && (long long)((a.M + 63) / 64) * ((nt + 63) / 64) < 2LL * n_cu) tile = 6;
+            // (a finer 64x32 tile was measured at 8 images per GPU and gains nothing: below one workgroup per CU a layer's time
+            //  is one workgroup's K loop -- 96 groups at 19 x 19 -- whatever the tile; profiles/r5_small_grid_tiles_b8.txt)
         }
     }
     const char *t = "?";
@@ -665,7 +665,7 @@ int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *nam
     case 3: t = "128x128t,pipe,x2"; rc = launch_row3_tile<128, 128, 2, 4, 2, 2, true>(d, s); break;
     case 4: t = "128x64t,mid"; rc = launch_row3_tile<128, 64, 2, 2, 2, 1>(d, s); break;
     case 5: t = "128x64t,pp1"; rc = launch_row3_tile<128, 64, 2, 2, 1, 0>(d, s); break;
-    case 6: t = "64x32t,pipe"; rc = launch_row3_tile<64, 32, 2, 1, 2, 2>(d, s); break;
+    case 6: t = "64x64t,pipe,x2"; rc = launch_row3_tile<64, 64, 2, 2, 2, 2, true>(d, s); break;
     case 7: t = "64x64t,pipe"; rc = launch_row3_tile<64, 64, 2, 2, 2, 2>(d, s); break;
     case 8: t = "64x128t,pipe"; rc = launch_row3_tile<64, 128, 2, 4, 2, 2>(d, s); break;
     case 9: t = "64x64t,end"; rc = launch_row3_tile<64, 64, 2, 2, 2, 0>(d, s); break;
