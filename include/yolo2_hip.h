@@ -295,6 +295,12 @@ int yl_network_get_boxes(yl_network *net, int image, int w, int h, float thresh,
 int yl_network_pull_heads(yl_network *net);
 
 /* Tuning/test hooks, PER NETWORK (two networks driven from two host threads share no launch state).
+ * yl_network_set_conv_tile and yl_network_set_variant may be called at any time, also after yl_network_to_device: the
+ * layer-fusion plan (conv + [shortcut], [yolo] folded into its head conv, a 2x2 / stride-2 [maxpool] written by the
+ * convolution in front of it) is made at yl_network_to_device from the knobs of that moment, and a later change never
+ * fails a forward pass -- where the newly selected kernel cannot write a planned pooled tensor, the convolution writes
+ * its full tensor and the stand-alone pooling kernel runs behind it (same bits).  Weight images that a variant bit
+ * selects (bit 5, yl_network_set_winograd) are packed at yl_network_to_device: set those BEFORE it.
  * yl_network_set_conv_tile: force the K1 kernel of every FP32 convolution of this network, any time:
  *   0 = built-in heuristic (default), 11..22 = direct implicit-GEMM tile 1..12 (conv_f32_mfma.hip),
  *   31 = Winograd F(2x2,3x3) (conv_f32_wino32.hip; a launch fails on layers it does not apply to),

@@ -733,6 +733,15 @@ def test_maxpool_fusion_whole_network_yolov3_tiny():
         assert np.array_equal(plain.layer_output(i).view(np.uint32), fused.layer_output(i).view(np.uint32)), "layer %d" % i
     for b in range(batch):
         assert np.array_equal(plain.get_boxes(b, width, height, 0.24, nms=0.4), fused.get_boxes(b, width, height, 0.24, nms=0.4))
+    # a kernel-selection knob moved AFTER to_device: the fusion plan was made for K1f / K1w, a forced direct
+    # tile has no pooled output -- the forward pass must not fail; the convolution writes its full tensor and the stand-alone
+    # pooling kernel follows (same bits as the unfused network on the same tile)
+    plain.set_conv_tile(14); fused.set_conv_tile(14)
+    a, b = plain.predict(x).copy(), fused.predict(x).copy()
+    assert all("pool" not in fused.layer_kernel(i) for i in range(fused.n))
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for i in (1, 3, 5):           # the pooling layers behind layers 0 / 2 / 4
+        assert np.array_equal(plain.layer_output(i).view(np.uint32), fused.layer_output(i).view(np.uint32)), "pool layer %d" % i
     plain.close(); fused.close()
 
 

@@ -535,8 +535,10 @@ static int launch_conv_f32_direct(const ConvF32Args &a, int cfg, int variant, vo
 }
 
 // The two branches of launch_conv_f32 below whose kernels have a pooled output (kept next to it on purpose).
-bool conv_f32_pool_fusable(const ConvF32Args &a0, const ConvF32Opts &o)
+bool conv_f32_pool_fusable(const ConvF32Args &a0, const ConvF32Opts &o_in)
 {
+    ConvF32Opts o = o_in;
+    if (o.force_tile >= 61 && o.force_tile <= 69) o.force_tile = 0;      // K1r's tile choice: every other layer keeps the heuristic
     ConvF32Args a = a0;
     a.pool_out = nullptr;
     if (a.q_out || a.bits_out || a.add || a.yolo_entries > 0 || ((a.H | a.W) & 1) || a.OH != a.H || a.OW != a.W) return false;
@@ -559,8 +561,8 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o_in, void *stream,
     // ([64,288,92416]) Winograd wins stand-alone (1.59 vs 2.16 ms) but not in the network, where the
     // layer carries a fused shortcut and is bound by 3 GB of epilogue traffic (2.31 vs 2.2 ms): C >= 64.
     if (a.q_out && a.wino32_u) return (int)hipErrorInvalidValue;      // the planner gives q_out to direct layers only
-    // a fused [maxpool] was planned for a kernel that has the pooled output: a later change of the kernel-selection
-    // knobs must fail loudly, not drop the pooling layer's tensor
+    // a fused [maxpool] needs a kernel that has the pooled output (the runtime checks conv_f32_pool_fusable before every launch
+    // and degrades to the stand-alone pooling kernel when a knob has moved the layer elsewhere: this is the backstop)
     if (a.pool_out && !conv_f32_pool_fusable(a, o)) return (int)hipErrorInvalidValue;
     // RGB first layers with <= 16 filters: the VALU kernel (force_tile 41 keeps the MFMA first-layer kernel for A/B)
     if (o.force_tile == 0 && (o.variant & 8) && first_layer_valu_applicable(a))

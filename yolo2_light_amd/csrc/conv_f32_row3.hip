@@ -18,7 +18,7 @@
 // 4 multiplies per 2 outputs and (c, ky) instead of 6: with U and V split into three bf16 pieces each that is
 // 6 / 1.5 = 4 BF16 MFMAs per 16 k and tap triple -- 136 matrix-pipe cycles where FP32 F(2x2,3x3) needs 228 and K1x 204.
 // Accuracy: the transforms only add and subtract (U's halves are formed in double), the split is exact, the dropped
-// cross terms a2 b3 + a3 b2 + a3 b3 are <= 2^-26 |a b| (conv_f32_x3.hip); checked against the oracle and against a
+// cross terms a2 b3 + a3 b2 + a3 b3 are ~2^-26 |a b| rms, <= 2^-23 |a b| worst case (conv_f32_x3.hip); checked against the oracle and against a
 // float64 convolution like the other FP32 kernels (tests/test_gpu_parity.py).
 //
 //   tiles        n = (b * H + oy) * TW + tx, TW = ceil(W / 2); a workgroup owns BM filters x BT consecutive tiles x 4 planes

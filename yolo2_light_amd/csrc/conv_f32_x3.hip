@@ -10,14 +10,21 @@
 //
 // a product of two bf16 numbers is exact in FP32, and the matrix pipe accumulates in FP32.  So
 //
-//     a * b  =  a1 b1 + (a1 b2 + a2 b1) + (a2 b2 + a1 b3 + a3 b1)  +  [a2 b3 + a3 b2 + a3 b3  <=  3 * 2^-24 |a b|]
+//     a * b  =  a1 b1 + (a1 b2 + a2 b1) + (a2 b2 + a1 b3 + a3 b1)  +  [a2 b3 + a3 b2 + a3 b3]
 //
-// six MFMAs per 16 k instead of eight FP32 MFMAs: 204 cycles instead of 520 for the same arithmetic to within FP32
-// rounding (the dropped terms are below half an ulp of the product).  Measured against a float64 convolution the result is
-// as close as the FP32-MFMA kernel's (tests/test_gpu_parity.py::test_fp32_error_vs_float64_truth covers every layer of
-// yolov3 with this kernel on; a numpy model of the scheme: rms error 3.5e-7 of the layer rms at K = 1024 vs 5.8e-7 for a
-// sequential FP32 dot product).  This is NOT the opt-in BF16 variant (conv_bf16_mfma.hip rounds the operands to ONE bf16
-// piece, 2^-9 relative): nothing is rounded here that FP32 arithmetic would keep.
+// six MFMAs per 16 k instead of eight FP32 MFMAs: 204 cycles instead of 520.  The dropped bracket: round-to-nearest leaves
+// |a - a1| <= 2^-8 |a| and |a - a1 - a2| <= 2^-16 |a| (a3 holds that residual exactly), so in the worst case a2 b3 + a3 b2 <=
+// 2 * 2^-24 |a b| and a3 b3 <= 2^-32 |a b| -- two half-ulps of the FP32 product; for operands spread over a binade the
+// residuals are uniform, |a2| ~ 2^-9.4 |a| and |a3| ~ 2^-17.4 |a| rms, and the bracket is ~2^-26 |a b| rms, a quarter of the
+// half-ulp (2^-24 |a b|) FP32 arithmetic itself loses wherever it rounds a product.  What differs
+// from the FP32-MFMA kernel in practice is the summation inside the matrix pipe: measured against a float64 convolution a layer
+// is up to 1.4x as far from the truth as conv_f32_mfma.hip's result (and at most 1.5x, asserted per shape in
+// tests/test_gpu_parity.py::test_conv_x3_vs_oracle; every layer of yolov3 with this kernel on stays inside the bound of
+// test_fp32_error_vs_float64_truth, measured 1.0 of it with K1x on all 75 layers, 0.72 in the shipped mix).  Inputs whose first
+// piece overflows bf16 (|x| >= 3.3961e38: beyond bf16's largest finite value 3.3895e38 by half its spacing) become Inf and the result NaN where FP32 arithmetic may
+// still give a finite product, and pieces below 2^-126 flush to zero (residuals of |x| < 2^-108): outside any activation this
+// path produces, stated in DESIGN.md and pinned by tests/test_gpu_row3.py::test_three_piece_kernels_at_the_edges_of_the_format.  This is NOT the opt-in BF16 variant
+// (conv_bf16_mfma.hip rounds the operands to ONE bf16 piece, 2^-9 relative).
 //
 // Weights are split once (x3_pack_weights); activations are split by the staging threads between their global load and
 // their LDS store (12 VALU per pair of elements -- free beside this MFMA).

@@ -408,8 +408,8 @@ static int to_device(Network &net, int device)
     // every activation tensor the library owns has ACT_FRONT_PAD readable floats in front of it: the Winograd kernel reads
     // ONE float before a tensor (column -1 of the first patch row of the first image, masked to zero in the transform)
     YL_HIP(hipMalloc((void **)&net.d_input, (in_elems + ACT_FRONT_PAD + ACT_TAIL_PAD) * sizeof(float)));
-    YL_HIP(hipMemsetAsync(net.d_input, 0, ACT_FRONT_PAD * sizeof(float), (hipStream_t)net.stream));
-    net.d_input += ACT_FRONT_PAD;
+    net.d_input += ACT_FRONT_PAD;            // (before the next fallible call: free_device frees d_input - ACT_FRONT_PAD)
+    YL_HIP(hipMemsetAsync(net.d_input - ACT_FRONT_PAD, 0, ACT_FRONT_PAD * sizeof(float), (hipStream_t)net.stream));
     net.pinned_bytes = in_elems * sizeof(float);
     YL_HIP(hipHostMalloc(&net.h_pinned, net.pinned_bytes, hipHostMallocDefault));
 
@@ -422,8 +422,8 @@ static int to_device(Network &net, int device)
         } else {
             l.d_output_alias = false;
             YL_HIP(hipMalloc((void **)&l.d_output, (out_elems + ACT_FRONT_PAD + ACT_TAIL_PAD) * sizeof(float)));
-            YL_HIP(hipMemsetAsync(l.d_output, 0, ACT_FRONT_PAD * sizeof(float), (hipStream_t)net.stream));      // finite: it is multiplied by 0
-            l.d_output += ACT_FRONT_PAD;
+            l.d_output += ACT_FRONT_PAD;     // (before the next fallible call: free_device frees d_output - ACT_FRONT_PAD)
+            YL_HIP(hipMemsetAsync(l.d_output - ACT_FRONT_PAD, 0, ACT_FRONT_PAD * sizeof(float), (hipStream_t)net.stream));      // finite: it is multiplied by 0
         }
         if (l.type == YL_CONVOLUTIONAL) {
             int rc = upload_conv(net, l);
@@ -742,10 +742,26 @@ static int forward_layer(Network &net, size_t i, const float *input)
                 a.yolo_entries = yo.classes + 5;
                 a.out = yo.d_output;
             }
-            if (l.fused_pool >= 0) a.pool_out = net.layers[l.fused_pool].d_output;      // 2x2 / stride-2 [maxpool] written by this epilogue
+            // 2x2 / stride-2 [maxpool] written by this epilogue.  The plan was made at yl_network_to_device from the kernel-selection
+            // knobs of that moment; if yl_network_set_conv_tile / yl_network_set_variant has since moved the layer to a kernel
+            // without a pooled output (e.g. a forced direct tile), degrade instead of failing: the full tensor (always allocated)
+            // is written and the stand-alone pooling kernel follows -- the same bits either way.
+            bool pool_after = false;
+            if (l.fused_pool >= 0) {
+                a.pool_out = net.layers[l.fused_pool].d_output;
+                if (!conv_f32_pool_fusable(a, net.conv_opts)) {
+                    a.pool_out = nullptr;
+                    a.out = l.d_output;
+                    pool_after = true;
+                }
+            }
             if (l.bits_out_slot >= 0)       // FP32 first layer -> [maxpool] -> XNOR conv: sign words instead of the FP32 tensor
                 a.bits_out = net.d_bitbuf + (size_t)(l.bits_out_slot % 3) * (net.bitbuf_bytes / sizeof(uint64_t));
             YL_LAUNCH(launch_conv_f32(a, net.conv_opts, s, l.kernel_name, sizeof(l.kernel_name)), "conv_f32");
+            if (pool_after) {
+                const Layer &pl = net.layers[l.fused_pool];
+                YL_LAUNCH(launch_maxpool(l.d_output, pl.d_output, B, pl.c, pl.h, pl.w, pl.out_h, pl.out_w, pl.size, pl.stride, pl.pad, s), "maxpool");
+            }
         } else if (l.conv_mode == CONV_INT8) {
             int8_t *q_in = net.d_qbuf + (i % 3) * net.qbuf_bytes;
             if (l.q_from_route) {
@@ -1213,7 +1229,11 @@ int yl_network_layer_traffic(const yl_network *net, int i, double *bytes)
             rd += bits + wel / 8;
             if (l.bits_out_slot >= 0) wr += B * (double)l.out_h * l.out_w * 8.0 * ((l.n + 63) / 64);
         } else {
-            rd += 4 * in_el + 4 * wel;
+            // the weight image the layer's last launch read: K1x 6 B per weight (three bf16 pieces), K1r 24 B per (filter, channel,
+            // filter row) = 8 B per weight (four planes x three pieces), the FP32 kernels 4 B (Winograd U: 16 floats per 9 weights)
+            const bool k1x = strncmp(l.kernel_name, "conv_f32_x3", 11) == 0, k1r = strncmp(l.kernel_name, "conv_f32_row3", 13) == 0;
+            const bool k1w = strncmp(l.kernel_name, "conv_f32_wino", 13) == 0;
+            rd += 4 * in_el + (k1x ? 6.0 : (k1r ? 8.0 : (k1w ? 4.0 * 16.0 / 9.0 : 4.0))) * wel;
             if (l.binarize_input) { rd += 4 * in_el; wr += 4 * in_el; }
             if (l.bits_out_slot >= 0) wr += B * (double)l.out_h * l.out_w * 8.0 * ((l.n + 63) / 64);
         }
