@@ -242,6 +242,11 @@ def test_dog_jpg_fp32_against_the_reference_cpu_fixture():
         # sum of N terms each within 1e-4 relative: compare against the abs-sum scale
         assert abs(o.sum() - sums[i, 0]) <= 1e-4 * sums[i, 1] + 1e-6, "layer %d sum" % i
         assert abs(np.abs(o).sum() - sums[i, 1]) <= 1e-4 * sums[i, 1] + 1e-6, "layer %d abs-sum" % i
+    # the [yolo] head tensors element by element at north_star's 1e-4 (|err| <= 1e-4 |ref| + 1e-4 RMS, common.fp32_close)
+    assert len(z["fp32_head_layers"]) == 2
+    for i in z["fp32_head_layers"]:
+        ok, ratio, worst = fp32_close(net.layer_output(int(i)), z["fp32_head_%d" % int(i)].reshape(-1))
+        assert ok, "head layer %d: err/allowed %.3g at element %d" % (int(i), ratio, worst)
     for key, thresh in (("fp32_dets", 0.24), ("fp32_dets_low", float(z["low_thresh"]))):
         r = z[key]
         g = net.get_boxes(0, sw, sh, thresh, nms=0.4)
