@@ -42,14 +42,9 @@
 #include "kernels.h"
 #include "../../include/yolo2_hip.h"
 
-// X_DBG (build-time timing experiments, -DX_DBG=<bits>; results are garbage): 1 no patch loads in the
-// K loop, 2 no weight loads, 4 no transform / LDS stores, 8 no MFMAs, 16 transform without the patch
-// stores, 32 patch stores without the transform, 64 no barriers inside the K loop, 128 no epilogue, 256 one
-// workgroup per CU (48 KB of dead LDS more), 512 no weight-panel LDS stores in the K loop.  tools/ab_builds.sh runs such builds side by side
-// on one GPU box (DESIGN.md, K1w "what still bounds it").
-#ifndef X_DBG
-#define X_DBG 0
-#endif
+// (The -DX_DBG timing-experiment hooks of rounds 3 / 4 -- no loads, no transform, no MFMAs, one workgroup per CU ... -- left the
+// file in round 5 with the kernel's demotion to the pooled layers; their measurements are in DESIGN.md, K1w, and profiles/r3_wino_ablation.txt,
+// profiles/r4_ab_wino_64x32_ablation_clock.txt; the tree that built them is 446af69.)
 
 namespace yl {
 
@@ -339,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     constexpr bool LS = (VAR & 8) != 0;          // left-edge patches one column early, column masks folded into the transform
     constexpr bool ODDW = (VAR & 16) != 0;       // (with LS) odd map width: the last tile column also masks patch column 2
     static_assert(!(UDMA && PERSIST), "the persistent form stages U through registers");
-    __shared__ __attribute__((aligned(16))) float smem[2 * XPA + 2 * XPB + ((X_DBG & 256) ? 12288 : 0)];      // 48 KB
+    __shared__ __attribute__((aligned(16))) float smem[2 * XPA + 2 * XPB];      // 48 KB
     __shared__ int s_next;
     float *As = smem;
     float *Bs = smem + 2 * XPA;
@@ -467,23 +462,15 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
 #define X_STORE_X(BUF, XR)                                                                             \
     {                                                                                              \
         float va[16];                                                                              \
-        if (!(X_DBG & 32)) {                                                                       \
-            if constexpr (LS) {                                                                    \
-                input_transform32m<ODDW>(XR, va, m0f, m2f, m3f);                                   \
-            } else {                                                                               \
-                fix_rows32(XR, left_s, inv2_s, inv3_s);                                            \
-                input_transform32(XR, va);                                                         \
-            }                                                                                      \
+        if constexpr (LS) {                                                                        \
+            input_transform32m<ODDW>(XR, va, m0f, m2f, m3f);                                       \
         } else {                                                                                   \
-            _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) va[e_] = XR[e_];                     \
+            fix_rows32(XR, left_s, inv2_s, inv3_s);                                                \
+            input_transform32(XR, va);                                                             \
         }                                                                                          \
         float *dst = Bs + (BUF) * XPB + half_s * 256 + kk_s * 128 + t_s * 2;                       \
-        if (!(X_DBG & 16)) {                                                                       \
-            _Pragma("unroll") for (int pr = 0; pr < 8; ++pr)                                       \
-                *reinterpret_cast<float2 *>(dst + pr * 512) = make_float2(va[2 * pr], va[2 * pr + 1]); \
-        } else {                                                                                   \
-            _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) asm volatile("" ::"v"(va[e_]));      \
-        }                                                                                          \
+        _Pragma("unroll") for (int pr = 0; pr < 8; ++pr)                                           \
+            *reinterpret_cast<float2 *>(dst + pr * 512) = make_float2(va[2 * pr], va[2 * pr + 1]); \
     }
 #define X_STORE_U(BUF, UR)                                                                             \
     {                                                                                              \
@@ -556,27 +543,27 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
 #define X_ITER_(KB, SET, DO_STORE, DO_LOAD, FIRST)                                                 \
     {                                                                                              \
         const int buf = (KB) & 1;                                                                  \
-        if (DO_STORE && !UDMA && !(X_DBG & (4 | 512))) X_STORE_U(buf ^ 1, ur)                              \
-        if (DO_STORE && !(X_DBG & 4)) X_STORE_X(buf ^ 1, xr)                                       \
+        if (DO_STORE && !UDMA) X_STORE_U(buf ^ 1, ur)                                              \
+        if (DO_STORE) X_STORE_X(buf ^ 1, xr)                                                        \
         _Pragma("unroll") for (int pp = 0; pp < 8; ++pp)                                           \
-            if (!(X_DBG & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][pp].x, fb[SET][pp][0], (FIRST) ? zero16 : acc[pp], 0, 0, 0); \
-        if (DO_STORE && X_DBG == 0) {                                                              \
+            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][pp].x, fb[SET][pp][0], (FIRST) ? zero16 : acc[pp], 0, 0, 0); \
+        if (DO_STORE) {                                                                            \
             _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                     \
                 X_PIPE(0x002, 9) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                \
             }                                                                                      \
         }                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                         \
         if (UDMA && DO_STORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
-        if (!(X_DBG & 64)) __syncthreads();                                                        \
+        __syncthreads();                                                                           \
         if (DO_STORE) X_READ_FRAGS((SET) ^ 1, buf ^ 1)                                             \
         /* the DMA is issued BEFORE the patch loads: vmcnt retires in order, so waiting for patch row r   */ \
         /* (vmcnt(3 - r)) covers the older DMAs and the rows are still consumed one by one                */ \
-        if (DO_LOAD && UDMA && !(X_DBG & 2)) X_DMA_U((KB) + 2, buf)                                \
-        if (DO_LOAD && !(X_DBG & 1)) X_LOAD_X((KB) + 2, xr)                                        \
-        if (DO_LOAD && !UDMA && !(X_DBG & 2)) X_LOAD_U((KB) + 2, ur)                               \
+        if (DO_LOAD && UDMA) X_DMA_U((KB) + 2, buf)                                                \
+        if (DO_LOAD) X_LOAD_X((KB) + 2, xr)                                                        \
+        if (DO_LOAD && !UDMA) X_LOAD_U((KB) + 2, ur)                                               \
         _Pragma("unroll") for (int pp = 0; pp < 8; ++pp)                                           \
-            if (!(X_DBG & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][pp].y, fb[SET][pp][1], acc[pp], 0, 0, 0); \
-        if (DO_STORE && X_DBG == 0) {                                                              \
+            acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SET][pp].y, fb[SET][pp][1], acc[pp], 0, 0, 0); \
+        if (DO_STORE) {                                                                            \
             _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                     \
                 X_PIPE(0x100, 2) __builtin_amdgcn_sched_group_barrier(UDMA ? 0x010 : 0x020, 1, 0); \
             }                                                                                      \
@@ -617,15 +604,6 @@ __global__ __launch_bounds__(256, 2) void conv_f32_wino32_kernel(ConvWino32Dev p
     // The plane half `ph` is wave-uniform: branch once so that every accumulator index below is a compile-time
     // constant (with a runtime `ph` the compiler indexed the 128 accumulator registers dynamically: 72
     // s_set_gpr_idx pairs and 330 v_mov per wave).
-    if (X_DBG & 128) {          // timing experiment: keep the accumulators alive, store almost nothing
-        float s = 0.f;
-#pragma unroll
-        for (int pp = 0; pp < 8; ++pp)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s += acc[pp][e];
-        if (s == 12345.678f && p.out) p.out[0] = s;
-        return;
-    }
     if (ph) wino32_epilogue<1, APF>(p, acc, smem, wave, lane, e_m0, e_t0);
     else wino32_epilogue<0, APF>(p, acc, smem, wave, lane, e_m0, e_t0);
     if (!PERSIST || nxt < 0) break;
