@@ -500,6 +500,10 @@ def live_pmc_traffic(args, kernel_name: str, mode: str, timeout_s: float = 240.0
     if not os.path.exists(rp):
         return None, "rocprofv3 not found"
     sym = next((v for k, v in _KERNEL_SYMBOL.items() if kernel_name.startswith(k)), None)
+    import re
+    m = re.match(r"conv_f32_(row3|x3)<(\d+)x(\d+)", kernel_name)
+    if m:           # the template instance of THIS tile (a step also launches other tiles of the same kernel on other layers)
+        sym = "conv_f32_%s_kernel<%s, %s," % (m.group(1), m.group(2), m.group(3))
     if sym is None:
         return None, "no kernel symbol known for %s" % kernel_name
     vals = {}
