@@ -115,6 +115,9 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned &p1, unsi
 //         already in registers while the next panel is split into the other stage and the second plane's fragments are
 //         read; barrier; second plane: its MFMAs cover the reads of the NEXT panel's first-plane fragments.  No LDS
 //         latency stands in front of an MFMA block, and no wave waits at the barrier with an idle matrix pipe behind it.
+// SCHED 2: SCHED 1 with the staging work pinned into the shadows of the wave's own MFMAs (sched_group_barrier): left to itself hipcc
+//         issues the ~60 VALU + 9 LDS stores of a panel as one block in front of the MFMAs, and the two waves of a SIMD -- same
+//         workgroup, same barrier -- stage at the same time while the matrix pipe waits (shipped default of the 128 x 128 tile)
 // LOADX2: the input rows as ONE 8-byte load per (tile, channel) -- lane = tile, a wave reads 512 contiguous bytes of a channel row --
 //         and the two outer columns (2t - 1, 2t + 2) from the neighbour lanes by DPP wave_shr:1 / wave_shl:1 (lanes 0 / 63: a
 //         two-lane dword load); false: one 16-byte load per (tile, channel) at an 8-byte lane stride (the first version: every
@@ -123,16 +126,9 @@ template <int BM, int BT, int WM, int WN, int PP, bool MFULL, bool WEVEN, int SC
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) ? 3 : 2) void conv_f32_row3_kernel(ConvRow3Dev p)
 {
     static_assert(SCHED == 0 || PP == 2, "the mid-panel barrier needs two planes per panel");
-    // SCHED 3 (128 x 128, 8 waves, LOADX2): PING-PONG.  The two waves a SIMD holds -- one of each half of the workgroup (waves 0-3 own
-    //          filters 0-63, waves 4-7 filters 64-127) -- never do the same thing at the same time: in every slot ONE half issues the 24
-    //          MFMAs of its share of a panel back to back (fragments of the first plane already in registers, those of the second read
-    //          under the first plane's MFMAs) while the OTHER half stages one plane of the next panel for the whole workgroup (A units,
-    //          input rows -> V -> three pieces -> LDS) and then fetches the first-plane fragments of the panel it computes next; barrier;
-    //          roles swap.  The matrix pipe of a SIMD always has exactly one wave feeding it (MI355X_MICROARCH.md, "Two waves per SIMD"):
-    //          with both waves in step (SCHED 0-2) they stage together and then contend for the pipe together -- measured 52 % busy.
-    // SCHED 2: SCHED 1 with the staging work pinned into the shadows of the wave's own MFMAs (sched_group_barrier): left to itself
-    //          hipcc issues the ~60 VALU + 9 LDS stores of a panel as one block in front of the MFMAs, and the two waves of a SIMD
-    //          -- same workgroup, same barrier -- stage at the same time while the matrix pipe waits
+    // (A ping-pong form -- the two waves of a SIMD alternating between a pure-MFMA slot and a staging slot -- was built and measured in
+    //  round 5: bit-identical, 30 % slower, because without LDS-DMA the staging half's requests sit on every slot's critical path;
+    //  profiles/r5_ab_row3_pingpong.txt.)
     constexpr int NT = WM * WN * 64;
     static_assert(NT == 4 * BT, "one thread per (tile, channel quad)");
     static_assert(!LOADX2 || BT % 64 == 0, "a wave stages 64 consecutive tiles");
@@ -346,137 +342,6 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
     };
 
     int g = 0;
-    if constexpr (SCHED == 3) {
-        static_assert(SCHED != 3 || (BM == 128 && BT == 128 && WM == 2 && WN == 4 && PP == 2 && LOADX2), "ping-pong form");
-        const int hf = wm;                        // half of the workgroup: 0 = waves 0-3, 1 = waves 4-7
-        const int st = tid & 255;                 // staging thread of its half
-        const int qh = wn >> 1;                   // a staging thread owns its tile's channel quads qh and qh + 2
-        // A units of ONE plane: 6 rows (piece, k-octet) x 128 filters = 768 units, three per thread of the staging half
-        const int pa_voff = ((st >> 7) * p.Mpad + (st & 127)) * 16;
-        v4i a3[3];
-        f32x2 rw[2][4];                           // input rows of the two quads: columns 2t, 2t+1 of four channels each
-        float rh[2][4];                           // + the outer column of lanes 0 / 63
-        const int qoff = 8 * HW * 4;              // byte distance of the two quads (eight channels)
-        const int voff0 = voff - (s_q - qh) * 4 * HW * 4;         // the generic mapping put quad s_q into voff
-        const int hvoff0 = hvoff < 0 ? -1 : hvoff - (s_q - qh) * 4 * HW * 4;
-        const int b_lds3 = s_tile * 16 + qh * 8;  // + item * BT * 16 (the item is the k-octet)
-        if constexpr (X_DBG != 0) {
-#pragma unroll
-            for (int e = 0; e < 3; ++e) a3[e] = v4i{0x3f803f80, 0x3f803f80, 0x3f803f80, 0x3f803f80};
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { rw[i][c] = f32x2{1.f, 2.f}; rh[i][c] = 3.f; }
-        }
-        auto pp_load_a = [&](int panel, int pl) {
-            if constexpr ((X_DBG & (1 | 128)) != 0) return;
-#pragma unroll
-            for (int e = 0; e < 3; ++e)
-                a3[e] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(
-                    rs_w, pa_voff, (((panel * 2 + pl) * 6 + e * 2) * p.Mpad + m0) * 16, 0));
-        };
-        auto pp_store_a = [&](int buf, int pl) {
-            if constexpr ((X_DBG & 4) != 0) return;
-#pragma unroll
-            for (int e = 0; e < 3; ++e) As[buf * STAGE_A + pl * 6 * BM + st + e * 256] = __builtin_bit_cast(uint4, a3[e]);
-        };
-        int cur_soff = 0, cur_tinv_ky = 0, cur_ok = 0;        // the group whose rows sit in rw (for its just-in-time outer columns)
-        auto pp_load_raw = [&]() {
-            if constexpr ((X_DBG & (1 | 256)) != 0) return;
-            const int soff = (ld_c0 * HW + ld_ky * p.W) * 4;
-            const int tinv = __builtin_amdgcn_sbfe((int)nrowmask, ld_ky, 1) | (ld_c0 < p.C ? 0 : -1);
-            cur_soff = soff; cur_tinv_ky = ld_ky; cur_ok = ld_c0 < p.C ? 0 : -1;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    rw[i][c] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (voff0 + i * qoff) | tinv, soff + c * HW * 4, 0));
-            ++ld_ky;
-            if (ld_ky == 3) { ld_ky = 0; ld_c0 += 16; }
-        };
-        // the outer column of lanes 0 / 63 for the group in rw: requested when the staging slot begins (the staging half has the slack
-        // to wait for it; kept across slots these eight registers, with the A units, were what spilled)
-        auto pp_load_halo = [&]() {
-            if constexpr ((X_DBG & (1 | 256)) != 0) return;
-            const int tinv = __builtin_amdgcn_sbfe((int)nrowmask, cur_tinv_ky, 1) | cur_ok;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    rh[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                        rsrc, (hvoff0 < 0 ? -1 : hvoff0 + i * qoff) | tinv, cur_soff + c * HW * 4, 0));
-        };
-        // plane xi of the group in rw / rh -> three pieces -> plane slot pl of B stage buf
-        auto pp_stage_b = [&](int buf, int pl, int xi) {
-            if constexpr ((X_DBG & 2) != 0) return;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                float v[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float x = rw[i][c][0], y = rw[i][c][1], h = rh[i][c];
-                    const float l = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, h), __builtin_bit_cast(int, y), 0x138, 0xf, 0xf, false));
-                    const float r = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, h), __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
-                    const float d0 = cm0 ? l : 0.f, d1 = x, d2 = cm2 ? y : 0.f, d3 = cm3 ? r : 0.f;
-                    v[c] = xi == 0 ? d0 - d2 : (xi == 1 ? d1 + d2 : (xi == 2 ? d2 - d1 : d1 - d3));
-                }
-                unsigned a1, a2, a3p, c1, c2, c3;
-                split3_pair(v[0], v[1], a1, a2, a3p);
-                split3_pair(v[2], v[3], c1, c2, c3);
-                char *dst = reinterpret_cast<char *>(Bs + buf * STAGE_B + pl * 6 * BT) + i * BT * 16 + b_lds3;
-                *reinterpret_cast<uint2 *>(dst + 0 * 2 * BT * 16) = make_uint2(a1, c1);
-                *reinterpret_cast<uint2 *>(dst + 1 * 2 * BT * 16) = make_uint2(a2, c2);
-                *reinterpret_cast<uint2 *>(dst + 2 * 2 * BT * 16) = make_uint2(a3p, c3);
-            }
-        };
-        Frags f0, f1;
-        if constexpr ((X_DBG & 16) != 0) { memset(&f0, 0x3f, sizeof(f0)); memset(&f1, 0x3f, sizeof(f1)); }
-        // ---- prologue: panel 0 (planes 0, 1 of group 0) -- half 1 stages plane 0, half 0 plane 1; half 0 fetches its first fragments ----
-        const int my_pl = hf ? 0 : 1;             // the plane (of every panel) this half stages
-        pp_load_a(0, my_pl);
-        pp_load_raw();                            // group 0: used here and again for panel 1
-        pp_load_halo();
-        pp_stage_b(0, my_pl, my_pl);
-        pp_store_a(0, my_pl);
-        __syncthreads();
-        if (hf == 0) read_frags(f0, 0, 0);
-        // slot (panel 2 g + H, R): half R computes the panel from stage H; the other half stages its plane of the NEXT panel into stage
-        // H ^ 1 (A units requested when the slot begins, stored when it ends; the rows of a group serve two panels, then the next group's
-        // are requested)
-        // and fetches the first-plane fragments of the panel IT computes next
-#define ROW3_SLOT(H, R, LASTPANEL, LASTSLOT)                                                       \
-        {                                                                                          \
-            const int pnl = g * 2 + (H);                                                           \
-            if (hf == (R)) {                                                                       \
-                read_frags(f1, (H), 1);                                                            \
-                mfma_plane(f0, (H) * 2);                                                           \
-                mfma_plane(f1, (H) * 2 + 1);                                                       \
-            } else {                                                                               \
-                constexpr int PL = (R) == 0 ? 0 : 1;                                               \
-                if (!(LASTPANEL)) {                                                                \
-                    pp_load_a(pnl + 1, PL);                                                        \
-                    pp_load_halo();                                                                \
-                    pp_stage_b(((H) + 1) & 1, PL, (((H) + 1) & 1) * 2 + PL);                       \
-                    if ((H) == 0) pp_load_raw();                                                   \
-                    pp_store_a(((H) + 1) & 1, PL);                                                 \
-                }                                                                                  \
-                if ((R) == 0) read_frags(f0, (H), 0);                                              \
-                else if (!(LASTPANEL)) read_frags(f0, ((H) + 1) & 1, 0);                           \
-            }                                                                                      \
-            if (!(LASTSLOT) && (X_DBG & 64) == 0) __syncthreads();                                 \
-        }
-        for (; g + 1 < G; ++g) {
-            ROW3_SLOT(0, 0, false, false)
-            ROW3_SLOT(0, 1, false, false)
-            ROW3_SLOT(1, 0, false, false)
-            ROW3_SLOT(1, 1, false, false)
-        }
-        ROW3_SLOT(0, 0, false, false)
-        ROW3_SLOT(0, 1, false, false)
-        ROW3_SLOT(1, 0, true, false)
-        ROW3_SLOT(1, 1, true, true)
-#undef ROW3_SLOT
-    } else {
     // ---- prologue: group 0 -> V, its first panel -> LDS[0]; group 1 requested; A panel 1 -> registers ----
     load_a(0);
     load_raw();
@@ -486,10 +351,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
     store_b(0, 0);
     load_a(1);
     __syncthreads();
-    }
 
-    if constexpr (SCHED == 3) {
-    } else if constexpr (SCHED == 0) {
+    if constexpr (SCHED == 0) {
         // One group = NIT panels.  Panel h of group g (iteration it = g * NIT + h) computes from LDS[h & 1] while the NEXT panel
         // (h + 1 of g, or panel 0 of g + 1 -- then V is re-formed from the raw rows requested one group earlier, and the rows of
         // group g + 2 are requested) is split into LDS[(h + 1) & 1] and the A panel after that travels to registers.
@@ -807,7 +670,7 @@ int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *nam
     switch (tile) {
     case 1: t = "128x128t,pipe"; rc = launch_row3_tile<128, 128, 2, 4, 2, 2>(d, s); break;
     case 2: t = "128x128t,end"; rc = launch_row3_tile<128, 128, 2, 4, 2, 0>(d, s); break;
-    case 3: t = "128x128t,pingpong"; rc = launch_row3_tile<128, 128, 2, 4, 2, 3, true>(d, s); break;
+    case 3: t = "128x128t,pipe,x2"; rc = launch_row3_tile<128, 128, 2, 4, 2, 2, true>(d, s); break;
     case 4: t = "128x64t,mid"; rc = launch_row3_tile<128, 64, 2, 2, 2, 1>(d, s); break;
     case 5: t = "128x64t,pp1"; rc = launch_row3_tile<128, 64, 2, 2, 1, 0>(d, s); break;
     case 6: t = "64x64t,pipe,x2"; rc = launch_row3_tile<64, 64, 2, 2, 2, 2, true>(d, s); break;
