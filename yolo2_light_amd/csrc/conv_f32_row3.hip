@@ -46,7 +46,7 @@
 
 // Lab builds only (tools/ab_builds.sh, ABFILE=conv_f32_row3: -DX_DBG=<bits>; results are garbage by design): 1 no global loads in
 // the K loop, 2 no split / B stores, 4 no A stores, 8 no MFMAs, 16 no fragment reads, 32 no epilogue stores, 64 no barriers in
-// the K loop, 128 no A (weight) loads, 256 no input-row loads.  The shipped library is built with X_DBG undefined: every guard
+// the K loop, 128 no A (weight) loads, 256 no input-row loads (+512: their transform + split stay in the loop).  The shipped library is built with X_DBG undefined: every guard
 // below folds away.
 #ifndef X_DBG
 #define X_DBG 0
@@ -226,7 +226,15 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
 
     // (always issued: past the last group the lane offsets are all-ones and the range check answers without touching memory)
     auto load_raw = [&]() {
-        if constexpr ((X_DBG & (1 | 256)) != 0) return;
+        if constexpr ((X_DBG & (1 | 256)) != 0) {
+            if constexpr ((X_DBG & 512) != 0) {        // 512: keep the transform + split in the loop (the skipped loads' registers become opaque)
+#pragma unroll
+                for (int i = 0; i < (LOADX2 ? 1 : 4); ++i) asm volatile("" : "+v"(raw[i]));
+#pragma unroll
+                for (int i = 0; i < (LOADX2 ? 4 : 1); ++i) asm volatile("" : "+v"(rw2[i]), "+v"(rwh[i]));
+            }
+            return;
+        }
         const int soff = (ld_c0 * HW + ld_ky * p.W) * 4;
         const int tinv = __builtin_amdgcn_sbfe((int)nrowmask, ld_ky, 1) | (ld_c0 < p.C ? 0 : -1);
         if constexpr (LOADX2) {
