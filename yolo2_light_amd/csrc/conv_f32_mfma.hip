@@ -580,9 +580,9 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o_in, void *stream,
         ((wino_takes && (o.variant & 2048)) || row3_tile))
         return launch_conv_f32_row3(a, row3_tile, stream, name, name_len);
     if (!wino_takes && a.x3_w && (a.out || a.add) && !a.q_out && !a.pool_out && !a.bits_out && (a.yolo_entries == 0 || (a.size == 1 && !a.add)) &&
-        ((o.force_tile == 0 && (o.variant & 1024) && a.M > 32) || (o.force_tile >= 51 && o.force_tile <= 54)))
-        return launch_conv_f32_x3(a, o.force_tile >= 51 ? o.force_tile - 50 : 0, stream, name, name_len);
-    if (o.force_tile >= 51 && o.force_tile <= 54) return (int)hipErrorInvalidValue;
+        ((o.force_tile == 0 && (o.variant & 1024) && a.M > 32) || (o.force_tile >= 51 && o.force_tile <= 55)))
+        return launch_conv_f32_x3(a, o.force_tile >= 51 ? o.force_tile - 50 : 0, stream, name, name_len, (o.variant & 4096) != 0);
+    if (o.force_tile >= 51 && o.force_tile <= 55) return (int)hipErrorInvalidValue;
     if (a.yolo_entries > 0)                                           // folded [yolo]: 1x1 direct kernel, two tiles
         return launch_conv_f32_direct(a, (o.force_tile == 14 || o.force_tile == 22 || o.force_tile == 20) ? o.force_tile - 10 :
                                       (((long long)((a.M + 127) / 128) * (((long long)a.B * a.OH * a.OW + 255) / 256) >= 384) ? 10 :

@@ -107,7 +107,7 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned &p1, unsi
 // KS: 1 / 3 = the layer's filter size (compile-time tap decode), 0 = any size <= 5
 // YOLO: rows m with m % yolo_entries not in {2, 3} get logistic_activate (forward_yolo_layer_cpu; the expression of
 // yolo_kernel in layers.hip, so the tensor is bit-identical to the unfused pair of layers)
-template <int BM, int BN, int WM, int WN, int KS, bool MFULL, bool YOLO = false>
+template <int BM, int BN, int WM, int WN, int KS, bool MFULL, bool YOLO = false, bool PIPE = false>
 // (occupancy as before the straight-line epilogue: 148 VGPRs = three waves per SIMD at 128 x 128, four at 64 x 128 -- hipcc otherwise
 // computes all 64 outputs of a block at once and takes 192-244 registers)
 __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : (BM == 64 ? (BN == 64 ? 3 : 4) : 2)) void conv_f32_x3_kernel(ConvX3Dev p)
@@ -299,6 +299,18 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : (BM ==
                 _Pragma("unroll") for (int j = 0; j < TN; ++j)                                     \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[TA[t]][i]), \
                                                                         __builtin_bit_cast(bf16x8, bv[TB[t]][j]), acc[i][j], 0, 0, 0); \
+        if (PIPE && (DO_STORE) && X_DBG == 0) {                                                    \
+            /* PIPE: the fragment reads first, then the split / LDS stores / requests pinned between the MFMAs (conv_f32_row3.hip's */ \
+            /* schedule; masks 0x008 MFMA, 0x002 VALU, 0x020 VMEM read, 0x100 DS read, 0x200 DS write) */ \
+            __builtin_amdgcn_sched_group_barrier(0x100, 3 * (TM + TN), 0);                         \
+            _Pragma("unroll") for (int i_ = 0; i_ < 6 * TM * TN; ++i_) {                           \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                 \
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);                                 \
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                 \
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                 \
+            }                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }                                                                                          \
     }
 
     int kb = 0;
@@ -398,7 +410,7 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : (BM ==
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool PIPE = false>
 int launch_x3_tile(ConvX3Dev p, hipStream_t s)
 {
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -408,8 +420,8 @@ int launch_x3_tile(ConvX3Dev p, hipStream_t s)
     const bool mfull = (p.M % BM) == 0;
 #define X3_GO(KS)                                                                                  \
     {                                                                                              \
-        if (mfull) hipLaunchKernelGGL((conv_f32_x3_kernel<BM, BN, WM, WN, KS, true>), grid, block, 0, s, p); \
-        else hipLaunchKernelGGL((conv_f32_x3_kernel<BM, BN, WM, WN, KS, false>), grid, block, 0, s, p); \
+        if (mfull) hipLaunchKernelGGL((conv_f32_x3_kernel<BM, BN, WM, WN, KS, true, false, PIPE>), grid, block, 0, s, p); \
+        else hipLaunchKernelGGL((conv_f32_x3_kernel<BM, BN, WM, WN, KS, false, false, PIPE>), grid, block, 0, s, p); \
     }
     if (p.size == 1 && p.yolo_entries > 0) {
         if (mfull) hipLaunchKernelGGL((conv_f32_x3_kernel<BM, BN, WM, WN, 1, true, true>), grid, block, 0, s, p);
@@ -462,8 +474,9 @@ void x3_pack_weights(const float *w, int C, int M, int size, void *dst)
             }
 }
 
-// tile: 0 = heuristic, 1 = 128x128 (wave tile 64x64), 2 = 64x128 (32x64), 3 = 32x256 (32x64), 4 = 64x64 (two waves of 32x64: small grids)
-int launch_conv_f32_x3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len)
+// tile: 0 = heuristic, 1 = 128x128 (wave tile 64x64), 2 = 64x128 (32x64), 3 = 32x256 (32x64), 4 = 64x64 (two waves of 32x64: small grids),
+// 5 = 128x128 without the pinned schedule (A/B)
+int launch_conv_f32_x3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len, bool plain)
 {
     if (!a.x3_w || !x3_applicable(a.C, a.M, a.size, a.stride, a.pad) || (!a.out && !a.add) || (a.add && !a.out_add) || a.q_out ||
         a.bits_out || a.pool_out || (a.yolo_entries > 0 && (a.size != 1 || a.add)))
@@ -498,11 +511,15 @@ int launch_conv_f32_x3(const ConvF32Args &a, int tile, void *stream, char *name,
     }
     const char *t = "?";
     int rc;
+    // every tile runs the pinned schedule (round 5: -8 ... -11 % per launch stand-alone on all of yolov3's direct shapes,
+    // profiles/r5_ab_x3_pinned_schedule.txt; same bits); `plain` (variant bit 12, or tile 5) keeps hipcc's own order for A/B runs
+    if (plain && tile == 1) tile = 5;
     switch (tile) {
-    case 1: t = "128x128"; rc = launch_x3_tile<128, 128, 2, 2>(d, s); break;
-    case 2: t = "64x128"; rc = launch_x3_tile<64, 128, 2, 2>(d, s); break;
+    case 1: t = "128x128"; rc = launch_x3_tile<128, 128, 2, 2, true>(d, s); break;
+    case 2: t = "64x128"; rc = plain ? launch_x3_tile<64, 128, 2, 2>(d, s) : launch_x3_tile<64, 128, 2, 2, true>(d, s); break;
     case 3: t = "32x256"; rc = launch_x3_tile<32, 256, 1, 4>(d, s); break;
     case 4: t = "64x64"; rc = launch_x3_tile<64, 64, 2, 1>(d, s); break;
+    case 5: t = "128x128,plain"; rc = launch_x3_tile<128, 128, 2, 2>(d, s); break;
     default: return (int)hipErrorInvalidValue;
     }
     if (name) snprintf(name, name_len, "conv_f32_x3<%s,ks%d%s>", t, a.size, a.yolo_entries > 0 ? ",yolo" : "");

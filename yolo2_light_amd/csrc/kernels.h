@@ -14,6 +14,7 @@ namespace yl {
 // tile + 0.063 ms of [maxpool] -> 0.119 ms with the pooling folded into the Winograd epilogue; config 2 +7.8 %)
 // bit 10 (round 4): the direct FP32 layers on the BF16 matrix pipe with three-piece operands (K1x, conv_f32_x3.hip): +1.8 ... +7 %
 // on the step depending on the box (the kernel drives the chip into its power cap), same accuracy against float64
+// bit 12 (round 5, A/B only, off): K1x without its pinned schedule
 // bit 11 (round 5): the 3x3 / stride-1 layers as row-wise Winograd F(2,3) on the BF16 matrix pipe with three-piece operands (K1r,
 // conv_f32_row3.hip) instead of F(2x2,3x3) on the FP32 matrix instruction
 constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8 | 16 | 32 | 1024 | 2048;
@@ -81,7 +82,7 @@ bool wino32_fits(int B, int M, int H, int W);     // output tensor below 4 GB (3
 bool x3_applicable(int C, int M, int size, int stride, int pad);
 size_t x3_packed_bytes(int C, int M, int size);
 void x3_pack_weights(const float *w, int C, int M, int size, void *dst);
-int launch_conv_f32_x3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len);
+int launch_conv_f32_x3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len, bool plain = false);
 // K1r (conv_f32_row3.hip): 3x3 / stride 1 / pad 1 as row-wise Winograd F(2,3) on the BF16 matrix pipe, three-piece operands
 bool row3_applicable(int C, int M, int size, int stride, int pad);
 size_t row3_packed_bytes(int C, int M);
