@@ -19,7 +19,7 @@
 // 6 / 1.5 = 4 BF16 MFMAs per 16 k and tap triple -- 136 matrix-pipe cycles where FP32 F(2x2,3x3) needs 228 and K1x 204.
 // Accuracy: the transforms only add and subtract (U's halves are formed in double), the split is exact, the dropped
 // cross terms a2 b3 + a3 b2 + a3 b3 are ~2^-26 |a b| rms, <= 2^-23 |a b| worst case (conv_f32_x3.hip); checked against the oracle and against a
-// float64 convolution like the other FP32 kernels (tests/test_gpu_parity.py).
+// float64 convolution like the other FP32 kernels (tests/test_gpu_row3.py, tests/test_gpu_parity.py::test_fp32_error_vs_float64_truth).
 //
 //   tiles        n = (b * H + oy) * TW + tx, TW = ceil(W / 2); a workgroup owns BM filters x BT consecutive tiles x 4 planes
 //   K order      groups g = (channel block c / 16, ky); a panel = PP planes of one group (PP = 2: two panels per group)
@@ -35,7 +35,12 @@
 //                with conv_f32_mfma.hip's arithmetic, fused [shortcut]
 //
 // Applicability: size 3, stride 1, pad 1, C % 16 == 0, the input tensor library-owned (front pad: the left-edge tile of
-// the first row reads one float in front of the tensor, multiplied out by a select).
+// the first row reads one float in front of the tensor, selected away; the last tile of the last row up to two floats
+// behind it: yl_internal.h ACT_FRONT_PAD / ACT_TAIL_PAD).
+//
+// Measured on MI355X, yolov3-608 batch 64: 0.83-0.87 ms per launch in the network where the FP32 Winograd kernel took
+// 1.06-1.08; 0.42 of the BF16 matrix peak issued (0.52 at the 1.94 GHz the part grants); the kernel is power-bound, and operand
+// traffic is what the power buys (profiles/r5_clock_power_row3_loads.txt).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
@@ -46,8 +51,8 @@
 
 // Lab builds only (tools/ab_builds.sh, ABFILE=conv_f32_row3: -DX_DBG=<bits>; results are garbage by design): 1 no global loads in
 // the K loop, 2 no split / B stores, 4 no A stores, 8 no MFMAs, 16 no fragment reads, 32 no epilogue stores, 64 no barriers in
-// the K loop, 128 no A (weight) loads, 256 no input-row loads (+512: their transform + split stay in the loop).  The shipped library is built with X_DBG undefined: every guard
-// below folds away.
+// the K loop, 128 no A (weight) loads, 256 no input-row loads (+512: their transform + split stay in the loop).  The shipped
+// library is built with X_DBG undefined: every guard below folds away.
 #ifndef X_DBG
 #define X_DBG 0
 #endif
