@@ -27,8 +27,16 @@ SHAPES_608 = [
 ]
 
 
+# the 3x3 / stride-1 layers of yolov3-tiny at 416x416 that K1r takes (no fused [maxpool]) and its 1x1 layers
+SHAPES_TINY_416 = [
+    (1, 512, 256, 3, 1, 13), (1, 1024, 512, 3, 1, 13), (1, 512, 256, 3, 1, 13), (1, 256, 384, 3, 1, 26),
+    (1, 256, 1024, 1, 1, 13), (1, 255, 512, 1, 1, 13), (1, 128, 256, 1, 1, 13), (1, 255, 256, 1, 1, 26),
+]
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--set", default="yolov3-608", choices=["yolov3-608", "yolov3-tiny-416"], help="which network's conv shapes")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--tiles", default="0,12,14,20,22,31",
                     help="forced tile ids: 11..22 = direct kernel tiles, 0 = heuristic, 31 = Winograd (3x3/1/1 only)")
@@ -45,13 +53,14 @@ def main():
     from yolo2_light_amd import Network
 
     tiles = [int(t) for t in args.tiles.split(",")]
-    only = [int(i) for i in args.only.split(",")] if args.only else range(len(SHAPES_608))
+    shapes = SHAPES_608 if args.set == "yolov3-608" else SHAPES_TINY_416
+    only = [int(i) for i in args.only.split(",")] if args.only else range(len(shapes))
     rng = np.random.default_rng(0)
     B = args.batch
     total_best = 0.0
     total_flops = 0.0
     for si in only:
-        cnt, M, Cc, size, stride, H = SHAPES_608[si]
+        cnt, M, Cc, size, stride, H = shapes[si]
         pad = size // 2
         K = Cc * size * size
         wts = rng.normal(0, np.sqrt(2.0 / K), M * K).astype(np.float32)

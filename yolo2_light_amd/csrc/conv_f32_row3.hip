@@ -666,16 +666,27 @@ int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *nam
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
             n_cu = v;
         }
-        auto per_cu = [&](int bm, int bt) {
+        // cost of a tile in units of one 128 x 128 workgroup's life: W = a workgroup of that tile alone on a CU, f[k-1] = its slowdown
+        // with k of them resident (128 x 64: two fit a CU, 64 x 64: three); beyond that, rounds.  Fitted on both regimes -- yolov3-608 at
+        // batch 64 (3 ... 91 workgroups per CU: 128x128 wins everywhere) and grids below the chip (yolov3-tiny 416 at batch 32,
+        // yolov3 at 8 images: profiles/r5_sweep_row3_tiles_b64.txt, r5_small_grid_tiles_b8.txt, r5_sweep_tiny_416_b32_tiles.txt), where a
+        // layer's time is ONE workgroup's K loop and the question is only how many of them share a CU.
+        auto cost = [&](int bm, int bt, double W, int resident, const double *f) {
             const long long nwg = (long long)((a.M + bm - 1) / bm) * ((nt + bt - 1) / bt);
-            return (double)((nwg + n_cu - 1) / n_cu);
+            const long long per = (nwg + n_cu - 1) / n_cu;                  // workgroups on the busiest CU
+            if (per <= resident) return W * f[per - 1];
+            // more than fit at once: rounds -- whole ones for the busiest CU, fractional ones on average (the dispatcher refills a CU as
+            // soon as a workgroup leaves, and the tail runs with fewer neighbours): the mean of the two matches the sweeps
+            const double whole = (double)((per + resident - 1) / resident), mean = (double)nwg / ((double)n_cu * resident);
+            return (resident == 1 ? whole : 0.5 * (whole + mean)) * W * f[resident - 1];
         };
+        static const double f128[1] = {1.0}, f128x64[2] = {1.0, 1.46}, f64[3] = {1.0, 1.4, 2.1};
         if (a.M <= 64) tile = 7;
         else {
-            const double c128 = per_cu(128, 128) * 1.0, c64t = per_cu(128, 64) * 0.5 * 1.09, c64 = per_cu(64, 64) * 0.25 * 1.23;
+            const double c128 = cost(128, 128, 1.0, 1, f128), c64t = cost(128, 64, 0.79, 2, f128x64), c64 = cost(64, 64, 0.53, 3, f64);
             tile = (c128 <= c64t && c128 <= c64) ? 1 : (c64t <= c64 ? 4 : 7);
             // (a finer 64x32 tile was measured at 8 images per GPU and gains nothing: below one workgroup per CU a layer's time
-            //  is one workgroup's K loop -- 96 groups at 19 x 19 -- whatever the tile; profiles/r5_small_grid_tiles_b8.txt)
+            //  is one workgroup's K loop -- 96 groups at 19 x 19 -- whatever the tile)
         }
     }
     const char *t = "?";
