@@ -305,7 +305,7 @@ int yl_network_pull_heads(yl_network *net);
  *   0 = built-in heuristic (default), 11..22 = direct implicit-GEMM tile 1..12 (conv_f32_mfma.hip),
  *   31 = Winograd F(2x2,3x3) (conv_f32_wino32.hip; a launch fails on layers it does not apply to),
  *   41 = LDS-free first-layer kernel (conv_f32_smallk.hip; C*size^2 <= 32 and filters <= 32 only),
- *   51..55 = the three-piece BF16 kernel's tiles (conv_f32_x3.hip), 61..69 = the row-wise Winograd kernel's tiles and
+ *   51..55 = the three-piece BF16 kernel's tiles (conv_f32_x3.hip), 61..70 = the row-wise Winograd kernel's tiles and
  *   schedules (conv_f32_row3.hip; 3x3 / stride 1 / pad 1 layers with C % 16 == 0 only).
  * yl_network_set_winograd: 0 = never pick Winograd heuristically and do not pack its weights, 1 = default;
  *   BEFORE yl_network_to_device.
@@ -323,7 +323,8 @@ int yl_network_set_conv_tile(yl_network *net, int cfg);
  * pipe with every operand as the exact sum of three bf16 pieces (conv_f32_x3.hip; FP32 tensors, FP32-class accuracy),
  * bit 11 the 3x3 / stride-1 layers Winograd would take as ROW-WISE Winograd F(2,3) on the BF16 matrix pipe, three-piece
  * operands (conv_f32_row3.hip) instead of F(2x2,3x3) on the FP32 matrix instruction, bit 12 (A/B only) conv_f32_x3.hip without its
- * pinned schedule (same bits);
+ * pinned schedule (same bits), bit 13 (off) conv_f32_row3.hip's 128 x 128 tile in its "view" form on maps up to 126 wide -- the
+ * transformed rows staged once per channel block instead of once per filter row; same bits, +0.2 ... +0.6 % in the network;
  * -1 = built-in default (bits 1-5, 10 and 11) */
 int yl_network_set_variant(yl_network *net, int bits);
 /* Opt-in BF16 variant of the FP32 path (north_star (a) "FP32/BF16"; BEFORE yl_network_to_device): every FP32

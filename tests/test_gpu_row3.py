@@ -13,7 +13,7 @@ from common import Network, fp, fp32_close
 
 pytestmark = pytest.mark.gpu
 
-ROW3_TILES = list(range(61, 70))         # yl_network_set_conv_tile: 61..69 = conv_f32_row3.hip's tiles and schedules
+ROW3_TILES = list(range(61, 71))         # yl_network_set_conv_tile: 61..69 = conv_f32_row3.hip's tiles and schedules, 70 = its view form
 
 ROW3_SHAPES = [
     # B, C, H, W, M, act
@@ -26,6 +26,7 @@ ROW3_SHAPES = [
     (4, 128, 6, 10, 255, D.LINEAR),        # M = 255, a tile block spans images
     (9, 16, 5, 5, 16, D.LEAKY),            # 15 tiles per image: a block of 128 tiles spans 9 images, mostly empty
     (1, 16, 4, 4, 8, D.LEAKY),             # the smallest layer the dispatcher sends here
+    (2, 32, 5, 125, 40, D.LEAKY),          # 63 tiles per row: the widest map the view form takes (128 + 2 * 63 = 254 entries), odd width
 ]
 
 
@@ -50,7 +51,7 @@ def _single(shape, wts, bias, variant=0):
 
 
 @pytest.mark.parametrize("shape", ROW3_SHAPES)
-@pytest.mark.parametrize("tile", [61, 62, 63, 64, 65, 66, 67, 68])
+@pytest.mark.parametrize("tile", [61, 62, 63, 64, 65, 66, 67, 68, 70])
 def test_conv_row3_vs_oracle(olib, shape, tile):
     B, Cc, H, W, M, act = shape
     wts, bias, x = _layer(shape, 2718)
@@ -82,7 +83,8 @@ def test_conv_row3_vs_oracle(olib, shape, tile):
 
 @pytest.mark.parametrize("shape", ROW3_SHAPES)
 def test_row3_tiles_and_schedules_bit_identical(shape):
-    """nine instances (workgroup tile, planes per panel, where the barrier sits): the same products in the same order"""
+    """ten instances (workgroup tile, planes per panel, where the barrier sits, V staged per filter row or once per channel block): the same
+    products in the same order"""
     wts, bias, x = _layer(shape, 31415)
     net, _ = _single(shape, wts, bias)
     base = None
@@ -125,6 +127,20 @@ def test_row3_fused_shortcut_is_bit_identical(width, height, act):
     assert not fused.layer_materialised(1)
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     plain.close(); fused.close()
+
+
+def test_row3_view_form_falls_back_on_wide_maps():
+    """more than 63 tiles per row: tile 70 runs the pinned 128 x 128 tile (a view would span more than 254 entries), same bits"""
+    shape = (1, 16, 4, 130, 24, D.LEAKY)
+    wts, bias, x = _layer(shape, 99)
+    net, _ = _single(shape, wts, bias)
+    net.set_conv_tile(61)
+    a = net.predict(x).copy()
+    net.set_conv_tile(70)
+    b = net.predict(x).copy()
+    assert net.layer_kernel(0) == "conv_f32_row3<128x128t,pipe>", net.layer_kernel(0)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    net.close()
 
 
 def test_row3_batch_items_independent():
@@ -170,6 +186,25 @@ def test_row3_whole_network_yolov3():
         assert ra.shape == rr.shape and np.allclose(ra, rr, rtol=1e-4, atol=1e-5)
         assert np.array_equal(ra, b.get_boxes(im, width, height, 0.24, nms=0.4))
     ref.close(); a.close(); b.close()
+
+
+def test_row3_view_form_by_variant_bit_is_bit_identical():
+    """variant bit 13: the heuristic takes the view form wherever it would take the pinned 128 x 128 tile (a grid that fills the chip
+    several times over), and nowhere else; same bits as the default variant"""
+    shape = (8, 64, 76, 76, 512, D.LEAKY)
+    wts, bias, x = _layer(shape, 4)
+    a, _ = _single(shape, wts, bias, variant=-1)
+    v, _ = _single(shape, wts, bias, variant=common.VARIANT_DEFAULT | 8192)
+    ya, yv = a.predict(x).copy(), v.predict(x).copy()
+    assert a.layer_kernel(0) == "conv_f32_row3<128x128t,pipe>" and v.layer_kernel(0) == "conv_f32_row3<128x128t,view>", (a.layer_kernel(0), v.layer_kernel(0))
+    assert np.array_equal(ya.view(np.uint32), yv.view(np.uint32))
+    a.close(); v.close()
+    small = (2, 32, 19, 19, 70, D.LINEAR)                # below the chip: the 64 x 64 tile either way
+    wts, bias, x = _layer(small, 5)
+    v, _ = _single(small, wts, bias, variant=common.VARIANT_DEFAULT | 8192)
+    v.predict(x)
+    assert "view" not in v.layer_kernel(0) and "conv_f32_row3<" in v.layer_kernel(0), v.layer_kernel(0)
+    v.close()
 
 
 @pytest.mark.parametrize("size,tile", [(1, 51), (3, 61)])

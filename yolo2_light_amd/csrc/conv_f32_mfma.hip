@@ -538,7 +538,7 @@ static int launch_conv_f32_direct(const ConvF32Args &a, int cfg, int variant, vo
 bool conv_f32_pool_fusable(const ConvF32Args &a0, const ConvF32Opts &o_in)
 {
     ConvF32Opts o = o_in;
-    if (o.force_tile >= 61 && o.force_tile <= 69) o.force_tile = 0;      // K1r's tile choice: every other layer keeps the heuristic
+    if (o.force_tile >= 61 && o.force_tile <= 70) o.force_tile = 0;      // K1r's tile choice: every other layer keeps the heuristic
     ConvF32Args a = a0;
     a.pool_out = nullptr;
     if (a.q_out || a.bits_out || a.add || a.yolo_entries > 0 || ((a.H | a.W) & 1) || a.OH != a.H || a.OW != a.W) return false;
@@ -552,11 +552,11 @@ bool conv_f32_pool_fusable(const ConvF32Args &a0, const ConvF32Opts &o_in)
 // 1..12 of launch_conv_f32_direct, 31 = Winograd (error if the layer has no packed U).
 int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o_in, void *stream, char *name, size_t name_len)
 {
-    // force_tile 61..69 picks the tile / schedule of K1r WHERE a layer qualifies for it; every other layer of the network
+    // force_tile 61..70 picks the tile / schedule of K1r WHERE a layer qualifies for it; every other layer of the network
     // keeps the heuristic (a whole network can be swept with one setting)
     ConvF32Opts o = o_in;
     int row3_tile = 0;
-    if (o.force_tile >= 61 && o.force_tile <= 69) { row3_tile = o.force_tile - 60; o.force_tile = 0; }
+    if (o.force_tile >= 61 && o.force_tile <= 70) { row3_tile = o.force_tile - 60; o.force_tile = 0; }
     // measured on MI355X (tools/sweep_conv.py, yolov3-608 shapes, B=64): with 32 input channels
     // ([64,288,92416]) Winograd wins stand-alone (1.59 vs 2.16 ms) but not in the network, where the
     // layer carries a fused shortcut and is bound by 3 GB of epilogue traffic (2.31 vs 2.2 ms): C >= 64.
@@ -575,10 +575,10 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o_in, void *stream,
     const bool wino_takes = a.wino32_u && (o.force_tile == 31 || (o.force_tile == 0 && o.winograd &&
         a.C >= ((o.variant & 32) ? 16 : ((o.variant & 16) ? 32 : 64)) && wino32_fits(a.B, a.M, a.H, a.W)));
     // K1r: the 3x3 / stride-1 layers as row-wise Winograd F(2,3) on the BF16 matrix pipe with three-piece operands (variant bit
-    // 11; force_tile 61..69 = its tiles); the layers with a pooled output keep the 2-D Winograd kernel (an F(2x2) tile is a window)
+    // 11; force_tile 61..70 = its tiles); the layers with a pooled output keep the 2-D Winograd kernel (an F(2x2) tile is a window)
     if (a.row3_w && a.in_front_pad && !a.pool_out && !a.q_out && !a.bits_out && a.yolo_entries == 0 && (a.out || a.add) && o.force_tile == 0 &&
         ((wino_takes && (o.variant & 2048)) || row3_tile))
-        return launch_conv_f32_row3(a, row3_tile, stream, name, name_len);
+        return launch_conv_f32_row3(a, row3_tile, stream, name, name_len, (o.variant & 8192) != 0);
     if (!wino_takes && a.x3_w && (a.out || a.add) && !a.q_out && !a.pool_out && !a.bits_out && (a.yolo_entries == 0 || (a.size == 1 && !a.add)) &&
         ((o.force_tile == 0 && (o.variant & 1024) && a.M > 32) || (o.force_tile >= 51 && o.force_tile <= 55)))
         return launch_conv_f32_x3(a, o.force_tile >= 51 ? o.force_tile - 50 : 0, stream, name, name_len, (o.variant & 4096) != 0);

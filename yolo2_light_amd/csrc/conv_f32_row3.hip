@@ -113,6 +113,125 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned &p1, unsi
     p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2));
 }
 
+// The epilogue every K1r kernel shares (MFMA C/D layout): Y(2t) = (M0 + M1) + M2, Y(2t+1) = (M1 - M2) - M3, + bias, activation, FP32 NCHW,
+// fused [shortcut].  acc[plane][i][j]: blocks of 32 filters x 32 tiles at (m0 + wm0 + 32 i, n0 + wn0 + 32 j).
+template <int TM, int TN, bool MFULL, bool WEVEN>
+__device__ __forceinline__ void row3_epilogue(const ConvRow3Dev &p, const f32x16 (&acc)[4][TM][TN], const float *bias_s, int m0, int n0, int wm0, int wn0)
+{
+    const int HW = p.H * p.W;
+    // (the lane's coordinates are derived again from threadIdx.x: kept alive across the K loop they are what the ping-pong form,
+    //  at 256 registers, spilled)
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int l31_e = tid_e & 31, half_e = (tid_e >> 5) & 1;
+    const int ob_first = __builtin_amdgcn_readfirstlane((n0 + wn0) / p.HTW);
+    int voff_o[TN];
+    bool px1[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + l31_e;
+        const int ob = n / p.HTW;
+        const int orem = n - ob * p.HTW;
+        const int ooy = orem / p.TW;
+        const int otx = orem - ooy * p.TW;
+        voff_o[j] = n < p.Ntiles ? (int)(((unsigned)(ob - ob_first) * (unsigned)p.M * (unsigned)HW + (unsigned)ooy * (unsigned)p.W +
+                                          (unsigned)(2 * otx) + 4u * (unsigned)half_e * (unsigned)HW) * 4u) : -1;
+        px1[j] = n < p.Ntiles && (WEVEN || (2 * otx + 1 < p.W));      // (a tile past the end has voff_o = -1: -1 + 4 would be a valid offset)
+    }
+    const size_t img_out = (size_t)p.M * HW;
+    size_t orec = ((size_t)p.B - ob_first) * img_out * 4;
+    if (orec > 0xFFFFFFFEull) orec = 0xFFFFFFFEull;
+    const bool has_out = p.out != nullptr && (X_DBG & 32) == 0, has_add = p.add != nullptr && (X_DBG & 32) == 0;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(has_out ? p.out + (size_t)ob_first * img_out : (float *)p.bias), 0, has_out ? (int)(unsigned)orec : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(has_add ? p.add + (size_t)ob_first * img_out : p.bias), 0, has_add ? (int)(unsigned)orec : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_oadd = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(has_add ? p.out_add + (size_t)ob_first * img_out : (float *)p.bias), 0, has_add ? (int)(unsigned)orec : 0, 0x00020000);
+    const int row_bytes = HW * 4;
+    const bool leaky = p.act == YL_LEAKY;
+    // one wave-uniform branch picks the output form; inside it the [shortcut] operand of a whole 32 x 32 block is requested
+    // before the block's arithmetic (MODE 0: out, 1: out_add only, 2: both)
+    auto epilogue = [&](auto mode_tag, auto leaky_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool LEAKY = decltype(leaky_tag)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float bias_r[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) bias_r[e] = bias_s[wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half_e];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int e0 = 0; e0 < 16; e0 += 8) {         // eight accumulator rows at a time: their [shortcut] operands first
+                    int vo[8], vo1[8];
+                    f32x2 addv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int e = e0 + k;
+                        const int mrow = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2);
+                        const bool ok = MFULL || (mrow + 4 * half_e) < p.M;
+                        vo[k] = ok ? voff_o[j] : -1;
+                        vo1[k] = (ok && px1[j]) ? voff_o[j] + 4 : -1;
+                        if constexpr (MODE >= 1) {
+                            if constexpr (WEVEN)
+                                addv[k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_add, vo[k], mrow * row_bytes, 0));
+                            else {
+                                addv[k][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_add, vo[k], mrow * row_bytes, 0));
+                                addv[k][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_add, vo1[k], mrow * row_bytes, 0));
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int e = e0 + k;
+                        const float q0 = acc[0][i][j][e], q1 = acc[1][i][j][e], q2 = acc[2][i][j][e], q3 = acc[3][i][j][e];
+                        float y0 = ((q0 + q1) + q2) + bias_r[e];
+                        float y1 = ((q1 - q2) - q3) + bias_r[e];
+                        if constexpr (LEAKY) {
+                            // (float)(.1 * (double)x), conv_f32_mfma.hip's arithmetic, as three conversions / multiplies and a select:
+                            // left as a ternary hipcc branches around the double-precision path for every output
+                            float t0 = (float)(.1 * (double)y0), t1 = (float)(.1 * (double)y1);
+                            asm volatile("" : "+v"(t0), "+v"(t1));
+                            y0 = (y0 > 0.f) ? y0 : t0;
+                            y1 = (y1 > 0.f) ? y1 : t1;
+                        }
+                        const int mrow = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2);
+                        if constexpr (MODE != 1) {
+                            if constexpr (WEVEN) {
+                                const f32x2 y = {y0, y1};
+                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, y), rs_out, vo[k], mrow * row_bytes, 0);
+                            } else {
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y0), rs_out, vo[k], mrow * row_bytes, 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y1), rs_out, vo1[k], mrow * row_bytes, 0);
+                            }
+                        }
+                        if constexpr (MODE >= 1) {
+                            const float s0 = __fadd_rn(y0, addv[k][0]), s1 = __fadd_rn(y1, addv[k][1]);
+                            if constexpr (WEVEN) {
+                                const f32x2 y = {s0, s1};
+                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, y), rs_oadd, vo[k], mrow * row_bytes, 0);
+                            } else {
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s0), rs_oadd, vo[k], mrow * row_bytes, 0);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s1), rs_oadd, vo1[k], mrow * row_bytes, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+    if (leaky) {
+        if (!has_add) epilogue(std::integral_constant<int, 0>{}, std::true_type{});
+        else if (!has_out) epilogue(std::integral_constant<int, 1>{}, std::true_type{});
+        else epilogue(std::integral_constant<int, 2>{}, std::true_type{});
+    } else {
+        if (!has_add) epilogue(std::integral_constant<int, 0>{}, std::false_type{});
+        else if (!has_out) epilogue(std::integral_constant<int, 1>{}, std::false_type{});
+        else epilogue(std::integral_constant<int, 2>{}, std::false_type{});
+    }
+}
+
 // BM x BT: filters x tiles of a workgroup; WM x WN waves, each TM x TN blocks of 32 x 32 for all four planes;
 // PP: planes per LDS panel (1 or 2); MFULL: M % BM == 0; WEVEN: W even (Y pairs are 8-byte aligned and always whole)
 // SCHED 0: one barrier at the end of a panel, the fragments of a panel are read after it (conv_f32_x3.hip's loop)
@@ -448,118 +567,276 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
 #undef ROW3_PANEL
     }
 
-    // ---- epilogue (C/D layout): Y(2t) = (M0 + M1) + M2, Y(2t+1) = (M1 - M2) - M3, + bias, activation, FP32 NCHW ----
-    // (the lane's coordinates are derived again from threadIdx.x: kept alive across the K loop they are what the ping-pong form,
-    //  at 256 registers, spilled)
-    int tid_e = threadIdx.x;
-    asm volatile("" : "+v"(tid_e));
-    const int l31_e = tid_e & 31, half_e = (tid_e >> 5) & 1;
-    const int ob_first = __builtin_amdgcn_readfirstlane((n0 + wn0) / p.HTW);
-    int voff_o[TN];
-    bool px1[TN];
+    row3_epilogue<TM, TN, MFULL, WEVEN>(p, acc, bias_s, m0, n0, wm0, wn0);
+}
+
+// ---- the "view" form of the 128 x 128 tile (TW <= 63) ----
+// The B panel of group (c, ky) at tile n = (b, oy, tx) is V of input row oy + ky - 1: the SAME transformed, split row serves the tiles
+// of three output rows.  The kernel above forms it three times (once per ky).  Here a workgroup stages V ONCE per 16-channel block,
+// for the rows its 128 consecutive tiles touch -- entries e = 0 .. 127 + 2 TW, entry e = the row-tile n0 - TW + e of the
+// (b, iy, tx) order -- and the panel of (c, ky) is a VIEW of that buffer: tile t reads entry t + ky TW (a row above / below the
+// image: an all-zero entry, picked per lane).  Row loads, transforms, splits and LDS stores drop by 3 * 128 / (128 + 2 TW): 1.9 x at
+// 76 x 76, 2.3 x at 38 x 38, 2.6 x at 19 x 19.  All four planes of 256 entries do not fit the LDS twice, so the K loop runs in plane
+// pairs: slots (c, h, ky) -- planes 2h, 2h + 1 of channel block c against filter row ky -- with the pair's half of the buffer
+// (X: planes 0, 1; Y: planes 2, 3) rewritten while the other half is read: X(c + 1) during (c, 1, *), Y(c) during (c, 0, *), V2 / V3
+// kept in registers in between.  Per plane the products accumulate in the order of the other tiles: bit-identical results.
+//   staging roles   round 0: entries 0 .. 127, round 1: entries 128 .. 255; wave w stages entries 32 (w & 3) + lane / 2 of a round for
+//                   the channel quads of k-octet w >> 2 (lane pairs = the two halves of a 16-byte unit); a wave whose round-1
+//                   entries lie past 127 + 2 TW skips the round (wave-uniform)
+//   LDS             A[2 stages][plane 2][piece 3][k-octet 2][128] + V[2 halves][plane 2][piece 3][k-octet 2][256] 16-byte units = 144 KB
+template <bool MFULL, bool WEVEN>
+__global__ __launch_bounds__(512, 2) void conv_f32_row3v_kernel(ConvRow3Dev p)
+{
+    constexpr int BM = 128, BT = 128, WN = 4, TM = 2, TN = 1, NT = 512;
+    constexpr int NE = 256, ZE = NE - 1;                // entries of a V slab; the all-zero entry
+    constexpr int STAGE_A = 2 * 6 * BM;                 // 16-byte units
+    constexpr int HALF_V = 2 * 6 * NE;
+    constexpr int APT = STAGE_A / NT, A_STEP = NT / BM;
+    static_assert(STAGE_A % NT == 0 && NT % BM == 0, "A panel mapping");
+
+    __shared__ __attribute__((aligned(16))) uint4 smem[2 * STAGE_A + 2 * HALF_V + BM / 4];
+    uint4 *As = smem;
+    uint4 *Vs = smem + 2 * STAGE_A;
+    float *bias_s = reinterpret_cast<float *>(smem + 2 * STAGE_A + 2 * HALF_V);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+
+    // XCD-aware tile order, as above
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+    const int logical = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+    const int tile_n = __builtin_amdgcn_readfirstlane(logical / p.tiles_m);
+    const int tile_m = logical - tile_n * p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BT;
+
+    if (tid < BM) bias_s[tid] = (m0 + tid < p.M) ? p.bias[m0 + tid] : 0.f;
+    if (tid < 24)                                       // the zero entry of every (half, plane, piece, k-octet) slab
+        Vs[(tid >> 1) * 2 * NE + (tid & 1) * NE + ZE] = make_uint4(0u, 0u, 0u, 0u);
+
+    // ---- staging role ----
+    const int HW = p.H * p.W;
+    const int wcol = wave & 3;
+    const int s_oct = wave >> 2, s_qlo = lane & 1, s_q = s_oct * 2 + s_qlo;
+    const bool act1 = 128 + wcol * 32 < BT + 2 * p.TW;   // wave-uniform: does round 1 hold an entry a view reads?
+    const int e_first = n0 - p.TW;                      // row-tile index of entry 0 (may be negative)
+    const int b_first = __builtin_amdgcn_readfirstlane((e_first > 0 ? e_first : 0) / p.HTW);
+    const size_t img_floats = (size_t)p.C * HW;
+    // descriptor based one column in front of the first image any entry lies in: lane offset (iy * W + 2 tx) = column 2 tx - 1
+    const float *tile_base = p.in + (size_t)b_first * img_floats - 1;
+    size_t rec = (((size_t)p.B - b_first) * img_floats + 1) * sizeof(float);
+    if (rec > 0xFFFFFFFEull) rec = 0xFFFFFFFEull;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)tile_base, 0, (int)(unsigned)rec, 0x00020000);
+    int voff[2];
+    unsigned cmask = 0;                                 // column validity: bits 3 r + {0: 2tx-1, 1: 2tx+1, 2: 2tx+2}
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn0 + j * 32 + l31_e;
-        const int ob = n / p.HTW;
-        const int orem = n - ob * p.HTW;
-        const int ooy = orem / p.TW;
-        const int otx = orem - ooy * p.TW;
-        voff_o[j] = n < p.Ntiles ? (int)(((unsigned)(ob - ob_first) * (unsigned)p.M * (unsigned)HW + (unsigned)ooy * (unsigned)p.W +
-                                          (unsigned)(2 * otx) + 4u * (unsigned)half_e * (unsigned)HW) * 4u) : -1;
-        px1[j] = n < p.Ntiles && (WEVEN || (2 * otx + 1 < p.W));      // (a tile past the end has voff_o = -1: -1 + 4 would be a valid offset)
+    for (int r = 0; r < 2; ++r) {
+        const int e = r * 128 + wcol * 32 + (lane >> 1);
+        const int eg = e_first + e;
+        const bool ok = eg >= 0 && eg < p.Ntiles && e != ZE;
+        const int egc = ok ? eg : 0;
+        const int b = egc / p.HTW;
+        const int rem = egc - b * p.HTW;
+        const int iy = rem / p.TW;
+        const int tx = rem - iy * p.TW;
+        voff[r] = ok ? (int)(((unsigned)(b - b_first) * (unsigned)img_floats + (unsigned)(s_q * 4) * (unsigned)HW +
+                              (unsigned)iy * (unsigned)p.W + (unsigned)(2 * tx)) * 4u) : -1;
+        cmask |= ((tx > 0 ? 1u : 0u) | (2 * tx + 1 < p.W ? 2u : 0u) | (2 * tx + 2 < p.W ? 4u : 0u)) << (3 * r);
     }
-    const size_t img_out = (size_t)p.M * HW;
-    size_t orec = ((size_t)p.B - ob_first) * img_out * 4;
-    if (orec > 0xFFFFFFFEull) orec = 0xFFFFFFFEull;
-    const bool has_out = p.out != nullptr && (X_DBG & 32) == 0, has_add = p.add != nullptr && (X_DBG & 32) == 0;
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(has_out ? p.out + (size_t)ob_first * img_out : (float *)p.bias), 0, has_out ? (int)(unsigned)orec : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(has_add ? p.add + (size_t)ob_first * img_out : p.bias), 0, has_add ? (int)(unsigned)orec : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_oadd = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(has_add ? p.out_add + (size_t)ob_first * img_out : (float *)p.bias), 0, has_add ? (int)(unsigned)orec : 0, 0x00020000);
-    const int row_bytes = HW * 4;
-    const bool leaky = p.act == YL_LEAKY;
-    // one wave-uniform branch picks the output form; inside it the [shortcut] operand of a whole 32 x 32 block is requested
-    // before the block's arithmetic (MODE 0: out, 1: out_add only, 2: both)
-    auto epilogue = [&](auto mode_tag, auto leaky_tag) {
-        constexpr int MODE = decltype(mode_tag)::value;
-        constexpr bool LEAKY = decltype(leaky_tag)::value;
+    const int v_lds = (s_oct * NE + wcol * 32 + (lane >> 1)) * 16 + s_qlo * 8;       // byte offset of the round-0 entry in a (plane, piece) slab
+
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)p.wr, 0, (int)((unsigned)p.G * 24u * (unsigned)p.Mpad * 16u), 0x00020000);
+    const int a_voff = ((tid / BM) * p.Mpad + (tid % BM)) * 16;
+
+    v4i a_reg[APT];
+    f32x4 raw[2][4];                          // [round][channel of the quad]: columns 2tx-1 .. 2tx+2
+    float V[2][4][4];                         // [round][plane][channel of the quad]
+    int ld_c0 = 0;                            // channel block of the NEXT row loads
+
+    auto load_raw = [&]() {
+        const int soff = ld_c0 * HW * 4;
+        const int tinv = ld_c0 < p.C ? 0 : -1;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float bias_r[16];
+        for (int i = 0; i < 4; ++i)
+            raw[0][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[0] | tinv, soff + i * HW * 4, 0));
+        if (act1) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) bias_r[e] = bias_s[wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half_e];
+            for (int i = 0; i < 4; ++i)
+                raw[1][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[1] | tinv, soff + i * HW * 4, 0));
+        }
+        ld_c0 += 16;
+    };
+    auto transform = [&](int r) {
+        const bool cm0 = (cmask >> (3 * r)) & 1u, cm2 = (cmask >> (3 * r + 1)) & 1u, cm3 = (cmask >> (3 * r + 2)) & 1u;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-#pragma unroll
-                for (int e0 = 0; e0 < 16; e0 += 8) {         // eight accumulator rows at a time: their [shortcut] operands first
-                    int vo[8], vo1[8];
-                    f32x2 addv[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int e = e0 + k;
-                        const int mrow = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2);
-                        const bool ok = MFULL || (mrow + 4 * half_e) < p.M;
-                        vo[k] = ok ? voff_o[j] : -1;
-                        vo1[k] = (ok && px1[j]) ? voff_o[j] + 4 : -1;
-                        if constexpr (MODE >= 1) {
-                            if constexpr (WEVEN)
-                                addv[k] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_add, vo[k], mrow * row_bytes, 0));
-                            else {
-                                addv[k][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_add, vo[k], mrow * row_bytes, 0));
-                                addv[k][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_add, vo1[k], mrow * row_bytes, 0));
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int e = e0 + k;
-                        const float q0 = acc[0][i][j][e], q1 = acc[1][i][j][e], q2 = acc[2][i][j][e], q3 = acc[3][i][j][e];
-                        float y0 = ((q0 + q1) + q2) + bias_r[e];
-                        float y1 = ((q1 - q2) - q3) + bias_r[e];
-                        if constexpr (LEAKY) {
-                            // (float)(.1 * (double)x), conv_f32_mfma.hip's arithmetic, as three conversions / multiplies and a select:
-                            // left as a ternary hipcc branches around the double-precision path for every output
-                            float t0 = (float)(.1 * (double)y0), t1 = (float)(.1 * (double)y1);
-                            asm volatile("" : "+v"(t0), "+v"(t1));
-                            y0 = (y0 > 0.f) ? y0 : t0;
-                            y1 = (y1 > 0.f) ? y1 : t1;
-                        }
-                        const int mrow = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2);
-                        if constexpr (MODE != 1) {
-                            if constexpr (WEVEN) {
-                                const f32x2 y = {y0, y1};
-                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, y), rs_out, vo[k], mrow * row_bytes, 0);
-                            } else {
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y0), rs_out, vo[k], mrow * row_bytes, 0);
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y1), rs_out, vo1[k], mrow * row_bytes, 0);
-                            }
-                        }
-                        if constexpr (MODE >= 1) {
-                            const float s0 = __fadd_rn(y0, addv[k][0]), s1 = __fadd_rn(y1, addv[k][1]);
-                            if constexpr (WEVEN) {
-                                const f32x2 y = {s0, s1};
-                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, y), rs_oadd, vo[k], mrow * row_bytes, 0);
-                            } else {
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s0), rs_oadd, vo[k], mrow * row_bytes, 0);
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, s1), rs_oadd, vo1[k], mrow * row_bytes, 0);
-                            }
-                        }
-                    }
-                }
-            }
+        for (int i = 0; i < 4; ++i) {
+            const float d0 = cm0 ? raw[r][i][0] : 0.f, d1 = raw[r][i][1], d2 = cm2 ? raw[r][i][2] : 0.f, d3 = cm3 ? raw[r][i][3] : 0.f;
+            V[r][0][i] = d0 - d2;
+            V[r][1][i] = d1 + d2;
+            V[r][2][i] = d2 - d1;
+            V[r][3][i] = d1 - d3;
         }
     };
-    if (leaky) {
-        if (!has_add) epilogue(std::integral_constant<int, 0>{}, std::true_type{});
-        else if (!has_out) epilogue(std::integral_constant<int, 1>{}, std::true_type{});
-        else epilogue(std::integral_constant<int, 2>{}, std::true_type{});
-    } else {
-        if (!has_add) epilogue(std::integral_constant<int, 0>{}, std::false_type{});
-        else if (!has_out) epilogue(std::integral_constant<int, 1>{}, std::false_type{});
-        else epilogue(std::integral_constant<int, 2>{}, std::false_type{});
+    // planes 2 hh, 2 hh + 1 of round r -> three pieces -> half hh of the V buffer
+    auto store_v = [&](int hh, int r) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            unsigned a1, a2, a3, c1, c2, c3;
+            split3_pair(V[r][2 * hh + pl][0], V[r][2 * hh + pl][1], a1, a2, a3);
+            split3_pair(V[r][2 * hh + pl][2], V[r][2 * hh + pl][3], c1, c2, c3);
+            char *dst = reinterpret_cast<char *>(Vs + hh * HALF_V + pl * 6 * NE) + v_lds + r * 128 * 16;
+            *reinterpret_cast<uint2 *>(dst + 0 * 2 * NE * 16) = make_uint2(a1, c1);
+            *reinterpret_cast<uint2 *>(dst + 1 * 2 * NE * 16) = make_uint2(a2, c2);
+            *reinterpret_cast<uint2 *>(dst + 2 * 2 * NE * 16) = make_uint2(a3, c3);
+        }
+    };
+    // A panel pa = (c * 3 + ky) * 2 + h: rows (plane of the pair, piece, k-octet) x 128 filters
+    auto load_a = [&](int pa) {
+#pragma unroll
+        for (int e = 0; e < APT; ++e)
+            a_reg[e] = __builtin_bit_cast(v4i, __builtin_amdgcn_raw_buffer_load_b128(
+                rs_w, a_voff, ((pa * 12 + e * A_STEP) * p.Mpad + m0) * 16, 0));
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < APT; ++e) As[buf * STAGE_A + tid + e * NT] = __builtin_bit_cast(uint4, a_reg[e]);
+    };
+
+    f32x16 acc[4][TM][TN];
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[xi][i][0][e] = 0.f;
+
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int wm0 = wm * TM * 32, wn0 = wn * TN * 32;
+
+    // the three views of this lane's tile: entry t + ky TW, or the zero entry for a row outside the image
+    int b_view[3];
+    {
+        const int n = n0 + wn0 + l31;
+        const int rem = n % p.HTW;
+        const int oy = rem / p.TW;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const bool ok = oy + ky - 1 >= 0 && oy + ky - 1 < p.H;
+            b_view[ky] = half * NE + (ok ? wn0 + l31 + ky * p.TW : ZE);
+        }
     }
+
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0};          // pieces of the six products, smallest terms first
+    constexpr int TB[6] = {0, 2, 1, 0, 1, 0};
+    struct Frags { v4i a[3][TM], b[3]; };
+    auto read_frags = [&](Frags &f, int abuf, int hh, int ky, int pl) {
+        int a_off = abuf * STAGE_A + half * BM + wm0 + l31;
+        int b_off = hh * HALF_V + b_view[ky];
+        asm volatile("" : "+v"(a_off), "+v"(b_off));           // one base register each, immediate offsets below
+        const uint4 *Ab = As + a_off;
+        const uint4 *Bb = Vs + b_off;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) f.a[pc][i] = __builtin_bit_cast(v4i, Ab[(pl * 3 + pc) * 2 * BM + i * 32]);
+            f.b[pc] = __builtin_bit_cast(v4i, Bb[(pl * 3 + pc) * 2 * NE]);
+        }
+    };
+    auto mfma_plane = [&](const Frags &f, int xi) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                acc[xi][i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8, f.a[TA[t]][i]), __builtin_bit_cast(bf16x8, f.b[TB[t]]), acc[xi][i][0], 0, 0, 0);
+    };
+
+    const int CB = p.C / 16;
+    int c = 0;
+    // slot (c, H, KY): stage (H * 3 + KY) & 1 of A.  It stores the A panel of the next slot, requests the one after, does its share
+    // of the V staging, then computes its two planes; one barrier at its end.
+    //   (c, 0, 0) / (c, 0, 1): Y(c) <- the V2, V3 kept in registers, round 0 / round 1; after (c, 0, 1) the rows of block c + 1 are requested
+    //   (c, 1, 0): rows of block c + 1 -> V; X(c + 1) <- V0, V1 of round 0        (c, 1, 1): ... of round 1
+    auto slot = [&](auto h_tag, auto ky_tag, auto last_tag) {
+        constexpr int H = decltype(h_tag)::value, KY = decltype(ky_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;
+        constexpr int S = H * 3 + KY;
+        constexpr bool HAS_NEXT = !(LAST && S == 5), HAS_NEXT2 = !(LAST && S >= 4);
+        if constexpr (HAS_NEXT) store_a((S + 1) & 1);
+        if constexpr (HAS_NEXT2) {
+            constexpr int S2 = (S + 2) % 6;
+            load_a(((c + (S + 2) / 6) * 3 + S2 % 3) * 2 + S2 / 3);
+        }
+        if constexpr (H == 0 && KY == 0) store_v(1, 0);
+        if constexpr (H == 0 && KY == 1) {
+            if (act1) store_v(1, 1);
+            if constexpr (!LAST) load_raw();
+        }
+        if constexpr (H == 1 && KY == 0 && !LAST) {
+            transform(0);
+            if (act1) transform(1);
+            store_v(0, 0);
+        }
+        if constexpr (H == 1 && KY == 1 && !LAST) {
+            if (act1) store_v(0, 1);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            Frags f;
+            read_frags(f, S & 1, H, KY, pl);
+            mfma_plane(f, H * 2 + pl);
+        }
+        if constexpr (HAS_NEXT) __syncthreads();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+
+    // ---- prologue: rows of block 0 -> V; X(0); A panel of slot 0 -> LDS, of slot 1 -> registers ----
+    load_a(0);
+    load_raw();
+    transform(0);
+    if (act1) transform(1);
+    store_a(0);
+    store_v(0, 0);
+    if (act1) store_v(0, 1);
+    load_a(2);                                 // slot (0, 0, 1): panel (0 * 3 + 1) * 2 + 0
+    __syncthreads();
+
+    for (; c + 1 < CB; ++c) {
+        slot(I0{}, I0{}, std::false_type{});
+        slot(I0{}, I1{}, std::false_type{});
+        slot(I0{}, I2{}, std::false_type{});
+        slot(I1{}, I0{}, std::false_type{});
+        slot(I1{}, I1{}, std::false_type{});
+        slot(I1{}, I2{}, std::false_type{});
+    }
+    slot(I0{}, I0{}, std::true_type{});
+    slot(I0{}, I1{}, std::true_type{});
+    slot(I0{}, I2{}, std::true_type{});
+    slot(I1{}, I0{}, std::true_type{});
+    slot(I1{}, I1{}, std::true_type{});
+    slot(I1{}, I2{}, std::true_type{});
+
+    row3_epilogue<TM, TN, MFULL, WEVEN>(p, acc, bias_s, m0, n0, wm0, wn0);
+}
+
+int launch_row3_view(ConvRow3Dev p, hipStream_t s)
+{
+    p.tiles_m = (p.M + 127) / 128;
+    const long long blocks = (long long)p.tiles_m * ((p.Ntiles + 127) / 128);
+    if (blocks <= 0 || blocks > 0x7fffffffLL || p.TW > 63) return (int)hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks), block(512);
+    const bool mfull = (p.M % 128) == 0, weven = (p.W & 1) == 0;
+    if (mfull && weven) hipLaunchKernelGGL((conv_f32_row3v_kernel<true, true>), grid, block, 0, s, p);
+    else if (mfull) hipLaunchKernelGGL((conv_f32_row3v_kernel<true, false>), grid, block, 0, s, p);
+    else if (weven) hipLaunchKernelGGL((conv_f32_row3v_kernel<false, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((conv_f32_row3v_kernel<false, false>), grid, block, 0, s, p);
+    return (int)hipGetLastError();
 }
 
 template <int BM, int BT, int WM, int WN, int PP, int SCHED, bool LOADX2 = false>
@@ -632,8 +909,9 @@ void row3_pack_weights(const float *w, int C, int M, void *dst)
 // tile: 0 = heuristic; 128x128 tiles, 8 waves: 1 = mid-panel barrier with the staging work pinned between the MFMAs, 2 = barrier at
 // the panel's end, 3 = 1 with the 8-byte + DPP row loads (A/B); 128x64, 4 waves (two workgroups per CU): 4 = mid-panel barrier,
 // 5 = one plane per panel; 64x64, 4 waves (three workgroups per CU): 7 = pinned, 9 = end barrier, 6 = 7 with the 8-byte + DPP row
-// loads; 8 = 64x128, 8 waves, pinned
-int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len)
+// loads; 8 = 64x128, 8 waves, pinned; 10 = 128x128 in the view form (tile 1 on maps wider than 126).  view: the heuristic
+// picks 10 wherever it would pick 1 (variant bit 13)
+int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len, bool view)
 {
     if (!a.row3_w || !row3_applicable(a.C, a.M, a.size, a.stride, a.pad) || a.OH != a.H || a.OW != a.W || !a.in_front_pad ||
         (!a.out && !a.add) || (a.add && !a.out_add) || a.q_out || a.bits_out || a.pool_out || a.yolo_entries > 0)
@@ -685,6 +963,7 @@ int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *nam
         else {
             const double c128 = cost(128, 128, 1.0, 1, f128), c64t = cost(128, 64, 0.79, 2, f128x64), c64 = cost(64, 64, 0.53, 3, f64);
             tile = (c128 <= c64t && c128 <= c64) ? 1 : (c64t <= c64 ? 4 : 7);
+            if (tile == 1 && view && d.TW <= 63) tile = 10;
             // (a finer 64x32 tile was measured at 8 images per GPU and gains nothing: below one workgroup per CU a layer's time
             //  is one workgroup's K loop -- 96 groups at 19 x 19 -- whatever the tile)
         }
@@ -701,6 +980,10 @@ int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *nam
     case 7: t = "64x64t,pipe"; rc = launch_row3_tile<64, 64, 2, 2, 2, 2>(d, s); break;
     case 8: t = "64x128t,pipe"; rc = launch_row3_tile<64, 128, 2, 4, 2, 2>(d, s); break;
     case 9: t = "64x64t,end"; rc = launch_row3_tile<64, 64, 2, 2, 2, 0>(d, s); break;
+    case 10:
+        if (d.TW > 63) { t = "128x128t,pipe"; rc = launch_row3_tile<128, 128, 2, 4, 2, 2>(d, s); }       // a view spans 128 + 2 TW <= 254 entries
+        else { t = "128x128t,view"; rc = launch_row3_view(d, s); }
+        break;
     default: return (int)hipErrorInvalidValue;
     }
     if (name) snprintf(name, name_len, "conv_f32_row3<%s>", t);

@@ -16,7 +16,10 @@ namespace yl {
 // on the step depending on the box (the kernel drives the chip into its power cap), same accuracy against float64
 // bit 12 (round 5, A/B only, off): K1x without its pinned schedule
 // bit 11 (round 5): the 3x3 / stride-1 layers as row-wise Winograd F(2,3) on the BF16 matrix pipe with three-piece operands (K1r,
-// conv_f32_row3.hip) instead of F(2x2,3x3) on the FP32 matrix instruction
+// conv_f32_row3.hip) instead of F(2x2,3x3) on the FP32 matrix instruction (K1w): +12.7 % on the step with its first version,
+// same box; +17 ... +19 % as shipped
+// bit 13 (round 5, off): K1r's 128 x 128 tile in its view form where 128 + 2 TW <= 254 (conv_f32_row3v_kernel): fewer row loads / splits /
+// LDS stores, lower power and a higher clock, more cycles -- +0.2 ... +0.6 % in the network (profiles/r5_ab_row3_view_form.txt)
 constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8 | 16 | 32 | 1024 | 2048;
 
 // ---- K1: FP32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 ----
@@ -88,7 +91,7 @@ bool row3_applicable(int C, int M, int size, int stride, int pad);
 size_t row3_packed_bytes(int C, int M);
 void row3_pack_weights(const float *w, int C, int M, void *dst);
 // tile: 0 = heuristic, 1..5 see conv_f32_row3.hip
-int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len);
+int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len, bool view = false);
 size_t wino32_packed_floats(int C, int M);
 void wino32_pack_weights(const float *w, int C, int M, float *dst);
 // K1s (conv_f32_smallk.hip): LDS-free kernel for first layers (C*size^2 <= 32, filters <= 32)

@@ -1587,7 +1587,7 @@ int yl_network_get_boxes(yl_network *net, int image, int w, int h, float thresh,
 int yl_network_set_conv_tile(yl_network *net, int cfg)
 {
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }
-    if (!(cfg == 0 || (cfg >= 11 && cfg <= 22) || cfg == 31 || cfg == 41 || (cfg >= 51 && cfg <= 55) || (cfg >= 61 && cfg <= 69))) { set_error("unknown tile id"); return YL_ERR_ARG; }
+    if (!(cfg == 0 || (cfg >= 11 && cfg <= 22) || cfg == 31 || cfg == 41 || (cfg >= 51 && cfg <= 55) || (cfg >= 61 && cfg <= 70))) { set_error("unknown tile id"); return YL_ERR_ARG; }
     net->net.conv_opts.force_tile = cfg;
     return YL_OK;
 }
@@ -1595,7 +1595,7 @@ int yl_network_set_conv_tile(yl_network *net, int cfg)
 int yl_network_set_variant(yl_network *net, int bits)
 {
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }
-    if (bits < -1 || bits > 8191) { set_error("unknown variant bits"); return YL_ERR_ARG; }
+    if (bits < -1 || bits > 16383) { set_error("unknown variant bits"); return YL_ERR_ARG; }
     net->net.conv_opts.variant = bits < 0 ? YL_VARIANT_DEFAULT : bits;
     return YL_OK;
 }
