@@ -324,8 +324,11 @@ int yl_network_set_conv_tile(yl_network *net, int cfg);
  * bit 11 the 3x3 / stride-1 layers Winograd would take as ROW-WISE Winograd F(2,3) on the BF16 matrix pipe, three-piece
  * operands (conv_f32_row3.hip) instead of F(2x2,3x3) on the FP32 matrix instruction, bit 12 (A/B only) conv_f32_x3.hip without its
  * pinned schedule (same bits), bit 13 (off) conv_f32_row3.hip's 128 x 128 tile in its "view" form on maps up to 126 wide -- the
- * transformed rows staged once per channel block instead of once per filter row; same bits, +0.2 ... +0.6 % in the network;
- * -1 = built-in default (bits 1-5, 10 and 11) */
+ * transformed rows staged once per channel block instead of once per filter row; same bits, +0.2 ... +0.6 % in the network,
+ * bit 14 RGB first layers whose only output is the sign words of an XNOR network (<= 16 filters; with the 2x2 / stride-2 [maxpool]
+ * behind them folded in) or the int8 units of an INT8 network (32 filters) on the FP32 matrix pipe (conv_f32_firstm.hip) instead of
+ * the VALU (conv_f32_first.hip): the same fmaf chains, the same bits;
+ * -1 = built-in default (bits 1-5, 10, 11 and 14) */
 int yl_network_set_variant(yl_network *net, int bits);
 /* Opt-in BF16 variant of the FP32 path (north_star (a) "FP32/BF16"; BEFORE yl_network_to_device): every FP32
  * convolution whose input has whole 8-channel groups runs on v_mfma_f32_32x32x16_bf16 with both operands rounded

@@ -269,19 +269,22 @@ def test_int8_fusion_is_bit_identical(width, height, batch, tile):
     plain.close(); fused.close()
 
 
+@pytest.mark.parametrize("variant", [8, 8 | 16384], ids=["valu", "mfma"])
 @pytest.mark.parametrize("width,height,batch", [(96, 96, 2), (160, 96, 3)])
-def test_int8_fusion_with_first_layer_kernel_is_bit_identical(width, height, batch):
-    """-quantized yolov3, fused, layer 0 through the first-layer kernel (conv_f32_first.hip, variant bit 3) writing ONLY
-    the int8 input of layer 1: same materialised tensors and detections as the unfused run on the generic kernels."""
+def test_int8_fusion_with_first_layer_kernel_is_bit_identical(width, height, batch, variant):
+    """-quantized yolov3, fused, layer 0 through the first-layer kernels (conv_f32_first.hip on the VALU, variant bit 3;
+    conv_f32_firstm.hip on the FP32 matrix pipe, + bit 14) writing ONLY the int8 input of layer 1:
+    same materialised tensors and detections as the unfused run on the generic kernels."""
     cfg, wts = common.model_files("yolov3", width, height)
     x = common.seeded_input(batch, 3, height, width)
     plain = Network.load(cfg, wts, batch, 1, device=0)
     fused = Network.load(cfg, wts, batch, 1, device=0, fuse=True)
     plain.set_variant(0)
-    fused.set_variant(8)
+    fused.set_variant(variant)
     plain.predict(x)
     fused.predict(x)
     assert "conv_f32_first" in fused.layer_kernel(0) and "qonly" in fused.layer_kernel(0), fused.layer_kernel(0)
+    assert ("mfma32x32x2" in fused.layer_kernel(0)) == bool(variant & 16384), fused.layer_kernel(0)
     infos = plain.layers()
     checked = 0
     for i, li in enumerate(infos):
@@ -294,6 +297,42 @@ def test_int8_fusion_with_first_layer_kernel_is_bit_identical(width, height, bat
         assert np.array_equal(plain.get_boxes(b, width, height, 0.24, nms=0.4),
                               fused.get_boxes(b, width, height, 0.24, nms=0.4))
     plain.close(); fused.close()
+
+
+@pytest.mark.parametrize("width,height,batch", [(40, 24, 3), (104, 88, 1), (32, 16, 2)])
+def test_int8_first_layer_units_mfma_equals_valu(olib, width, height, batch):
+    """conv(FP32, RGB -> 32, leaky) -> conv(INT8): with fusion on, layer 0 writes only the int8 units of layer 1 -- on the VALU
+    (conv_f32_first.hip) or on the FP32 matrix pipe (conv_f32_firstm.hip, variant bit 14; ragged 32 x 16 patches at 40 x 24 and
+    104 x 88) -- and both equal the unfused run bit for bit, the `int16_t = float` wrap corner of the quantiser included."""
+    rng = np.random.default_rng(width + height)
+    M0, M1 = 32, 48
+    w0 = rng.normal(0, np.sqrt(2.0 / 27), M0 * 27).astype(np.float32)
+    b0 = rng.normal(0, 0.5, M0).astype(np.float32)
+    w1 = rng.normal(0, np.sqrt(2.0 / (M0 * 9)), M1 * M0 * 9).astype(np.float32)
+    b1 = rng.normal(0, 0.5, M1).astype(np.float32)
+    wq = np.zeros(w1.size, np.int8)
+    w_mult = olib.oracle_quantize_weights(fp(w1), w1.size, wq.ctypes.data_as(_i8p))
+    in_mult = 15.497
+    x = (rng.standard_normal((batch, 3, height, width)) * 2).astype(np.float32)
+    x[0, 0, 3, 5] = 1e9; x[0, 1, 9, 30] = -1e9; x[-1, 2, height - 1, width - 1] = 3000.0      # |y * mult| >= 32768 somewhere
+
+    def build(fuse, variant):
+        l0 = D.conv(batch, width, height, 3, M0, 3, 1, 1, D.LEAKY, w0, b0)
+        l1 = D.conv(batch, width, height, M0, M1, 3, 1, 1, D.LEAKY, w1, b1, weights_int8=wq, in_mult=in_mult, w_mult=w_mult)
+        net = Network.from_desc([l0, l1], batch, width, height, 3, 1)
+        net.set_fusion(fuse)
+        net.set_variant(variant)
+        net.to_device(0)
+        return net
+
+    plain, valu, mfma = build(False, 0), build(True, 8), build(True, 8 | 16384)
+    ref = plain.predict(x).copy()
+    a, b = valu.predict(x).copy(), mfma.predict(x).copy()
+    assert "valu" in valu.layer_kernel(0) and "qonly" in valu.layer_kernel(0), valu.layer_kernel(0)
+    assert "mfma32x32x2" in mfma.layer_kernel(0) and "qonly" in mfma.layer_kernel(0), mfma.layer_kernel(0)
+    assert np.array_equal(ref.view(np.uint32), a.view(np.uint32))
+    assert np.array_equal(ref.view(np.uint32), b.view(np.uint32))
+    plain.close(); valu.close(); mfma.close()
 
 
 @pytest.mark.parametrize("name,width,height,batch,quantized", [
@@ -383,9 +422,10 @@ def test_xnor_fallback_layers_teacher_forced(olib):
     assert stats["exact"] >= 2
 
 
+@pytest.mark.parametrize("variant", [-1, common.VARIANT_DEFAULT & ~16384], ids=["first-mfma", "first-valu"])
 @pytest.mark.parametrize("name,width,height,batch", [("tiny-yolo-xnor", 416, 416, 2), ("tiny-yolo-xnor", 96, 96, 3),
-                                                     ("tiny-yolo-xnor", 160, 224, 1)])
-def test_xnor_sign_domain_fusion_is_bit_identical(name, width, height, batch):
+                                                     ("tiny-yolo-xnor", 160, 224, 1), ("tiny-yolo-xnor", 224, 160, 2)])
+def test_xnor_sign_domain_fusion_is_bit_identical(name, width, height, batch, variant):
     """yl_network_set_fusion on an XNOR network: conv(xnor) -> [maxpool] -> conv(xnor) chains hand over sign
     words (the producer's epilogue packs (y > 0), max-pooling is the OR of the window), FP32 tensors nobody else
     reads are not written.  Every tensor that is still materialised -- the head above all -- equals the unfused
@@ -393,9 +433,11 @@ def test_xnor_sign_domain_fusion_is_bit_identical(name, width, height, batch):
     cfg, wts = common.model_files(name, width, height)
     x = common.seeded_input(batch, 3, height, width)
     plain = Network.load(cfg, wts, batch, 0, device=0)
-    fused = Network.load(cfg, wts, batch, 0, device=0, fuse=True)
+    fused = Network.load(cfg, wts, batch, 0, device=0, fuse=True, variant=variant)
     plain.predict(x)
     fused.predict(x)
+    # the first layer hands over sign words: on the FP32 matrix pipe by default (conv_f32_firstm.hip), on the VALU without bit 14
+    assert ("mfma16x16x4" in fused.layer_kernel(0)) == (variant == -1), fused.layer_kernel(0)
     skipped = checked = 0
     for i in range(plain.n):
         if not fused.layer_materialised(i):

@@ -18,8 +18,10 @@ def test_hot_kernels_have_no_scratch_and_no_dynamic_register_indexing():
     csrc = os.path.join(ROOT, "yolo2_light_amd", "csrc")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_lint.py"),
                         os.path.join(csrc, "conv_f32_wino32.hip"), os.path.join(csrc, "conv_f32_smallk.hip"),
-                        os.path.join(csrc, "conv_f32_first.hip"), os.path.join(csrc, "conv_f32_row3.hip")],
+                        os.path.join(csrc, "conv_f32_first.hip"), os.path.join(csrc, "conv_f32_firstm.hip"),
+                        os.path.join(csrc, "conv_f32_row3.hip")],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "conv_f32_wino32_kernel" in r.stdout and "conv_f32_first_kernel" in r.stdout and "conv_f32_row3_kernel" in r.stdout
+    assert "conv_f32_firstm_signs_kernel" in r.stdout and "conv_f32_row3v_kernel" in r.stdout
     assert "0 kernel(s) flagged" in r.stdout

@@ -2,7 +2,8 @@
 # round 5, GPU call: shader clock / power (a) while the whole FP32 step runs, K1r pinned tile against its view form (variant bit 13),
 # (b) while ONE K1r layer runs back to back, tile 61 against tile 70
 OUT=gpurun_out/${1:-r5w}; mkdir -p $OUT
-for v in 3134 11326; do
+DEF=$(python -c "import sys; sys.path.insert(0, 'tests'); import common; print(common.VARIANT_DEFAULT)")
+for v in $DEF $((DEF | 8192)); do
   echo "== step, variant $v" | tee -a $OUT/clock_view.txt
   PROBE_DELAY=12 PROBE_N=8 bash tools/clock_probe.sh $OUT/clk_step_$v.txt python bench.py --mode fp32 --no-extras --no-cpu-baseline --no-e2e --steps 400 --warmup 3 --variant $v
   cat $OUT/clk_step_$v.txt | sed 's/GPU\[0\]\t\t: //g; s/=* Power Consumption =*;//' | cut -c1-260 | tee -a $OUT/clock_view.txt

@@ -5,7 +5,8 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 timeout 900 python -m pytest tests/test_gpu_row3.py -x -q > $OUT/pytest_row3.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_row3.log
 tail -3 $OUT/pytest_row3.log
-for v in 3134 11326 3134 11326; do
+DEF=$(python -c "import sys; sys.path.insert(0, 'tests'); import common; print(common.VARIANT_DEFAULT)")
+for v in $DEF $((DEF | 8192)) $DEF $((DEF | 8192)); do
   timeout 600 python bench.py --mode fp32 --no-extras --no-cpu-baseline --no-e2e --steps 10 --warmup 3 --variant $v --layers > $OUT/bench_v$v.json 2>$OUT/bench_v$v.err
   python - <<PY | tee -a $OUT/bench.txt
 import json

@@ -565,8 +565,10 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o_in, void *stream,
     // and degrades to the stand-alone pooling kernel when a knob has moved the layer elsewhere: this is the backstop)
     if (a.pool_out && !conv_f32_pool_fusable(a, o)) return (int)hipErrorInvalidValue;
     // RGB first layers with <= 16 filters: the VALU kernel (force_tile 41 keeps the MFMA first-layer kernel for A/B)
-    if (o.force_tile == 0 && (o.variant & 8) && first_layer_valu_applicable(a))
+    if (o.force_tile == 0 && (o.variant & 8) && first_layer_valu_applicable(a)) {
+        if ((o.variant & 16384) && first_layer_mfma_applicable(a)) return launch_conv_f32_firstm(a, stream, name, name_len);
         return launch_conv_f32_first(a, stream, name, name_len);
+    }
     if (a.bits_out)                                                   // sign-word side output: only the first-layer kernels have it
         return smallk_applicable(a) ? launch_conv_f32_smallk(a, stream, name, name_len) : (int)hipErrorInvalidValue;
     // K1x: the layer on the BF16 matrix pipe with three-piece operands (variant bit 10; force_tile 51..54 = its tiles)

@@ -20,7 +20,9 @@ namespace yl {
 // same box; +17 ... +19 % as shipped
 // bit 13 (round 5, off): K1r's 128 x 128 tile in its view form where 128 + 2 TW <= 254 (conv_f32_row3v_kernel): fewer row loads / splits /
 // LDS stores, lower power and a higher clock, more cycles -- +0.2 ... +0.6 % in the network (profiles/r5_ab_row3_view_form.txt)
-constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8 | 16 | 32 | 1024 | 2048;
+// bit 14 (round 5): RGB first layers that emit sign words only / int8 units only on the FP32 matrix pipe (K1m, conv_f32_firstm.hip) instead
+// of the VALU (K1f): the same fmaf chains, the same bits
+constexpr int YL_VARIANT_DEFAULT = 2 | 4 | 8 | 16 | 32 | 1024 | 2048 | 16384;
 
 // ---- K1: FP32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 ----
 struct ConvF32Args {
@@ -35,6 +37,8 @@ struct ConvF32Args {
     int q_G = 0;          // its channel groups (Cpad/16); direct kernel only, needs M % 16 == 0
     uint64_t *bits_out = nullptr;   // optional sign words (x > 0) of the activated output, bits[B][1][OH][OW], for an XNOR
                           // convolution behind this layer; first-layer kernel only (conv_f32_smallk.hip, M <= 32)
+    bool bits_pooled = false;  // bits_out receives the sign words of the 2x2 / stride-2 [maxpool] behind the layer, bits[B][1][OH/2][OW/2]
+                          // (the OR of each window's words); conv_f32_firstm.hip only
     float *pool_out = nullptr; // optional fused [maxpool] 2x2 / stride 2 / pad 1 behind the layer (H, W even): [B][M][H/2][W/2],
                           // written by the epilogue next to (or instead of, out == nullptr) the full tensor; only the kernels
                           // conv_f32_pool_fusable() names have it (K1f: a lane owns a 2 x 4 patch; K1w: an F(2x2) tile is a window)
@@ -101,6 +105,10 @@ int launch_conv_f32_smallk(const ConvF32Args &a, void *stream, char *name, size_
 // lane, scalar weights), bit-identical to K1s; FP32 rows and / or sign words out
 bool first_layer_valu_applicable(const ConvF32Args &a);
 int launch_conv_f32_first(const ConvF32Args &a, void *stream, char *name, size_t name_len);
+// K1m (conv_f32_firstm.hip): the same layer on the FP32 matrix pipe (K1f's bits) where the output is sign words only (<= 16 filters) or
+// int8 units only (32 filters)
+bool first_layer_mfma_applicable(const ConvF32Args &a);
+int launch_conv_f32_firstm(const ConvF32Args &a, void *stream, char *name, size_t name_len);
 int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, int variant, void *stream, char *name, size_t name_len);
 
 // ---- K2: INT8 path ----

@@ -755,8 +755,24 @@ static int forward_layer(Network &net, size_t i, const float *input)
                     pool_after = true;
                 }
             }
-            if (l.bits_out_slot >= 0)       // FP32 first layer -> [maxpool] -> XNOR conv: sign words instead of the FP32 tensor
+            if (l.bits_out_slot >= 0) {     // FP32 first layer -> [maxpool] -> XNOR conv: sign words instead of the FP32 tensor
                 a.bits_out = net.d_bitbuf + (size_t)(l.bits_out_slot % 3) * (net.bitbuf_bytes / sizeof(uint64_t));
+                // ... and where the kernel of the moment can OR the 2x2 / stride-2 windows itself (K1m), the POOLED words, straight into
+                // the consumer's slot: the pooling layer then has nothing to do in this pass (decided per launch, like pool_after above)
+                if (l.bits_out_slot == (int)i + 1 && i + 1 < net.layers.size()) {
+                    Layer &pl = net.layers[i + 1];
+                    pl.bits_pooled_by_producer = false;
+                    if (pl.type == YL_MAXPOOL && pl.pool_bits_mode == 1 && pl.size == 2 && pl.stride == 2 && pl.pad >= 0 && pl.pad <= 1 &&
+                        !((pl.h | pl.w) & 1) && pl.out_h == pl.h / 2 && pl.out_w == pl.w / 2 && net.conv_opts.force_tile == 0 &&
+                        (net.conv_opts.variant & 8) && (net.conv_opts.variant & 16384)) {
+                        a.bits_pooled = true;
+                        if (first_layer_mfma_applicable(a)) {
+                            a.bits_out = net.d_bitbuf + (size_t)((i + 2) % 3) * (net.bitbuf_bytes / sizeof(uint64_t));
+                            pl.bits_pooled_by_producer = true;
+                        } else a.bits_pooled = false;
+                    }
+                }
+            }
             YL_LAUNCH(launch_conv_f32(a, net.conv_opts, s, l.kernel_name, sizeof(l.kernel_name)), "conv_f32");
             if (pool_after) {
                 const Layer &pl = net.layers[l.fused_pool];
@@ -863,7 +879,9 @@ static int forward_layer(Network &net, size_t i, const float *input)
     case YL_MAXPOOL: {
         if (l.fused_into_conv) break;          // written by the epilogue of the convolution in front of it
         auto ring = [&](int slot) { return net.d_bitbuf + (size_t)(slot % 3) * (net.bitbuf_bytes / sizeof(uint64_t)); };
-        if (l.pool_bits_mode == 1)
+        if (l.pool_bits_mode == 1 && l.bits_pooled_by_producer)
+            ;                                  // the convolution in front of this layer wrote slot i + 1 itself (K1m)
+        else if (l.pool_bits_mode == 1)
             YL_LAUNCH(launch_bit_maxpool(ring((int)i), ring((int)i + 1), B, (l.c + 63) / 64, l.h, l.w, l.out_h, l.out_w,
                                          l.size, l.stride, l.pad, s), "bit_maxpool");
         else if (l.pool_bits_mode == 2)
@@ -1595,7 +1613,7 @@ int yl_network_set_conv_tile(yl_network *net, int cfg)
 int yl_network_set_variant(yl_network *net, int bits)
 {
     if (!net) { set_error("null argument"); return YL_ERR_ARG; }
-    if (bits < -1 || bits > 16383) { set_error("unknown variant bits"); return YL_ERR_ARG; }
+    if (bits < -1 || bits > 32767) { set_error("unknown variant bits"); return YL_ERR_ARG; }
     net->net.conv_opts.variant = bits < 0 ? YL_VARIANT_DEFAULT : bits;
     return YL_OK;
 }

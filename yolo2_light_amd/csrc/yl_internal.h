@@ -93,6 +93,7 @@ struct Layer {
     bool  bits_from_producer = false;    // XNOR conv: its packed input is written by the layer(s) before it
     int   bits_out_slot = -1;            // XNOR conv: also emits the sign words of its result into bit-ring slot (index % 3)
     int   pool_bits_mode = 0;            // maxpool: 1 = OR-pool sign words (slot i -> slot i+1), 2 = FP32 in -> pooled sign words
+    bool  bits_pooled_by_producer = false;   // maxpool, mode 1: the convolution in front of it wrote the pooled words into slot i+1 in this pass
 };
 
 // arguments of the cached yl_network_get_boxes pass
