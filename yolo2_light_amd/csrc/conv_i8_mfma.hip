@@ -58,22 +58,32 @@ typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 // one lane per (b, cg, pixel): 16 coalesced plane reads, one 16-byte coalesced store
 // G = channel groups of THIS source, written at groups [g_off, g_off + G) of a tensor with G_total groups (a
 // multi-input [route] is quantised source by source into one int8 tensor: the FP32 concatenation is never built)
+// up > 1: `in` is the INPUT of a nearest-neighbour [upsample] (scale 1) whose output this pass would otherwise read -- quantising is
+// pointwise, so quantise(upsample(x)) = upsample(quantise(x)): pixel (y, x) of the H x W output takes (y / up, x / up) of the
+// (H / up) x (W / up) tensor, and the upsampled FP32 tensor is never written (forward_upsample_layer_cpu, src/additionally.c)
 __global__ __launch_bounds__(256) void quantize_nc16_kernel(const float *__restrict__ in, int8_t *__restrict__ out,
-                                                            size_t total, int C, int HW, int G, int G_total, int g_off, float mult)
+                                                            size_t total, int C, int HW, int G, int G_total, int g_off, float mult,
+                                                            int W, int up)
 {
+    const int HWin = up > 1 ? HW / (up * up) : HW;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (size_t)gridDim.x * blockDim.x) {
         const int pix = (int)(idx % HW);
         size_t t = idx / HW;
         const int cg = (int)(t % G);
         const size_t b = t / G;
-        const float *src = in + (b * C + (size_t)cg * 16) * HW + pix;
+        int spix = pix;
+        if (up > 1) {
+            const int y = pix / W, x = pix - y * W;
+            spix = (y / up) * (W / up) + x / up;
+        }
+        const float *src = in + (b * C + (size_t)cg * 16) * HWin + spix;
         unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             int q = 0;
             if (cg * 16 + j < C) {
-                q = quantize_input_i8(src[(size_t)j * HW], mult);
+                q = quantize_input_i8(src[(size_t)j * HWin], mult);
             }
             w[j >> 2] |= ((unsigned)(q & 0xFF)) << ((j & 3) * 8);
         }
@@ -83,8 +93,9 @@ __global__ __launch_bounds__(256) void quantize_nc16_kernel(const float *__restr
 }
 
 int launch_quantize_nhwc(const float *in, int8_t *out, int B, int C, int H, int W, int Cpad, float mult, void *stream,
-                         int g_off, int G_total)
+                         int g_off, int G_total, int up)
 {
+    if (up < 1 || (up > 1 && (H % up || W % up))) return (int)hipErrorInvalidValue;
     const int G = Cpad / 16;
     if (G_total <= 0) G_total = G;
     const size_t total = (size_t)B * G * H * W;
@@ -92,7 +103,7 @@ int launch_quantize_nhwc(const float *in, int8_t *out, int B, int C, int H, int 
     if (g > 256 * 16) g = 256 * 16;
     if (g == 0) g = 1;
     hipLaunchKernelGGL(quantize_nc16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
-                       in, out, total, C, H * W, G, G_total, g_off, mult);
+                       in, out, total, C, H * W, G, G_total, g_off, mult, W, up);
     return (int)hipGetLastError();
 }
 

@@ -116,7 +116,7 @@ int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, int vari
 // (g_off, G_total): write this source's Cpad/16 groups at group offset g_off of a tensor with G_total groups
 // (0, 0 = the source is the whole tensor)
 int launch_quantize_nhwc(const float *in, int8_t *out, int B, int C, int H, int W, int Cpad,
-                         float mult, void *stream, int g_off = 0, int G_total = 0);
+                         float mult, void *stream, int g_off = 0, int G_total = 0, int up = 1);      // up > 1: `in` is the input of an [upsample] by `up`
 struct ConvI8Args {
     const int8_t *in_q;   // [B][H][W][Cpad]
     const int8_t *w_q;    // [Mpad][size*size][Cpad]

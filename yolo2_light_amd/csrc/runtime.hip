@@ -615,6 +615,25 @@ static int to_device(Network &net, int device)
             if (!ok) continue;
             cons.q_from_route = true;
             rt.skip_f32_out = true;
+            // a source that is a nearest-neighbour [upsample] (scale 1) read by nothing but this [route]: quantising is pointwise, so the
+            // int8 units are formed from the upsample's INPUT (quantize_nc16_kernel, up = stride) and its FP32 output is never written
+            // (yolov3: layers 85 and 97, 0.07 + 0.13 ms of copies and 4x the quantiser's reads per step at 608 x 608, batch 64)
+            if (cons.conv_mode == CONV_INT8) {
+                for (int k = 0; k < rt.n; ++k) {
+                    const int u = rt.input_layers[k];
+                    Layer &up = net.layers[u];
+                    if (up.type != YL_UPSAMPLE || up.scale != 1.f || up.stride < 2 || u < 1 || u == nl - 1) continue;
+                    if ((up.out_h % up.stride) || (up.out_w % up.stride) || up.out_h / up.stride != up.h || up.out_w / up.stride != up.w) continue;
+                    bool other = false;
+                    for (int m = u + 1; m < nl && !other; ++m) {
+                        const Layer &o = net.layers[m];
+                        if (m == u + 1 && o.type != YL_ROUTE) other = true;                          // running input of u + 1
+                        if (o.type == YL_SHORTCUT && o.index == u) other = true;
+                        if (o.type == YL_ROUTE && m != j - 1) for (int id : o.input_layers) if (id == u) other = true;
+                    }
+                    if (!other) up.skip_f32_out = true;
+                }
+            }
         }
         // ---- sign-domain plan (XNOR): an XNOR convolution reads only (x > 0); sign(maxpool(x)) is the OR of
         //      the window's signs.  conv(xnor) [-> maxpool] -> conv(xnor) chains hand sign words over, the FP32
@@ -785,6 +804,10 @@ static int forward_layer(Network &net, size_t i, const float *input)
                 int g_off = 0;
                 for (int k = 0; k < rt.n; ++k) {
                     const Layer &src = net.layers[rt.input_layers[k]];
+                    if (src.type == YL_UPSAMPLE && src.skip_f32_out)        // straight from the upsample's input (see the plan)
+                        YL_LAUNCH(launch_quantize_nhwc(net.layers[rt.input_layers[k] - 1].d_output, q_in, B, src.out_c, l.h, l.w, src.out_c,
+                                                       l.input_quant_multipler, s, g_off, l.Cpad / 16, src.stride), "quantize_route_up");
+                    else
                     YL_LAUNCH(launch_quantize_nhwc(src.d_output, q_in, B, src.out_c, l.h, l.w, src.out_c, l.input_quant_multipler,
                                                    s, g_off, l.Cpad / 16), "quantize_route");
                     g_off += src.out_c / 16;
@@ -908,6 +931,7 @@ static int forward_layer(Network &net, size_t i, const float *input)
                                   l.out_w, l.out_h, l.out_c, l.activation, s), "shortcut");
         break;
     case YL_UPSAMPLE:
+        if (l.skip_f32_out) break;             // its only reader quantises straight from this layer's input
         YL_LAUNCH(launch_upsample(input, l.d_output, B, l.c, l.h, l.w, l.stride, l.scale, s), "upsample");
         break;
     case YL_YOLO:
@@ -951,7 +975,7 @@ static int forward(Network &net, const float *input_dev, int slot)
 // whose only reader takes the int8 side output)
 static bool layer_materialised(const Layer &l)
 {
-    if (l.type == YL_MAXPOOL || l.type == YL_ROUTE) return !l.skip_f32_out;
+    if (l.type == YL_MAXPOOL || l.type == YL_ROUTE || l.type == YL_UPSAMPLE) return !l.skip_f32_out;
     return !(l.type == YL_CONVOLUTIONAL && (l.fused_shortcut >= 0 || l.fused_yolo >= 0 || l.skip_f32_out));
 }
 
@@ -1276,6 +1300,9 @@ int yl_network_layer_traffic(const yl_network *net, int i, double *bytes)
     }
     case YL_ROUTE:
         if (!l.d_output_alias && !(l.n == 1) && !l.skip_f32_out) { rd += 4 * out_el; wr += 4 * out_el; }
+        break;
+    case YL_UPSAMPLE:
+        if (!l.skip_f32_out) { rd += 4 * in_el; wr += 4 * out_el; }
         break;
     default:
         rd += 4 * in_el; wr += 4 * out_el;
