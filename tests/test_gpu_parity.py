@@ -646,7 +646,12 @@ def test_shortcut_fusion_is_bit_identical(width, height, batch):
     for i, li in enumerate(infos):
         nxt = infos[i + 1] if i + 1 < len(infos) else None
         folded = li["type"] == common.CONV and nxt is not None and nxt["type"] in (common.SHORTCUT, common.YOLO)
-        assert fused.layer_materialised(i) == (not folded), "layer %d %r" % (i, li)
+        # (round 5: the [upsample] and the two-input [route] in front of a 1x1 convolution that reads its two sources itself)
+        around = "up+route" in (fused.layer_kernel(i + 1) if li["type"] == common.ROUTE else
+                                (fused.layer_kernel(i + 2) if li["type"] == common.UPSAMPLE else ""))
+        assert fused.layer_materialised(i) == (not folded and not around), "layer %d %r" % (i, li)
+        if around:
+            continue
         if folded:
             skipped += 1              # folded conv: its own tensor is not materialised
             if nxt["type"] == common.YOLO:

@@ -185,6 +185,25 @@ def test_row3_whole_network_yolov3():
         ra, rr = a.get_boxes(im, width, height, 0.24, nms=0.4), ref.get_boxes(im, width, height, 0.24, nms=0.4)
         assert ra.shape == rr.shape and np.allclose(ra, rr, rtol=1e-4, atol=1e-5)
         assert np.array_equal(ra, b.get_boxes(im, width, height, 0.24, nms=0.4))
+    # [upsample] -> [route] -> conv 1x1 (layers 85-87, 97-99): under fusion K1x reads the two sources directly, the upsampled tensor
+    # and the concatenation are not written (and everything behind them equalled the unfused run above)
+    two = [i for i in range(a.n) if "up+route" in kernels[i]]
+    assert len(two) == 2 and not any("up+route" in b.layer_kernel(i) for i in range(b.n)), kernels
+    for i in two:
+        assert not a.layer_materialised(i - 1) and not a.layer_materialised(i - 2) and b.layer_materialised(i - 1) and b.layer_materialised(i - 2)
+    # ... and a knob that moves those convolutions to another kernel brings the two layers back in the same pass (same bits)
+    head = a.predict(x).copy()
+    a.set_conv_tile(14)
+    again = a.predict(x).copy()
+    assert all(a.layer_materialised(i - 1) and a.layer_materialised(i - 2) and "x3" not in a.layer_kernel(i) for i in two)
+    li, ls = a.layer_info(two[0] - 1), a.layer_info(two[0] - 3)             # the [route] and the convolution in front of the [upsample]
+    cat = a.layer_output(two[0] - 1).reshape(batch, li["out_c"], li["out_h"], li["out_w"])
+    src = a.layer_output(two[0] - 3).reshape(batch, ls["out_c"], ls["out_h"], ls["out_w"])
+    assert np.array_equal(cat[:, :ls["out_c"]].view(np.uint32), src.repeat(2, axis=2).repeat(2, axis=3).view(np.uint32))
+    a.set_conv_tile(0)
+    assert np.array_equal(head.view(np.uint32), a.predict(x).view(np.uint32))
+    ok, ratio, _ = fp32_close(again, head)
+    assert ok, ratio
     ref.close(); a.close(); b.close()
 
 

@@ -548,6 +548,11 @@ bool conv_f32_pool_fusable(const ConvF32Args &a0, const ConvF32Opts &o_in)
            wino_applicable(a.C, a.M, a.size, a.stride, a.pad) && a.H >= 4 && a.W >= 4 && a.C / 4 >= 4 && ((a.C / 4) & 1) == 0;
 }
 
+bool conv_f32_two_source_now(const ConvF32Args &a, const ConvF32Opts &o)
+{
+    return o.force_tile == 0 && (o.variant & 1024) && !(o.variant & 4096) && x3_two_source_ok(a);
+}
+
 // Kernel choice for one FP32 convolution.  o.force_tile: 0 = heuristic, 11..22 = direct tile
 // 1..12 of launch_conv_f32_direct, 31 = Winograd (error if the layer has no packed U).
 int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o_in, void *stream, char *name, size_t name_len)
@@ -560,6 +565,8 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o_in, void *stream,
     // measured on MI355X (tools/sweep_conv.py, yolov3-608 shapes, B=64): with 32 input channels
     // ([64,288,92416]) Winograd wins stand-alone (1.59 vs 2.16 ms) but not in the network, where the
     // layer carries a fused shortcut and is bound by 3 GB of epilogue traffic (2.31 vs 2.2 ms): C >= 64.
+    if (a.in2)                                                        // two-source 1x1: only K1x reads it (the runtime asked conv_f32_two_source_now)
+        return conv_f32_two_source_now(a, o) ? launch_conv_f32_x3(a, 0, stream, name, name_len, false) : (int)hipErrorInvalidValue;
     if (a.q_out && a.wino32_u) return (int)hipErrorInvalidValue;      // the planner gives q_out to direct layers only
     // a fused [maxpool] needs a kernel that has the pooled output (the runtime checks conv_f32_pool_fusable before every launch
     // and degrades to the stand-alone pooling kernel when a knob has moved the layer elsewhere: this is the backstop)

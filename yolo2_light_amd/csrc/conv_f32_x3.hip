@@ -89,6 +89,11 @@ struct ConvX3Dev {
     int taps, nkb;
     int Ntotal, OHW, tiles_m;
     int yolo_entries;       // > 0: the [yolo] layer behind a linear 1x1 head folded into the epilogue (as in conv_f32_mfma.hip)
+    // SRC2 instances (1x1 layers): the input is the channel concatenation of TWO tensors that is never built -- channels 0 .. C1 - 1
+    // = `in`, a tensor of (H / up) x (W / up) read through a nearest-neighbour [upsample] by `up` (pixel (y, x) takes (y / up, x / up)),
+    // channels C1 .. C - 1 = `in2` at H x W: [upsample] -> [route] -> conv of yolov3 (forward_upsample_layer_cpu / forward_route_layer_cpu)
+    const float *in2;
+    int C1, up;
 };
 
 // two FP32 values -> their three bf16 pieces, packed (low half = x)
@@ -107,7 +112,9 @@ __device__ __forceinline__ void split3_pair(float x, float y, unsigned &p1, unsi
 // KS: 1 / 3 = the layer's filter size (compile-time tap decode), 0 = any size <= 5
 // YOLO: rows m with m % yolo_entries not in {2, 3} get logistic_activate (forward_yolo_layer_cpu; the expression of
 // yolo_kernel in layers.hip, so the tensor is bit-identical to the unfused pair of layers)
-template <int BM, int BN, int WM, int WN, int KS, bool MFULL, bool YOLO = false, bool PIPE = false>
+// SRC2 (KS = 1): two-source input, see ConvX3Dev -- a panel of 16 channels lies in one source (C1 % 16 == 0), which one is a scalar
+// decision per panel: descriptor, lane offset and channel stride are selected, the loads are the same
+template <int BM, int BN, int WM, int WN, int KS, bool MFULL, bool YOLO = false, bool PIPE = false, bool SRC2 = false>
 // (occupancy as before the straight-line epilogue: 148 VGPRs = three waves per SIMD at 128 x 128, four at 64 x 128 -- hipcc otherwise
 // computes all 64 outputs of a block at once and takes 192-244 registers)
 __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : (BM == 64 ? (BN == 64 ? 3 : 4) : 2)) void conv_f32_x3_kernel(ConvX3Dev p)
@@ -172,6 +179,17 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : (BM ==
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)tile_base, 0, (int)(unsigned)rec, 0x00020000);
     const int voff = (int)(((unsigned)(bimg - b_first) * (unsigned)img_floats + (unsigned)(oy * p.stride) * (unsigned)p.W +
                             (unsigned)(ox * p.stride)) * 4u);
+    // SRC2: the descriptor / lane offset above are not used; source 1 (upsampled on the fly) and source 2 get their own
+    static_assert(!SRC2 || KS == 1, "two-source input: 1x1 layers");
+    const int W1 = SRC2 ? p.W / p.up : 0, HW1 = SRC2 ? (p.H / p.up) * W1 : 0, C2 = SRC2 ? p.C - p.C1 : 0;
+    const size_t img1 = (size_t)(SRC2 ? p.C1 : 0) * HW1, img2 = (size_t)C2 * HW;
+    size_t rec1 = ((size_t)p.B - b_first) * img1 * sizeof(float), rec2 = ((size_t)p.B - b_first) * img2 * sizeof(float);
+    if (rec1 > 0xFFFFFFFEull) rec1 = 0xFFFFFFFEull;
+    if (rec2 > 0xFFFFFFFEull) rec2 = 0xFFFFFFFEull;
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)(SRC2 ? p.in + (size_t)b_first * img1 : p.in), 0, SRC2 ? (int)(unsigned)rec1 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)(SRC2 ? p.in2 + (size_t)b_first * img2 : p.in), 0, SRC2 ? (int)(unsigned)rec2 : 0, 0x00020000);
+    const int voff1 = !SRC2 ? 0 : (n_ok ? (int)(((unsigned)(bimg - b_first) * (unsigned)img1 + (unsigned)(oy / p.up) * (unsigned)W1 + (unsigned)(ox / p.up)) * 4u) : -1);
+    const int voff2 = !SRC2 ? 0 : (n_ok ? (int)(((unsigned)(bimg - b_first) * (unsigned)img2 + (unsigned)oy * (unsigned)p.W + (unsigned)ox) * 4u) : -1);
     unsigned ntapmask = 0xFFFFFFFFu;          // inverted tap validity, bit t = ky * size + kx
     if (n_ok) {
         unsigned m = 0;
@@ -192,8 +210,13 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : (BM ==
     float b_raw[OPT][8];
     int pn_tap = 0, pn_c0 = 0;                // tap / first channel of the NEXT panel to be loaded
     int pn_soff = 0, pn_tinv = 0;
+    bool pn_first = true;                     // SRC2: the next panel's channels lie in source 1
 #define X3_PANEL_SETUP()                                                                           \
-    {                                                                                              \
+    if constexpr (SRC2) {                                                                          \
+        pn_first = pn_c0 < p.C1;                                                                   \
+        pn_soff = pn_first ? pn_c0 * HW1 * 4 : (pn_c0 - p.C1) * HW * 4;                            \
+        pn_tinv = pn_c0 < p.C ? 0 : -1;                                                            \
+    } else {                                                                                       \
         const int ky = (KS == 3) ? ((pn_tap * 11) >> 5) : ((KS == 1) ? 0 : pn_tap / size);         \
         const int kx = pn_tap - ky * size;                                                         \
         pn_soff = (pn_c0 * HW + ky * p.W + kx) * 4;                                                \
@@ -217,7 +240,20 @@ __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : (BM ==
         if (A_FULL || idx < A_UNITS) As[(BUF) * 6 * BM + idx] = __builtin_bit_cast(uint4, a_reg[E]); \
     }
 #define X3_LOAD_B()                                                                                \
-    {                                                                                              \
+    if constexpr (SRC2) {                                                                          \
+        /* (two straight-line forms behind one scalar branch: a select of the 128-bit descriptor would cost four s_cselect per load) */ \
+        if (pn_first) {                                                                            \
+            _Pragma("unroll") for (int o = 0; o < OPT; ++o)                                        \
+                _Pragma("unroll") for (int e = 0; e < 8; ++e)                                      \
+                    b_raw[o][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(  \
+                        rs1, voff1 | pn_tinv, pn_soff + ((oct0 + o) * 8 + e) * HW1 * 4, 0));       \
+        } else {                                                                                   \
+            _Pragma("unroll") for (int o = 0; o < OPT; ++o)                                        \
+                _Pragma("unroll") for (int e = 0; e < 8; ++e)                                      \
+                    b_raw[o][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(  \
+                        rs2, voff2 | pn_tinv, pn_soff + ((oct0 + o) * 8 + e) * HW * 4, 0));        \
+        }                                                                                          \
+    } else {                                                                                       \
         _Pragma("unroll") for (int o = 0; o < OPT; ++o)                                            \
             _Pragma("unroll") for (int e = 0; e < 8; ++e)                                          \
                 b_raw[o][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(      \
@@ -423,7 +459,12 @@ int launch_x3_tile(ConvX3Dev p, hipStream_t s)
         if (mfull) hipLaunchKernelGGL((conv_f32_x3_kernel<BM, BN, WM, WN, KS, true, false, PIPE>), grid, block, 0, s, p); \
         else hipLaunchKernelGGL((conv_f32_x3_kernel<BM, BN, WM, WN, KS, false, false, PIPE>), grid, block, 0, s, p); \
     }
-    if (p.size == 1 && p.yolo_entries > 0) {
+    if (p.in2) {            // two-source 1x1 (x3_two_source_ok): the 128 x 128 and 64 x 64 tiles have the instance
+        if constexpr ((BM == 128 && BN == 128 && PIPE) || (BM == 64 && BN == 64)) {
+            if (mfull) hipLaunchKernelGGL((conv_f32_x3_kernel<BM, BN, WM, WN, 1, true, false, PIPE, true>), grid, block, 0, s, p);
+            else hipLaunchKernelGGL((conv_f32_x3_kernel<BM, BN, WM, WN, 1, false, false, PIPE, true>), grid, block, 0, s, p);
+        } else return (int)hipErrorInvalidValue;
+    } else if (p.size == 1 && p.yolo_entries > 0) {
         if (mfull) hipLaunchKernelGGL((conv_f32_x3_kernel<BM, BN, WM, WN, 1, true, true>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((conv_f32_x3_kernel<BM, BN, WM, WN, 1, false, true>), grid, block, 0, s, p);
     } else if (p.yolo_entries > 0) return (int)hipErrorInvalidValue;
@@ -474,6 +515,14 @@ void x3_pack_weights(const float *w, int C, int M, int size, void *dst)
             }
 }
 
+// a 1x1 layer whose input is [route]([upsample](a.in), a.in2), read from the two tensors directly (ConvX3Dev::in2)
+bool x3_two_source_ok(const ConvF32Args &a)
+{
+    return a.x3_w && a.in2 && a.size == 1 && a.stride == 1 && a.pad == 0 && a.in2_C1 > 0 && a.in2_C1 < a.C && (a.in2_C1 % 16) == 0 &&
+           ((a.C - a.in2_C1) % 16) == 0 && a.in2_up >= 1 && (a.H % a.in2_up) == 0 && (a.W % a.in2_up) == 0 && a.M > 64 &&
+           a.OH == a.H && a.OW == a.W && a.yolo_entries == 0 && !a.q_out && !a.bits_out && !a.pool_out;
+}
+
 // tile: 0 = heuristic, 1 = 128x128 (wave tile 64x64), 2 = 64x128 (32x64), 3 = 32x256 (32x64), 4 = 64x64 (two waves of 32x64: small grids),
 // 5 = 128x128 without the pinned schedule (A/B)
 int launch_conv_f32_x3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len, bool plain)
@@ -481,8 +530,10 @@ int launch_conv_f32_x3(const ConvF32Args &a, int tile, void *stream, char *name,
     if (!a.x3_w || !x3_applicable(a.C, a.M, a.size, a.stride, a.pad) || (!a.out && !a.add) || (a.add && !a.out_add) || a.q_out ||
         a.bits_out || a.pool_out || (a.yolo_entries > 0 && (a.size != 1 || a.add)))
         return (int)hipErrorInvalidValue;
+    if (a.in2 && (!x3_two_source_ok(a) || (tile != 0 && tile != 1 && tile != 4) || plain)) return (int)hipErrorInvalidValue;
     ConvX3Dev d;
     d.in = a.in; d.w3 = a.x3_w; d.bias = a.bias; d.out = a.out; d.add = a.add; d.out_add = a.out_add;
+    d.in2 = a.in2; d.C1 = a.in2_C1; d.up = a.in2_up;
     d.B = a.B; d.C = a.C; d.H = a.H; d.W = a.W; d.M = a.M; d.OH = a.OH; d.OW = a.OW;
     d.Mpad = (a.M + X3_MPAD - 1) / X3_MPAD * X3_MPAD;
     d.size = a.size; d.stride = a.stride; d.pad = a.pad; d.act = a.act;
@@ -522,7 +573,7 @@ int launch_conv_f32_x3(const ConvF32Args &a, int tile, void *stream, char *name,
     case 5: t = "128x128,plain"; rc = launch_x3_tile<128, 128, 2, 2>(d, s); break;
     default: return (int)hipErrorInvalidValue;
     }
-    if (name) snprintf(name, name_len, "conv_f32_x3<%s,ks%d%s>", t, a.size, a.yolo_entries > 0 ? ",yolo" : "");
+    if (name) snprintf(name, name_len, "conv_f32_x3<%s,ks%d%s>", t, a.size, a.yolo_entries > 0 ? ",yolo" : (a.in2 ? ",up+route" : ""));
     return rc;
 }
 

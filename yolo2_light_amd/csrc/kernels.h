@@ -37,6 +37,8 @@ struct ConvF32Args {
     int q_G = 0;          // its channel groups (Cpad/16); direct kernel only, needs M % 16 == 0
     uint64_t *bits_out = nullptr;   // optional sign words (x > 0) of the activated output, bits[B][1][OH][OW], for an XNOR
                           // convolution behind this layer; first-layer kernel only (conv_f32_smallk.hip, M <= 32)
+    const float *in2 = nullptr;   // two-source 1x1 layers (conv_f32_x3.hip only, x3_two_source_ok): the layer's input is the channel
+    int in2_C1 = 0, in2_up = 0;   // concatenation [upsample by in2_up of `in` (in2_C1 channels at H/up x W/up), `in2` (C - in2_C1 channels)]
     bool bits_pooled = false;  // bits_out receives the sign words of the 2x2 / stride-2 [maxpool] behind the layer, bits[B][1][OH/2][OW/2]
                           // (the OR of each window's words); conv_f32_firstm.hip only
     float *pool_out = nullptr; // optional fused [maxpool] 2x2 / stride 2 / pad 1 behind the layer (H, W even): [B][M][H/2][W/2],
@@ -89,6 +91,9 @@ bool wino32_fits(int B, int M, int H, int W);     // output tensor below 4 GB (3
 bool x3_applicable(int C, int M, int size, int stride, int pad);
 size_t x3_packed_bytes(int C, int M, int size);
 void x3_pack_weights(const float *w, int C, int M, int size, void *dst);
+bool x3_two_source_ok(const ConvF32Args &a);
+// ... and whether launch_conv_f32 would run that form with these knobs (the runtime asks before it skips the [upsample] / [route] layers)
+bool conv_f32_two_source_now(const ConvF32Args &a, const ConvF32Opts &o);
 int launch_conv_f32_x3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len, bool plain = false);
 // K1r (conv_f32_row3.hip): 3x3 / stride 1 / pad 1 as row-wise Winograd F(2,3) on the BF16 matrix pipe, three-piece operands
 bool row3_applicable(int C, int M, int size, int stride, int pad);

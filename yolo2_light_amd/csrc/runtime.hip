@@ -489,7 +489,8 @@ static int to_device(Network &net, int device)
     }
     if (net.binbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_binbuf, net.binbuf_bytes));
     // ---- optional conv+shortcut fusion plan ----
-    for (Layer &l : net.layers) { l.fused_shortcut = -1; l.fused_yolo = -1; l.fused_pool = -1; l.fused_into_conv = false; }
+    for (Layer &l : net.layers) { l.fused_shortcut = -1; l.fused_yolo = -1; l.fused_pool = -1; l.fused_into_conv = false;
+                                  l.two_src_up = -1; l.two_src_other = -1; l.two_src_conv = -1; l.two_src_skipped = false; }
     if (net.fuse && !net.debug) {
         const int nl = (int)net.layers.size();
         for (int i = 1; i < nl; ++i) {
@@ -674,6 +675,37 @@ static int to_device(Network &net, int device)
                 }
             }
         }
+        // ---- [upsample] -> [route](upsampled, other) -> conv 1x1 (FP32): K1x reads the two tensors directly -- source 1 through the
+        //      nearest-neighbour index map, source 2 as it is -- so neither the upsampled tensor nor the concatenation is written
+        //      (yolov3 layers 85-87 and 97-99: 0.51 ms of copies per step at 608 x 608, batch 64).  The same values in the same channel
+        //      order: the same bits.  Whether the kernel of the moment can do it is asked per forward pass (conv_f32_two_source_now).
+        auto tensor_written = [&](const Layer &x) {
+            if (x.type == YL_MAXPOOL || x.type == YL_ROUTE || x.type == YL_UPSAMPLE) return !x.skip_f32_out && !x.fused_into_conv;
+            return !(x.type == YL_CONVOLUTIONAL && (x.fused_shortcut >= 0 || x.fused_yolo >= 0 || x.skip_f32_out));
+        };
+        for (int j = 2; j < nl; ++j) {
+            Layer &cv = net.layers[j];
+            Layer &rt = net.layers[j - 1];
+            if (cv.type != YL_CONVOLUTIONAL || cv.conv_mode != CONV_F32 || cv.xnor || cv.binarize_input || !cv.d_weights_x3) continue;
+            if (cv.size != 1 || cv.stride != 1 || cv.pad != 0 || cv.fused_yolo >= 0) continue;
+            if (rt.type != YL_ROUTE || rt.n != 2 || rt.d_output_alias || rt.skip_f32_out || referenced_elsewhere(j - 1, j)) continue;
+            const int u = rt.input_layers[0], o = rt.input_layers[1];
+            Layer &up = net.layers[u];
+            const Layer &ot = net.layers[o];
+            if (up.type != YL_UPSAMPLE || up.scale != 1.f || up.stride < 2 || u < 1 || up.skip_f32_out) continue;
+            if (up.out_h != up.h * up.stride || up.out_w != up.w * up.stride || up.out_h != cv.h || up.out_w != cv.w) continue;
+            if (ot.out_h != cv.h || ot.out_w != cv.w || up.out_c + ot.out_c != cv.c || !tensor_written(ot) || !tensor_written(net.layers[u - 1])) continue;
+            bool other = false;                         // the upsampled tensor: read by this [route] only
+            for (int m = u + 1; m < nl && !other; ++m) {
+                const Layer &x = net.layers[m];
+                if (m == u + 1 && x.type != YL_ROUTE) other = true;
+                if (x.type == YL_SHORTCUT && x.index == u) other = true;
+                if (x.type == YL_ROUTE && m != j - 1) for (int id : x.input_layers) if (id == u) other = true;
+            }
+            if (other) continue;
+            cv.two_src_up = u; cv.two_src_other = o;
+            up.two_src_conv = j; rt.two_src_conv = j;
+        }
         // ---- 2x2 / stride-2 [maxpool] folded into the FP32 convolution in front of it (round 4): the kernels whose
         //      lanes finish whole pooling windows (K1f: a 2 x 4 patch per lane; K1w: an F(2x2) output tile) write the
         //      pooled tensor themselves; the full-resolution tensor is written only where something else reads it
@@ -710,6 +742,22 @@ static int to_device(Network &net, int device)
     return YL_OK;
 }
 
+// does the FP32 1x1 convolution `j` read [route]([upsample](x), y) from x and y directly in this pass?  (plan + the kernel-selection
+// knobs of the moment; asked by the [upsample], the [route] and the convolution itself: one answer per pass)
+static bool two_source_now(const Network &net, int j)
+{
+    const Layer &l = net.layers[j];
+    if (l.two_src_up < 0) return false;
+    const Layer &up = net.layers[l.two_src_up];
+    ConvF32Args a;
+    a.in = nullptr; a.wt = nullptr; a.bias = nullptr; a.add = nullptr; a.out_add = nullptr; a.out = nullptr;
+    a.x3_w = l.d_weights_x3;
+    a.in2 = net.layers[l.two_src_other].d_output; a.in2_C1 = up.out_c; a.in2_up = up.stride;
+    a.B = net.batch; a.C = l.c; a.H = l.h; a.W = l.w; a.M = l.n; a.OH = l.out_h; a.OW = l.out_w;
+    a.size = l.size; a.stride = l.stride; a.pad = l.pad; a.act = l.activation;
+    return hot_activation(l.activation) && conv_f32_two_source_now(a, net.conv_opts);
+}
+
 // ------------------------------------------------------------------ forward
 static int forward_layer(Network &net, size_t i, const float *input)
 {
@@ -731,6 +779,11 @@ static int forward_layer(Network &net, size_t i, const float *input)
             }
             a.in = conv_in; a.wt = l.d_weights_t; a.bias = l.d_biases; a.add = nullptr; a.out_add = nullptr;
             a.out = l.skip_f32_out ? nullptr : l.d_output;
+            if (l.two_src_up >= 0 && two_source_now(net, (int)i)) {      // [upsample] and [route] in front of it wrote nothing in this pass
+                const Layer &up = net.layers[l.two_src_up];
+                a.in = net.layers[l.two_src_up - 1].d_output;
+                a.in2 = net.layers[l.two_src_other].d_output; a.in2_C1 = up.out_c; a.in2_up = up.stride;
+            }
             if (l.q_out_layer >= 0) {
                 const Layer &nx = net.layers[l.q_out_layer];
                 a.q_out = net.d_qbuf + (l.q_out_layer % 3) * net.qbuf_bytes;
@@ -916,6 +969,8 @@ static int forward_layer(Network &net, size_t i, const float *input)
     }
     case YL_ROUTE: {
         if (l.d_output_alias || l.skip_f32_out) break;          // alias, or quantised straight from its sources
+        l.two_src_skipped = l.two_src_conv >= 0 && two_source_now(net, l.two_src_conv);
+        if (l.two_src_skipped) break;                           // the convolution behind it reads the two sources itself
         size_t offset = 0;
         for (int k = 0; k < l.n; ++k) {
             const Layer &src = net.layers[l.input_layers[k]];
@@ -932,6 +987,8 @@ static int forward_layer(Network &net, size_t i, const float *input)
         break;
     case YL_UPSAMPLE:
         if (l.skip_f32_out) break;             // its only reader quantises straight from this layer's input
+        l.two_src_skipped = l.two_src_conv >= 0 && two_source_now(net, l.two_src_conv);
+        if (l.two_src_skipped) break;          // its only reader's reader indexes this layer's input itself
         YL_LAUNCH(launch_upsample(input, l.d_output, B, l.c, l.h, l.w, l.stride, l.scale, s), "upsample");
         break;
     case YL_YOLO:
@@ -975,6 +1032,7 @@ static int forward(Network &net, const float *input_dev, int slot)
 // whose only reader takes the int8 side output)
 static bool layer_materialised(const Layer &l)
 {
+    if (l.two_src_skipped) return false;
     if (l.type == YL_MAXPOOL || l.type == YL_ROUTE || l.type == YL_UPSAMPLE) return !l.skip_f32_out;
     return !(l.type == YL_CONVOLUTIONAL && (l.fused_shortcut >= 0 || l.fused_yolo >= 0 || l.skip_f32_out));
 }
@@ -1276,6 +1334,10 @@ int yl_network_layer_traffic(const yl_network *net, int i, double *bytes)
             const bool k1x = strncmp(l.kernel_name, "conv_f32_x3", 11) == 0, k1r = strncmp(l.kernel_name, "conv_f32_row3", 13) == 0;
             const bool k1w = strncmp(l.kernel_name, "conv_f32_wino", 13) == 0;
             rd += 4 * in_el + (k1x ? 6.0 : (k1r ? 8.0 : (k1w ? 4.0 * 16.0 / 9.0 : 4.0))) * wel;
+            if (l.two_src_up >= 0 && n.layers[l.two_src_up].two_src_skipped) {     // the upsampled source is read at its own resolution
+                const Layer &up = n.layers[l.two_src_up];
+                rd -= 4.0 * B * up.out_c * ((double)up.out_h * up.out_w - (double)up.h * up.w);
+            }
             if (l.binarize_input) { rd += 4 * in_el; wr += 4 * in_el; }
             if (l.bits_out_slot >= 0) wr += B * (double)l.out_h * l.out_w * 8.0 * ((l.n + 63) / 64);
         }
@@ -1299,10 +1361,10 @@ int yl_network_layer_traffic(const yl_network *net, int i, double *bytes)
         break;
     }
     case YL_ROUTE:
-        if (!l.d_output_alias && !(l.n == 1) && !l.skip_f32_out) { rd += 4 * out_el; wr += 4 * out_el; }
+        if (!l.d_output_alias && !(l.n == 1) && !l.skip_f32_out && !l.two_src_skipped) { rd += 4 * out_el; wr += 4 * out_el; }
         break;
     case YL_UPSAMPLE:
-        if (!l.skip_f32_out) { rd += 4 * in_el; wr += 4 * out_el; }
+        if (!l.skip_f32_out && !l.two_src_skipped) { rd += 4 * in_el; wr += 4 * out_el; }
         break;
     default:
         rd += 4 * in_el; wr += 4 * out_el;

@@ -81,6 +81,9 @@ struct Layer {
     char kernel_name[64] = "";           // kernel instance of this layer's last launch
     int   fused_shortcut = -1;           // conv: index of the [shortcut] layer folded into its epilogue
     int   fused_yolo = -1;               // FP32 1x1 head conv: index of the [yolo] layer folded into its epilogue
+    int   two_src_up = -1, two_src_other = -1;   // FP32 1x1 conv behind [route]([upsample], other): the two layers it can read directly (K1x)
+    int   two_src_conv = -1;             // that [upsample] / [route]: the convolution that reads around them
+    bool  two_src_skipped = false;       // ... and whether the last forward pass did (then this layer's tensor was not written)
     int   fused_pool = -1;               // FP32 conv (K1f / K1w): index of the 2x2 / stride-2 [maxpool] layer its epilogue also writes
     bool  pool_follows = false;          // FP32 conv in front of a 2x2 / stride-2 [maxpool] its kernel can fold in: keeps that kernel (K1f / K1w)
     bool  fused_into_conv = false;       // shortcut: produced by the preceding conv's epilogue
