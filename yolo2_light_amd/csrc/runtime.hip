@@ -687,7 +687,7 @@ static int to_device(Network &net, int device)
             Layer &cv = net.layers[j];
             Layer &rt = net.layers[j - 1];
             if (cv.type != YL_CONVOLUTIONAL || cv.conv_mode != CONV_F32 || cv.xnor || cv.binarize_input || !cv.d_weights_x3) continue;
-            if (cv.size != 1 || cv.stride != 1 || cv.pad != 0 || cv.fused_yolo >= 0) continue;
+            if (cv.size != 1 || cv.stride != 1 || cv.pad != 0 || cv.fused_yolo >= 0 || cv.q_out_layer >= 0 || cv.bits_out_slot >= 0 || cv.fused_pool >= 0) continue;
             if (rt.type != YL_ROUTE || rt.n != 2 || rt.d_output_alias || rt.skip_f32_out || referenced_elsewhere(j - 1, j)) continue;
             const int u = rt.input_layers[0], o = rt.input_layers[1];
             Layer &up = net.layers[u];
