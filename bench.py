@@ -16,12 +16,13 @@ leg, the `-quantized` INT8 leg of the same workload is timed in the same run and
 Scaling is STRONG by default (config 3: the batch of 64 independent images is sharded over the N GPUs with
 yl_shard_range, 64/N images per GPU); `--scaling weak` keeps `--batch` images per GPU.
 
-Rank 0 prints ONE JSON line with the driver's fields plus
-  "roofline"     -- dominant kernel of the FP32 leg: EXECUTED matrix FLOPs of its launches (for the Winograd
-                    kernel the 16-multiply form incl. odd-size tile padding, i.e. what the MFMA pipe issued)
-                    / their HIP-event-measured duration inside the timed region, vs the 157.3 TFLOP/s FP32
-                    matrix peak: `frac` <= 1.  The algorithmic rate (2*M*K*N) and the Winograd
-                    speed-up are separate fields.  `traffic` of the FP32 leg is MEASURED in the run (N=1, default
+Rank 0 prints ONE compact JSON line (< 4 KB: compact_line) as the LAST stdout line -- the driver's fields, `roofline`,
+`cpu_baseline` and one number per side leg -- and writes everything else to bench_detail.json + stderr:
+  "roofline"     -- dominant kernel of the FP32 leg.  K1r / K1x run on the BF16 matrix pipe with every FP32 operand the
+                    exact sum of three bf16 pieces: `achieved` = ISSUED BF16-MFMA FLOPs of its launches / their
+                    HIP-event-measured duration inside the timed region, `peak` = the 2 500 TFLOP/s dense BF16 peak,
+                    `frac` <= 1.  `algorithmic_tflops` (2*M*K*N) and its ratio to the 157.3 TFLOP/s
+                    FP32-matrix peak are separate fields.  `traffic` is MEASURED in the run (N=1, default
                     line): two child runs of one step under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE
                     (separate passes); the committed passes (profiles/pmc_traffic.json) are the fallback and the
                     source for the other legs.
@@ -794,13 +795,14 @@ def group_leg(args, torch, dev, Network, cfg, wts, x, steps=4):
             "what": "yl_group_forward + yl_group_detect_batch (ncclSend/ncclRecv gather to the root) on 1 device"}
 
 
-def side_leg(args, torch, dist, dev, stream, Network, weights, zoo, model, size, batch, steps=10, warmup=2):
+def side_leg(args, torch, dist, dev, stream, Network, weights, zoo, model, size, batch):
     """BASELINE configs 2 and 5 as short extra legs of the default line: the same step
     (forward + on-device decode + NMS, inputs resident in HBM) on yolov3-tiny 416 batch 32 FP32 / tiny-yolo-xnor 416
     batch 128, each with the roofline block of its dominant kernel."""
     import copy
     a = copy.copy(args)
     a.model, a.size, a.batch, a.global_batch = model, size, batch, batch
+    steps, warmup = args.steps, args.warmup          # side legs honour --steps / --warmup
     work = tempfile.mkdtemp(prefix="yl_bench_side_")
     cfg = zoo.write_cfg(model, work, size, size)
     wts = os.path.join(work, "synthetic.weights")
@@ -887,6 +889,109 @@ def int8_vs_reference_int8(Network, cfg_q, wts, size, device, thresh, nms, image
         "what": "HIP -quantized path vs the reference's network_predict_quantized (AVX=1 OPENMP=1 build) on the same "
                 "%d synthetic 608-style images, batch 1 each" % images,
     }
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The result line.  The driver reads the LAST stdout line and it has to stay small (round 5's 20.7 KB line was not
+# parsed): stdout gets compact_line(out) (< 4 KB, numbers only, no prose); everything else -- per-kernel / per-pipe
+# dictionaries, side legs, agreement blocks, the prose that says what each number is -- goes to bench_detail.json
+# (repo root, and gpurun_out/ when that exists) and a short summary on stderr.
+LINE_LIMIT_BYTES = 4096
+
+
+def _r(v, sig=5):
+    """Round floats to `sig` significant digits (ints, strings, None, bools pass through)."""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (sig, v))
+    return v
+
+
+def _pick(src, keys, sig=5):
+    if not isinstance(src, dict):
+        return None
+    return {k: _r(src[k], sig) for k in keys if k in src and not isinstance(src[k], (dict, list))}
+
+
+_ROOFLINE_KEYS = ("bound", "pipe", "kernel", "achieved", "peak", "unit", "frac", "frac_at_sclk", "sclk_mhz",
+                  "algorithmic_tflops", "algorithmic_vs_fp32_matrix_peak", "traffic", "algorithmic_bytes_per_launch",
+                  "launches_per_step", "avg_launch_ms", "mfma_frac", "mfma_tops", "measured_ceiling",
+                  "frac_of_measured_ceiling")
+
+
+def compact_line(out: dict) -> dict:
+    """The driver's line: contract fields + roofline + cpu_baseline + one number per side leg.  No prose beyond
+    config.workload; every dropped field is in bench_detail.json."""
+    line = {k: _r(out.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                        "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = out.get("config") or {}
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:240], "global_batch": cfg.get("global_batch"),
+                      "parallelism": cfg.get("parallelism"), "gflop_per_image": _r(cfg.get("gflop_per_image"))}
+    line["roofline"] = _pick(out.get("roofline"), _ROOFLINE_KEYS)
+    cpu = out.get("cpu_baseline")
+    if isinstance(cpu, dict) and "value" in cpu:
+        c = _pick(cpu, ("value", "unit", "cores", "kind"))
+        c["sample"] = str(cpu.get("sample", ""))[:140]
+        if isinstance(cpu.get("int8"), dict):
+            c["int8_value"] = _r(cpu["int8"].get("value"))
+        line["cpu_baseline"] = c
+    else:
+        line["cpu_baseline"] = cpu if cpu is None else {"error": str(cpu.get("error", cpu))[:120]}
+    for leg in ("int8", "bf16"):
+        if isinstance(out.get(leg), dict):
+            d = _pick(out[leg], ("value", "unit", "ms_per_step", "speedup_vs_fp32", "detect_ms_per_step"))
+            d["roofline"] = _pick(out[leg].get("roofline"), ("bound", "kernel", "achieved", "peak", "unit", "frac", "mfma_frac",
+                                                            "mfma_tops", "launches_per_step", "avg_launch_ms"))
+            line[leg] = d
+    line["detect_ms_per_step"] = _r(out.get("detect_ms_per_step"))
+    pc = out.get("pcie_inclusive")
+    if isinstance(pc, dict):
+        line["pcie_inclusive"] = _pick(pc, ("value", "ms_per_step"))
+        if isinstance(pc.get("predict_float_host"), dict):
+            line["pcie_inclusive"]["predict_float_host"] = _r(pc["predict_float_host"].get("value"))
+    bs = out.get("batch_sweep")
+    if isinstance(bs, dict):
+        line["batch_sweep"] = {k: _r(v.get("images_per_sec", v.get("value"))) if isinstance(v, dict) else None
+                               for k, v in bs.items() if k != "error"}
+    for key in ("group_n1", "torchrun_world1", "weak_scaling", "config2_yolov3_tiny_416_b32_fp32",
+                "config5_tiny_yolo_xnor_416_b128", "decode_inclusive", "strict_fp32"):
+        v = out.get(key)
+        if isinstance(v, dict):
+            d = _pick(v, ("value", "ms_per_step", "error"))
+            if isinstance(v.get("roofline"), dict):
+                d["frac"] = _r(v["roofline"].get("frac"))
+            line[key] = d
+    line["detail"] = "bench_detail.json"
+    return line
+
+
+def emit(out: dict):
+    """Detail to bench_detail.json (+ gpurun_out/) and stderr; the compact line as the LAST stdout line."""
+    line = compact_line(out)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT_BYTES:        # never let the line outgrow the driver again: drop side legs, keep the contract
+        for k in ("config5_tiny_yolo_xnor_416_b128", "config2_yolov3_tiny_416_b32_fp32", "batch_sweep", "bf16",
+                  "group_n1", "torchrun_world1", "pcie_inclusive", "weak_scaling"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) < LINE_LIMIT_BYTES:
+                break
+    detail = json.dumps(out, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(detail + "\n")
+        except OSError as ex:
+            print("bench.py: could not write %s/bench_detail.json: %r" % (d, ex), file=sys.stderr)
+    print("bench.py detail (also in bench_detail.json):", file=sys.stderr)
+    print(json.dumps(out), file=sys.stderr)
+    sys.stderr.flush()
+    sys.stdout.flush()
+    print(text, flush=True)
 
 
 def relaunch_one_rank_per_gpu(n: int) -> int:
@@ -1190,7 +1295,7 @@ def main():
             out["bf16"]["what"] = ("opt-in: yl_network_set_precision(BF16) -- bf16 operands on v_mfma_f32_32x32x16_bf16, "
                                    "FP32 accumulate; outside the 1e-4 contract, never `value`")
         out.update(extras)
-        print(json.dumps(out))
+        emit(out)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
