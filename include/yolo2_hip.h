@@ -337,6 +337,15 @@ int yl_network_set_variant(yl_network *net, int bits);
  * (operand rounding ~2^-9 relative): default is YL_PRECISION_FP32. */
 #define YL_PRECISION_FP32 0
 #define YL_PRECISION_BF16 1
+/* YL_PRECISION_FP32_STRICT: every FP32 convolution on the direct implicit-GEMM kernel of the FP32 matrix instruction
+ * (v_mfma_f32_32x32x2_f32, an fmaf chain in gemm_nn's k order per 32-deep block: conv_f32_mfma.hip) -- no Winograd
+ * transform, no three-piece bf16 operands.  Equivalent to yl_network_set_winograd(0) + yl_network_set_variant(62).
+ * The default FP32 path (K1r + K1x) is closer to a float64 evaluation than the reference's own builds but differs from
+ * the reference's SCALAR build by more than 1e-4 relative on ~3e-3 of the yolov3-608 head elements; this mode keeps
+ * that fraction at the level of the reference's own AVX-vs-scalar disagreement (5.7e-4 vs 3.5e-4,
+ * tests/test_gpu_parity.py::test_fp32_error_vs_float64_truth) at ~0.55x the throughput (bench_detail.json
+ * "strict_fp32"). */
+#define YL_PRECISION_FP32_STRICT 2
 int yl_network_set_precision(yl_network *net, int precision);
 /* the same for the INT8 convolution (conv_i8_mfma.hip): 0 = heuristic, 1 = 64x128, 2 = 32x256, 3 = 128x128,
  * 4 = 128x256 (8 waves), 5 = 64x256, 6 / 7 = 128x128 / 64x128 with half-depth LDS panels */

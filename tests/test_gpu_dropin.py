@@ -69,7 +69,12 @@ def test_reference_host_code_quantized():
     ref.predict_hip(x)
     for i in heads:
         g = ref.layer_output(i).astype(np.float64); r = cpu_heads[i]
-        assert np.sqrt(np.mean((g - r) ** 2)) / np.sqrt(np.mean(r * r)) < 0.05
+        # the integer layers are bit-exact and the FP32 first layer keeps gemm_nn's k order, so end to end the heads agree to
+        # FP32 rounding of the un-quantised layers (measured 3e-7 ... 1e-6 at yolov3-608, bench_detail.json
+        # hip_int8_vs_reference_int8): a wrong dequantisation scale on any layer is orders of magnitude above this bound
+        err = np.sqrt(np.mean((g - r) ** 2)) / np.sqrt(np.mean(r * r))
+        print("quantized drop-in head %d: relative RMS error vs network_predict_quantized %.3g" % (i, err))
+        assert err < 1e-4
     ref.lib.ref_free_hip()
 
 

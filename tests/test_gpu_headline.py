@@ -108,6 +108,42 @@ def test_yolov3_608_batch64_fp32_fused_equals_batch1():
     _big_batch_equals_batch1("yolov3", 608, 64, 0, IMAGES, 3 * 60 + 1)
 
 
+def test_yolov3_608_batch64_image_against_the_reference_library_directly():
+    """The benched configuration (batch 64, fusion on) compared with the reference CPU path DIRECTLY, not through the
+    batch-1 chain: image 17 of the batch -- one that the bit-equality test above does not
+    read back -- every materialised tensor against network_predict_cpu of the unmodified reference on that image alone
+    (batch B == B independent images), at the FP32 contract's fp32_close and the strict
+    per-layer relative bound test_full_size_vs_reference_library uses."""
+    common.require_ref()
+    size, B, b = 608, 64, 17
+    cfg, wts = common.model_files("yolov3", size, size)
+    x = common.seeded_input(B, 3, size, size)
+    big = Network.load(cfg, wts, B, 0, device=0, fuse=True)
+    big.predict(x)
+    ref = refbind.RefNetwork(cfg, wts, 1, 0)
+    ref.predict(x[b:b + 1])
+    n = 0
+    worst_ratio = worst_strict = 0.0
+    for i in range(big.n):
+        if not big.layer_materialised(i):
+            continue
+        got = big.layer_output_image(i, b)
+        want = ref.layer_output(i)
+        ok, ratio, worst = fp32_close(got, want)
+        assert ok, "batch-64 image %d layer %d %r: err/allowed %.3g" % (b, i, big.layer_info(i), ratio)
+        strict = common.strict_max_rel(got, want)
+        assert strict <= 2e-2, "batch-64 image %d layer %d: strict max relative error %.3g" % (b, i, strict)
+        worst_ratio, worst_strict = max(worst_ratio, ratio), max(worst_strict, strict)
+        n += 1
+    assert n >= 60
+    r = ref.get_detections(0, size, size, 0.24, nms=0.4)
+    g = big.get_boxes(b, size, size, 0.24, nms=0.4, relative=1)
+    assert abs(len(r) - len(g)) <= 2, "%d vs %d detections" % (len(r), len(g))
+    print("yolov3 608 batch 64 image %d vs the reference: %d tensors, worst fp32_close ratio %.3g, strict max-rel %.3g, %d / %d detections"
+          % (b, n, worst_ratio, worst_strict, len(g), len(r)))
+    big.close()
+
+
 def test_yolov3_608_batch64_int8_fused_equals_batch1():
     _big_batch_equals_batch1("yolov3", 608, 64, 1, IMAGES, 3 * 40)      # (40 tensors per image: the two upsampled ones in front of the multi-input routes are never written)
 

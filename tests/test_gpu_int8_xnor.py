@@ -221,10 +221,10 @@ def test_int8_network_vs_reference_library_batch1():
     x = common.seeded_input(1, 3, height, width)
     ref.predict(x)
     net.predict(x)
-    # Quantisation is a step function of the FP32 inputs: a 1-ulp difference in the FP32 first
-    # layer flips some int8 codes by +-1, and that noise (1/127 relative per flipped code) is
-    # amplified through 10 quantised layers.  Layer exactness is established by the
-    # teacher-forced tests above; here the END-TO-END result must agree statistically.
+    # Layer exactness is established by the teacher-forced tests above; END TO END the integer layers are bit-exact and the
+    # FP32 layers (first conv, linear heads) differ from the reference by FP32 rounding only, so the heads agree to ~1e-6
+    # relative RMS (measured at yolov3-608: 3e-7 ... 1e-6).  A wrong dequantisation scale, a flipped clamp or a skipped
+    # /32 on any one layer is orders of magnitude above the 1e-4 bound.
     for i in range(net.n):
         li = net.layer_info(i)
         if li["type"] not in (common.YOLO,):
@@ -232,8 +232,9 @@ def test_int8_network_vs_reference_library_batch1():
         g = net.layer_output(i).astype(np.float64); r = ref.layer_output(i).astype(np.float64)
         rms = np.sqrt(np.mean(r * r))
         rel_rms_err = np.sqrt(np.mean((g - r) ** 2)) / rms
-        assert rel_rms_err < 0.05, "yolo layer %d: relative RMS error %.4f" % (i, rel_rms_err)
-        assert np.corrcoef(g, r)[0, 1] > 0.995
+        print("yolo layer %d: INT8 end-to-end relative RMS error vs the reference %.3g" % (i, rel_rms_err))
+        assert rel_rms_err < 1e-4, "yolo layer %d: relative RMS error %.3g" % (i, rel_rms_err)
+        assert np.corrcoef(g, r)[0, 1] > 0.99999
     r = ref.get_detections(0, width, height, 0.24, nms=0.4)
     g = net.get_boxes(0, width, height, 0.24, nms=0.4)
     assert abs(len(r) - len(g)) <= max(2, len(r) // 50)

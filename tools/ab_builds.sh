@@ -14,7 +14,7 @@ if [ "$MODE" = build ]; then
   mkdir -p tools/ab yolo2_light_amd/csrc/build_repro
   for v in $VALS; do
     ( cd yolo2_light_amd/csrc
-      case $v in ''|*[!0-9]*) fl_var=ABFLAGS_$v; FL=${!fl_var};; *) FL="-DX_DBG=$v";; esac
+      case $v in ''|*[!0-9]*) fl_var=ABFLAGS_$v; FL=${!fl_var};; *) FL="-DYL_LAB -DX_DBG=$v";; esac
       SLP=""; [ "$SRC" = conv_f32_wino32 ] && SLP="-fno-slp-vectorize"       # as csrc/Makefile builds that file
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $SLP $FL -c $SRC.hip -o build_repro/${SRC}_x$v.o
       objs=$(ls build/*.o | grep -v "build/$SRC.o")

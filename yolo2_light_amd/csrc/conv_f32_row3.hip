@@ -49,10 +49,13 @@
 #include "kernels.h"
 #include "../../include/yolo2_hip.h"
 
-// Lab builds only (tools/ab_builds.sh, ABFILE=conv_f32_row3: -DX_DBG=<bits>; results are garbage by design): 1 no global loads in
+// Lab builds only (tools/ab_builds.sh, ABFILE=conv_f32_row3: -DYL_LAB -DX_DBG=<bits>; results are garbage by design): 1 no global loads in
 // the K loop, 2 no split / B stores, 4 no A stores, 8 no MFMAs, 16 no fragment reads, 32 no epilogue stores, 64 no barriers in
 // the K loop, 128 no A (weight) loads, 256 no input-row loads (+512: their transform + split stay in the loop).  The shipped
-// library is built with X_DBG undefined: every guard below folds away.
+// library is built without -DYL_LAB, which forces X_DBG to 0: every guard below folds away.
+#if !defined(YL_LAB)
+#undef X_DBG
+#endif
 #ifndef X_DBG
 #define X_DBG 0
 #endif

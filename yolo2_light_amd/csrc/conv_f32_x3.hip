@@ -46,7 +46,10 @@
 #include "../../include/yolo2_hip.h"
 
 // Lab builds only (tools/ab_builds.sh, ABFILE=conv_f32_x3: -DX_DBG=<bits>; results are garbage by design): 1 no global loads in the
-// K loop, 2 no split / LDS stores, 4 no MFMAs, 8 no epilogue stores.  The shipped library is built with X_DBG undefined.
+// K loop, 2 no split / LDS stores, 4 no MFMAs, 8 no epilogue stores.  The shipped library is built without -DYL_LAB, which forces X_DBG to 0.
+#if !defined(YL_LAB)
+#undef X_DBG
+#endif
 #ifndef X_DBG
 #define X_DBG 0
 #endif

@@ -1709,8 +1709,17 @@ int yl_network_set_variant(yl_network *net, int bits)
 
 int yl_network_set_precision(yl_network *net, int precision)
 {
-    if (!net || (precision != YL_PRECISION_FP32 && precision != YL_PRECISION_BF16)) { set_error("bad argument"); return YL_ERR_ARG; }
+    if (!net || (precision != YL_PRECISION_FP32 && precision != YL_PRECISION_BF16 && precision != YL_PRECISION_FP32_STRICT)) {
+        set_error("bad argument");
+        return YL_ERR_ARG;
+    }
     if (net->net.on_device) { set_error("set_precision must precede to_device"); return YL_ERR_STATE; }
+    if (precision == YL_PRECISION_FP32_STRICT) {
+        // FP32-MFMA direct kernels only: no Winograd weight images, no three-piece (bits 10 / 11) kernels
+        net->net.conv_opts.winograd = false;
+        net->net.conv_opts.variant = 2 | 4 | 8 | 16 | 32;
+        precision = YL_PRECISION_FP32;
+    }
     net->net.precision = precision;
     select_conv_modes(net->net);
     return YL_OK;

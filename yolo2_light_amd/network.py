@@ -64,7 +64,7 @@ class Network:
     def load(cls, cfg_path: str, weights_path: str, batch: int = 1, quantized: int = 0,
              device: Optional[int] = None, debug: bool = False, fuse: bool = False,
              quant_rule: int = 0, winograd: bool = True, bf16: bool = False, device_prep: bool = False,
-             variant: Optional[int] = None, device_pack: Optional[bool] = None) -> "Network":
+             variant: Optional[int] = None, device_pack: Optional[bool] = None, strict: bool = False) -> "Network":
         """The full prep sequence of test_detector_cpu (src/main.c:160-171)."""
         net = cls.from_cfg(cfg_path, batch, quantized)
         if quant_rule:
@@ -73,6 +73,8 @@ class Network:
             check(lib.yl_network_set_winograd(net._h, 0), "yl_network_set_winograd")
         if bf16:
             net.set_precision(1)
+        if strict:
+            net.set_precision(2)
         if variant is not None:
             net.set_variant(variant)       # before to_device: bit 5 selects the Winograd weight packing
         if device_pack is not None:
@@ -208,7 +210,8 @@ class Network:
         check(lib.yl_network_set_conv_tile(self._h, cfg), "yl_network_set_conv_tile")
 
     def set_precision(self, precision: int) -> None:
-        """0 = FP32 (default), 1 = opt-in BF16 operands for the FP32 convolutions; before to_device"""
+        """0 = FP32 (default), 1 = opt-in BF16 operands for the FP32 convolutions, 2 = strict FP32 (FP32-MFMA direct kernels
+        only); before to_device"""
         check(lib.yl_network_set_precision(self._h, precision), "yl_network_set_precision")
 
     def set_variant(self, bits: int) -> None:
