@@ -738,6 +738,120 @@ def pcie_inclusive(net, torch, stream, args, B, rec, cnt, steps: int = 3):
     }
 
 
+def decode_inclusive(net, torch, stream, args, B, rec, cnt, threads=(1, 8, 32, 64)):
+    """SURVEY 8f-2's open question, answered with a number: does HOST JPEG decode keep up with the GPU?
+    The reference decodes with stb on one core per image (load_image_stb, src/additionally.c:3084-3106, called from
+    src/main.c:187).  A 768x576 JPEG (the size of bin/dog.jpg; made here from a smooth synthetic frame, quality 90, because the
+    reference tree does not travel to the GPU box) is decoded on N host threads (Pillow = libjpeg-turbo, the GIL is released
+    inside the decoder) and every decoded frame goes through the same boundary the PCIe-inclusive leg uses
+    (yl_network_set_input_u8 -> GPU /255 + resize_image -> forward -> detect_batch -> rows on the host).
+    Reported: decode-only img/s and decode-inclusive img/s per thread count, and the reference's own front end
+    (load_image + resize_image on one core, oracle/_ref) beside them."""
+    import io
+    from concurrent.futures import ThreadPoolExecutor
+    try:
+        from PIL import Image
+    except Exception as ex:
+        return {"error": "Pillow not importable: %r" % (ex,)}
+    yy, xx = np.mgrid[0:576, 0:768].astype(np.float32)
+    rng = np.random.default_rng(11)
+    frame = np.stack([127 + 90 * np.sin(xx / 37.0 + c) * np.cos(yy / 23.0 - c) + rng.normal(0, 6, xx.shape) for c in range(3)],
+                     axis=-1).clip(0, 255).astype(np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(frame).save(buf, format="JPEG", quality=90)
+    jpeg = buf.getvalue()
+
+    def decode(_):
+        im = Image.open(io.BytesIO(jpeg))
+        im.draft("RGB", im.size)
+        return np.asarray(im.convert("RGB"))
+
+    rec_h = torch.empty(rec.shape, dtype=rec.dtype).pin_memory()
+    cnt_h = torch.empty(cnt.shape, dtype=cnt.dtype).pin_memory()
+    out = {"jpeg_bytes": len(jpeg), "frame": "768x576x3", "decoder": "Pillow %s (libjpeg-turbo)" % getattr(Image, "__version__", "?"),
+           "host_cores": os.cpu_count(), "by_threads": {}}
+    for nt in threads:
+        if nt > (os.cpu_count() or 1):
+            continue
+        with ThreadPoolExecutor(max_workers=nt) as ex:
+            list(ex.map(decode, range(min(B, 2 * nt))))         # warm the pool
+            t0 = time.perf_counter()
+            frames = list(ex.map(decode, range(B)))
+            t_dec = time.perf_counter() - t0
+            steps = 2
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                for b, fr in enumerate(ex.map(decode, range(B))):
+                    net.set_input_u8(b, fr)
+                net.forward_staged()
+                with torch.cuda.stream(stream):
+                    net.detect_batch(args.thresh, args.nms if args.nms > 0 else 0.4, args.cap, rec.data_ptr(), cnt.data_ptr(),
+                                     sizes=(768, 576), relative=0)
+                    rec_h.copy_(rec, non_blocking=True)
+                    cnt_h.copy_(cnt, non_blocking=True)
+            torch.cuda.synchronize()
+            t_all = (time.perf_counter() - t0) / steps
+        del frames
+        out["by_threads"][str(nt)] = {"decode_only_images_per_sec": B / t_dec, "decode_inclusive_images_per_sec": B / t_all,
+                                      "ms_per_step": t_all * 1e3}
+    best = max(out["by_threads"].values(), key=lambda v: v["decode_inclusive_images_per_sec"]) if out["by_threads"] else None
+    if best:
+        out["value"] = best["decode_inclusive_images_per_sec"]
+        out["unit"] = "images/sec"
+        out["ms_per_step"] = best["ms_per_step"]
+    try:                      # the reference's own front end on one core (stb decode + /255 + resize_image), via oracle/_ref
+        from oracle import refbind
+        if refbind.available():
+            import ctypes as C
+            lib = refbind._bind(refbind.GOLD)
+            if lib is not None:
+                tmp = os.path.join(tempfile.mkdtemp(prefix="yl_jpeg_"), "frame.jpg")
+                with open(tmp, "wb") as f:
+                    f.write(jpeg)
+                dst = np.zeros(3 * args.size * args.size, dtype=np.float32)
+                sw, sh = C.c_int(0), C.c_int(0)
+                fp = dst.ctypes.data_as(C.POINTER(C.c_float))
+                lib.ref_load_resized(tmp.encode(), args.size, args.size, fp, C.byref(sw), C.byref(sh))
+                t0 = time.perf_counter()
+                k = 8
+                for _ in range(k):
+                    lib.ref_load_resized(tmp.encode(), args.size, args.size, fp, C.byref(sw), C.byref(sh))
+                out["reference_front_end_one_core_images_per_sec"] = k / (time.perf_counter() - t0)
+    except Exception as ex:
+        out["reference_front_end_error"] = repr(ex)
+    out["what"] = ("JPEG decode on N host threads -> yl_network_set_input_u8 -> forward -> yl_network_detect_batch -> rows on the host; "
+                   "`value` = the best thread count")
+    return out
+
+
+def strict_leg(args, torch, dev, stream, Network, cfg, wts, x):
+    """YL_PRECISION_FP32_STRICT (every FP32 convolution on the direct FP32-matrix-instruction kernel): the same step, its img/s"""
+    B = x.shape[0]
+    net = Network.load(cfg, wts, B, 0, device=dev.index, fuse=not args.no_fuse, strict=True)
+    net.set_stream(stream.cuda_stream)
+    classes = net.layer_info(net.n - 1)["classes"]
+    rec = torch.zeros((B, args.cap, 6 + classes), device=dev, dtype=torch.float32)
+    cnt = torch.zeros((B,), device=dev, dtype=torch.int32)
+
+    def one():
+        with torch.cuda.stream(stream):
+            net.forward_device(x.data_ptr())
+            net.detect_batch(args.thresh, args.nms if args.nms > 0 else 0.4, args.cap, rec.data_ptr(), cnt.data_ptr())
+    one()
+    torch.cuda.synchronize()
+    steps = max(2, args.steps // 4)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / steps
+    kernels = sorted({net.layer_kernel(i).split("<")[0] for i in range(net.n) if net.layer_kernel(i)})
+    net.close()
+    return {"value": B / t, "unit": "images/sec", "ms_per_step": t * 1e3, "steps": steps, "kernels": kernels,
+            "what": "yl_network_set_precision(YL_PRECISION_FP32_STRICT): FP32-MFMA direct kernels only (no Winograd, no three-piece bf16)"}
+
+
 def batch_sweep(args, torch, dev, stream, Network, cfg, wts, x, batches=(8, 16, 32), steps=4):
     """FP32 step rate of one GPU at the per-rank batch of a strong-scaled 8/4/2-GPU run"""
     out = {}
@@ -1170,6 +1284,11 @@ def main():
                     info["pcie_inclusive"] = pcie_inclusive(leg.net, torch, stream, args, b_local, leg.rec, leg.cnt)
                 except Exception as ex:      # the headline number must not depend on this leg
                     info["pcie_inclusive"] = {"error": repr(ex)}
+                if not args.no_extras:
+                    try:
+                        info["decode_inclusive"] = decode_inclusive(leg.net, torch, stream, args, b_local, leg.rec, leg.cnt)
+                    except Exception as ex:
+                        info["decode_inclusive"] = {"error": repr(ex)}
         result[("fp32", "int8", "bf16")[quantized]] = info
         leg.close()
 
@@ -1205,6 +1324,10 @@ def main():
                 extras["group_n1"] = group_leg(args, torch, dev, Network, cfg, wts, x)
             except Exception as ex:
                 extras["group_n1"] = {"error": repr(ex)}
+            try:
+                extras["strict_fp32"] = strict_leg(args, torch, dev, stream, Network, cfg, wts, x)
+            except Exception as ex:
+                extras["strict_fp32"] = {"error": repr(ex)}
             if args.model == "yolov3" and args.size == 608:
                 del x
                 torch.cuda.empty_cache()
@@ -1281,6 +1404,8 @@ def main():
             "cpu_baseline": cpu,
             "pcie_inclusive": head.get("pcie_inclusive"),
         }
+        if head.get("decode_inclusive") is not None:
+            out["decode_inclusive"] = head["decode_inclusive"]
         if do_fp32 and do_int8:
             i8 = result["int8"]
             out["int8"] = {k: i8.get(k) for k in ("value", "ms_per_step", "roofline", "agreement_vs_fp32",

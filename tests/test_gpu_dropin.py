@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import common
-from common import refbind, fp32_close
+from common import Network, refbind, fp32_close
 
 pytestmark = pytest.mark.gpu
 
@@ -94,3 +94,35 @@ def test_reference_host_code_softmax_tree():
     assert np.abs(got.reshape(-1, sz)[:, 5:8].sum(axis=1) - 1.0).max() < 1e-5        # the root group is a softmax
     np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-6)
     ref.lib.ref_free_hip()
+
+
+@pytest.mark.parametrize("name,size,batch,quantized", [("yolov3-tiny", 96, 5, 0), ("yolov3", 64, 6, 0), ("yolov3", 64, 5, 1),
+                                                       ("tiny-yolo-xnor", 96, 7, 0)])
+def test_pipelined_predict_equals_one_pass(name, size, batch, quantized):
+    """yl_network_predict runs the batch as sub-batches (input of k+1 and heads of k-1 on the copy streams while k computes,
+    runtime.hip BatchWindow): every split, uneven ones included, leaves the bits of ONE pass over the whole batch in every
+    tensor and in the returned host heads."""
+    import torch
+    cfg, wts = common.model_files(name, size, size)
+    x = common.seeded_input(batch, 3, size, size)
+    net = Network.load(cfg, wts, batch, quantized, device=0, fuse=True)
+    xd = torch.from_numpy(x).to("cuda:0")
+    net.forward_device(xd.data_ptr())
+    net.synchronize()
+    want = {i: net.layer_output(i).copy() for i in range(net.n) if net.layer_materialised(i)}
+    old = os.environ.get("YL_PREDICT_SPLIT")
+    try:
+        for split in (1, 2, 3, 4):
+            os.environ["YL_PREDICT_SPLIT"] = str(split)
+            xd.zero_()
+            last = net.predict(x)
+            for i, w in want.items():
+                assert np.array_equal(net.layer_output(i).view(np.uint32), w.view(np.uint32)), "split %d layer %d" % (split, i)
+            if last is not None:
+                assert np.array_equal(np.asarray(last).ravel().view(np.uint32), want[net.n - 1].ravel().view(np.uint32))
+    finally:
+        if old is None:
+            os.environ.pop("YL_PREDICT_SPLIT", None)
+        else:
+            os.environ["YL_PREDICT_SPLIT"] = old
+    net.close()

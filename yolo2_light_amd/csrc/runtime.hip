@@ -141,6 +141,16 @@ static void free_device(Network &net)
     net.d_input = nullptr; net.d_qbuf = nullptr; net.d_bitbuf = nullptr; net.h_pinned = nullptr;
     for (void *e : net.layer_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
     net.layer_events.clear();
+    for (void **st : {&net.in_stream, &net.out_stream}) {
+        if (*st) { (void)hipStreamSynchronize((hipStream_t)*st); (void)hipStreamDestroy((hipStream_t)*st); }
+        *st = nullptr;
+    }
+    for (void *e : net.in_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
+    net.in_events.clear();
+    for (void *e : net.head_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
+    net.head_events.clear();
+    for (void *e : net.chunk_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
+    net.chunk_events.clear();
     if (net.ev0) (void)hipEventDestroy((hipEvent_t)net.ev0);
     if (net.ev1) (void)hipEventDestroy((hipEvent_t)net.ev1);
     net.ev0 = net.ev1 = nullptr;
@@ -467,6 +477,28 @@ static int to_device(Network &net, int device)
             l.host_output = net.h_heads + l.h_head_off;
             l.host_kind = HOST_PINNED;
             l.host_in_heads = true;
+        }
+        // yl_network_predict's pipeline: two copy streams (PCIe is full duplex), per sub-batch an "input landed" event and per
+        // head / last layer an event that forward() records on the compute stream behind the kernel that completes the tensor
+        for (void **st : {&net.in_stream, &net.out_stream})
+            if (!*st) {
+                hipStream_t cs;
+                YL_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+                *st = cs;
+            }
+        const size_t nl = net.layers.size();
+        net.in_events.assign(PREDICT_MAX_SPLIT, nullptr);
+        net.head_events.assign(PREDICT_MAX_SPLIT * nl, nullptr);
+        for (int k = 0; k < PREDICT_MAX_SPLIT; ++k) {
+            hipEvent_t e;
+            YL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            net.in_events[k] = e;
+            for (size_t i = 0; i < nl; ++i) {
+                const Layer &l = net.layers[i];
+                if (!(l.type == YL_YOLO || l.type == YL_REGION || i + 1 == nl)) continue;
+                YL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                net.head_events[k * nl + i] = e;
+            }
         }
     }
     // an FP32 first layer that hands sign words to an XNOR convolution through a [maxpool] writes PRE-pool words
@@ -1023,6 +1055,8 @@ static int forward(Network &net, const float *input_dev, int slot)
         int rc = forward_layer(net, i, input);
         if (rc != YL_OK) return rc;
         input = net.layers[i].d_output;
+        if (net.head_event_base >= 0 && net.head_events[net.head_event_base + i])
+            YL_HIP(hipEventRecord((hipEvent_t)net.head_events[net.head_event_base + i], (hipStream_t)net.stream));
     }
     if (ev) YL_HIP(hipEventRecord((hipEvent_t)ev[nl], (hipStream_t)net.stream));
     return YL_OK;
@@ -1037,48 +1071,101 @@ static bool layer_materialised(const Layer &l)
     return !(l.type == YL_CONVOLUTIONAL && (l.fused_shortcut >= 0 || l.fused_yolo >= 0 || l.skip_f32_out));
 }
 
-// memcpy split over a few host threads (one core moves ~8 GB/s; yolov3-608's heads are 495 MB per batch of 64)
-static void parallel_memcpy(void *dst, const void *src, size_t bytes)
+// D2H of the heads / last layer (what network_predict_* leaves in l.output; the reference pulls each [yolo] tensor with a blocking
+// cudaMemcpy as its layer ends, src/yolov2_forward_network_gpu.cu:438).  Here: on out_stream, each head behind an event recorded on
+// the compute stream (head_event_base >= 0: the one forward() recorded behind that head -- head 82 of yolov3 is complete 40 % into
+// the pass and travels while the rest computes; < 0: one event at the stream's tail), in 16 MB chunks into library-pinned memory;
+// where the destination is caller memory, finish_head_pull copies chunk k out on the host pool while chunk k+1 is on the bus.
+// Images [b0, b0 + nb) of the full batch; l.d_output is the UNSHIFTED tensor (call outside a BatchWindow).
+struct HeadPiece { size_t ev; char *dst; const char *pinned; size_t bytes; };
+
+static int enqueue_head_pull(Network &net, bool also_last, int b0, int nb, int head_event_base, std::vector<HeadPiece> &pieces, size_t &n_ev)
 {
-    unsigned hw = std::thread::hardware_concurrency();
-    const unsigned nt = bytes < ((size_t)4 << 20) ? 1u : (hw >= 8 ? 4u : (hw >= 4 ? 2u : 1u));
-    if (nt == 1) { memcpy(dst, src, bytes); return; }
-    const size_t slice = ((bytes / nt) + 63) & ~(size_t)63;
-    std::vector<std::thread> th;
-    for (unsigned t = 1; t < nt; ++t) {
-        const size_t o = (size_t)t * slice;
-        if (o >= bytes) break;
-        const size_t l = (t + 1 < nt && o + slice < bytes) ? slice : bytes - o;
-        th.emplace_back([=] { memcpy((char *)dst + o, (const char *)src + o, l); });
+    hipStream_t s = (hipStream_t)net.stream, cs = (hipStream_t)net.out_stream;
+    const size_t CHUNK = (size_t)16 << 20;
+    const size_t nl = net.layers.size();
+    hipEvent_t tail = nullptr;
+    if (head_event_base < 0) {            // one event at the tail of the compute stream (the last layer's slot of sub-batch 0 serves)
+        tail = (hipEvent_t)net.head_events[nl - 1];
+        YL_HIP(hipEventRecord(tail, s));
     }
-    memcpy(dst, src, slice < bytes ? slice : bytes);
-    for (auto &x : th) x.join();
+    for (size_t i = 0; i < nl; ++i) {
+        Layer &l = net.layers[i];
+        const bool is_head = (l.type == YL_YOLO || l.type == YL_REGION);
+        if (!(is_head || (also_last && i + 1 == nl))) continue;
+        if (!l.host_output) continue;
+        // the DMA always lands in library-pinned memory: the destination itself, or this layer's region of h_heads
+        const size_t img = sizeof(float) * (size_t)l.outputs;
+        char *pinned = (char *)(l.host_kind == HOST_PINNED ? l.host_output : net.h_heads + l.h_head_off) + (size_t)b0 * img;
+        const bool bounce = l.host_kind != HOST_PINNED;
+        const size_t bytes = img * (size_t)nb;
+        const char *src = (const char *)l.d_output + (size_t)b0 * img;
+        YL_HIP(hipStreamWaitEvent(cs, head_event_base >= 0 ? (hipEvent_t)net.head_events[head_event_base + i] : tail, 0));
+        for (size_t off = 0; off < bytes; off += CHUNK) {
+            const size_t len = bytes - off < CHUNK ? bytes - off : CHUNK;
+            YL_HIP(hipMemcpyAsync(pinned + off, src + off, len, hipMemcpyDeviceToHost, cs));
+            if (n_ev == net.chunk_events.size()) {
+                hipEvent_t e;
+                YL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                net.chunk_events.push_back(e);
+            }
+            YL_HIP(hipEventRecord((hipEvent_t)net.chunk_events[n_ev], cs));
+            if (bounce) pieces.push_back(HeadPiece{n_ev, (char *)l.host_output + (size_t)b0 * img + off, pinned + off, len});
+            ++n_ev;
+        }
+    }
+    return YL_OK;
+}
+
+static int finish_head_pull(Network &net, const std::vector<HeadPiece> &pieces)
+{
+    HostCopyJob job;
+    int rc = YL_OK;
+    for (const HeadPiece &pc : pieces) {
+        if (hipEventSynchronize((hipEvent_t)net.chunk_events[pc.ev]) != hipSuccess) { set_error("D2H of a head chunk failed"); rc = YL_ERR_DEVICE; break; }
+        host_copy_async(job, pc.dst, pc.pinned, pc.bytes);
+    }
+    host_copy_wait(job);
+    if (rc != YL_OK) return rc;
+    YL_HIP(hipStreamSynchronize((hipStream_t)net.out_stream));
+    YL_HIP(hipStreamSynchronize((hipStream_t)net.stream));
+    return YL_OK;
 }
 
 static int pull_heads(Network &net, bool also_last)
 {
-    hipStream_t s = (hipStream_t)net.stream;
-    bool bounce = false;
-    for (size_t i = 0; i < net.layers.size(); ++i) {
-        Layer &l = net.layers[i];
-        const bool is_head = (l.type == YL_YOLO || l.type == YL_REGION);
-        if (!(is_head || (also_last && i + 1 == net.layers.size()))) continue;
-        if (!l.host_output) continue;
-        // the DMA always lands in library-pinned memory: the destination itself, or this layer's region of h_heads
-        float *pinned = l.host_kind == HOST_PINNED ? l.host_output : net.h_heads + l.h_head_off;
-        bounce = bounce || l.host_kind != HOST_PINNED;
-        YL_HIP(hipMemcpyAsync(pinned, l.d_output, sizeof(float) * (size_t)net.batch * l.outputs, hipMemcpyDeviceToHost, s));
-    }
-    YL_HIP(hipStreamSynchronize(s));
-    if (bounce)
-        for (size_t i = 0; i < net.layers.size(); ++i) {
-            Layer &l = net.layers[i];
-            const bool is_head = (l.type == YL_YOLO || l.type == YL_REGION);
-            if (!(is_head || (also_last && i + 1 == net.layers.size())) || !l.host_output || l.host_kind == HOST_PINNED) continue;
-            parallel_memcpy(l.host_output, net.h_heads + l.h_head_off, sizeof(float) * (size_t)net.batch * l.outputs);
-        }
-    return YL_OK;
+    std::vector<HeadPiece> pieces;
+    size_t n_ev = 0;
+    int rc = enqueue_head_pull(net, also_last, 0, net.batch, -1, pieces, n_ev);
+    if (rc != YL_OK) return rc;
+    return finish_head_pull(net, pieces);
 }
+
+// Images [b0, b0 + nb) of the batch as a batch of their own: every kernel takes its image count and tensor bases per launch
+// (forward_layer), images are independent and a batch-B pass equals B batch-1 passes bit for bit
+// (tests/test_gpu_headline.py), so a pass over a window of the tensors IS that part of the full pass.  The scratch rings
+// (d_qbuf, d_bitbuf, d_binbuf) are consumed inside a pass and are reused from their start by every window.
+struct BatchWindow {
+    Network &net;
+    int full, b0;
+    BatchWindow(Network &n, int b0_, int nb) : net(n), full(n.batch), b0(b0_)
+    {
+        shift(+1);
+        net.batch = nb;
+    }
+    ~BatchWindow()
+    {
+        net.batch = full;
+        shift(-1);
+    }
+    void shift(int sign)
+    {
+        for (Layer &l : net.layers)
+            if (l.d_output) l.d_output += (ptrdiff_t)sign * (ptrdiff_t)b0 * (ptrdiff_t)l.outputs;
+        // the library's own input tensor too: forward_layer tells it (front pad, finite) from a caller's device pointer by address
+        if (net.d_input) net.d_input += (ptrdiff_t)sign * (ptrdiff_t)b0 * (ptrdiff_t)net.c * net.h * net.w;
+    }
+};
 
 }  // namespace yl
 
@@ -1430,40 +1517,48 @@ int yl_network_forward(yl_network *net, const float *input_dev)
     return forward(net->net, input_dev, -1);
 }
 
-// Host float images -> pinned staging -> device, in 32 MB chunks: the staging copy of a chunk is
-// split over a few threads (one core moves ~8 GB/s, the 284 MB of a 608x608 batch of 64 took 35 ms)
-// and the H2D of chunk k runs while chunk k+1 is being staged.
-static int stage_input_h2d(Network &n, const float *input)
+// Host float images [b0, b0 + nb) -> pinned staging -> device on in_stream, in 16 MB chunks: the staging copy of a chunk is
+// spread over the host pool (one core moves ~8 GB/s; the 284 MB of a 608x608 batch of 64 took 35 ms on one) and the H2D of
+// chunk k runs while chunk k+1 is being staged.  h_pinned holds the whole batch, so no chunk is reused inside a call.
+static int stage_input_h2d(Network &n, const float *input, int b0, int nb, hipEvent_t landed)
 {
-    const size_t total = n.pinned_bytes;
-    const size_t CHUNK = (size_t)32 << 20;
-    unsigned hw = std::thread::hardware_concurrency();
-    const unsigned nt = hw >= 8 ? 4u : (hw >= 4 ? 2u : 1u);
-    const char *src = reinterpret_cast<const char *>(input);
-    char *pin = reinterpret_cast<char *>(n.h_pinned);
-    char *dev = reinterpret_cast<char *>(n.d_input);
+    const size_t img = (size_t)n.c * n.h * n.w * sizeof(float);
+    const size_t base = (size_t)b0 * img, total = (size_t)nb * img;
+    const size_t CHUNK = (size_t)16 << 20;
+    const char *src = reinterpret_cast<const char *>(input) + base;
+    char *pin = reinterpret_cast<char *>(n.h_pinned) + base;
+    char *dev = reinterpret_cast<char *>(n.d_input) + base;
+    hipStream_t cs = (hipStream_t)n.in_stream;
     for (size_t off = 0; off < total; off += CHUNK) {
         const size_t len = (total - off < CHUNK) ? total - off : CHUNK;
-        if (nt > 1 && len >= ((size_t)4 << 20)) {
-            const size_t slice = ((len / nt) + 63) & ~(size_t)63;
-            std::vector<std::thread> th;
-            for (unsigned t = 1; t < nt; ++t) {
-                const size_t o = (size_t)t * slice;
-                if (o >= len) break;
-                const size_t l = (o + slice < len && t + 1 < nt) ? slice : len - o;
-                th.emplace_back([=] { memcpy(pin + off + o, src + off + o, l); });
-            }
-            memcpy(pin + off, src + off, slice < len ? slice : len);
-            for (auto &x : th) x.join();
-        } else {
-            memcpy(pin + off, src + off, len);
-        }
-        if (hipMemcpyAsync(dev + off, pin + off, len, hipMemcpyHostToDevice, (hipStream_t)n.stream) != hipSuccess) {
+        HostCopyJob job;
+        host_copy_async(job, pin + off, src + off, len);
+        host_copy_wait(job);
+        if (hipMemcpyAsync(dev + off, pin + off, len, hipMemcpyHostToDevice, cs) != hipSuccess) {
             set_error("H2D input copy failed");
             return YL_ERR_DEVICE;
         }
     }
+    YL_HIP(hipEventRecord(landed, cs));
     return YL_OK;
+}
+
+// network_predict_cpu's contract (src/yolov2_forward_network.c:632-646: host floats in, every head's l.output filled, the last
+// layer's returned) as a three-stage pipeline instead of the reference GPU path's stage-all -> forward -> pull-all
+// (src/yolov2_forward_network_gpu.cu:547-573, :438): the batch runs as `split` sub-batches; while sub-batch k computes, the
+// input of k+1 is staged and sent (in_stream) and the heads of k-1 come back (out_stream) and are copied out to the caller.
+// Same bits as one pass over the whole batch (BatchWindow).  split: 2 from 32 images (a 32-image pass runs at 0.96 of the
+// 64-image rate per image), 1 below; YL_PREDICT_SPLIT overrides (1 .. PREDICT_MAX_SPLIT).
+static int predict_split(const Network &n)
+{
+    int split = n.batch >= 32 ? 2 : 1;
+    if (const char *e = getenv("YL_PREDICT_SPLIT")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= PREDICT_MAX_SPLIT) split = v;
+    }
+    if (n.debug) split = 1;              // the debug tensors (d_debug) are whole-batch
+    if (split > n.batch) split = n.batch;
+    return split;
 }
 
 float *yl_network_predict(yl_network *net, const float *input)
@@ -1472,9 +1567,26 @@ float *yl_network_predict(yl_network *net, const float *input)
     Network &n = net->net;
     if (!n.on_device) { set_error("network not on device: call yl_network_to_device first"); return nullptr; }
     if (hipSetDevice(n.device) != hipSuccess) { set_error("hipSetDevice failed"); return nullptr; }
-    if (stage_input_h2d(n, input) != YL_OK) return nullptr;
-    if (forward(n, n.d_input, -1) != YL_OK) return nullptr;
-    if (pull_heads(n, true) != YL_OK) return nullptr;
+    const int B = n.batch, split = predict_split(n);
+    const size_t nl = n.layers.size();
+    std::vector<HeadPiece> pieces;
+    size_t n_ev = 0;
+    // (h_pinned / h_heads of the previous call are free: every predict ends with its streams drained)
+    for (int k = 0; k < split; ++k) {
+        const int b0 = (int)((long long)B * k / split), nb = (int)((long long)B * (k + 1) / split) - b0;
+        if (stage_input_h2d(n, input, b0, nb, (hipEvent_t)n.in_events[k]) != YL_OK) return nullptr;
+        if (hipStreamWaitEvent((hipStream_t)n.stream, (hipEvent_t)n.in_events[k], 0) != hipSuccess) { set_error("hipStreamWaitEvent failed"); return nullptr; }
+        int frc;
+        {
+            BatchWindow win(n, b0, nb);
+            n.head_event_base = (int)(k * nl);
+            frc = forward(n, n.d_input, -1);
+            n.head_event_base = -1;
+        }
+        if (frc != YL_OK) return nullptr;
+        if (enqueue_head_pull(n, true, b0, nb, (int)(k * nl), pieces, n_ev) != YL_OK) return nullptr;
+    }
+    if (finish_head_pull(n, pieces) != YL_OK) return nullptr;
     // last non-COST layer (src/yolov2_forward_network.c:644-645); COST never parses here
     return n.layers.back().host_output;
 }

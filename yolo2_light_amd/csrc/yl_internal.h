@@ -4,6 +4,7 @@
 #pragma once
 #include <cstdint>
 #include <cstddef>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -16,6 +17,7 @@ namespace yl {
 enum ConvMode { CONV_F32 = 0, CONV_INT8 = 1, CONV_XNOR = 2, CONV_BF16 = 3 };
 enum HostKind { HOST_NONE = 0, HOST_CALLER = 1, HOST_PINNED = 2 };
 
+constexpr int PREDICT_MAX_SPLIT = 4;  // sub-batches of one yl_network_predict call
 constexpr int ACT_FRONT_PAD = 64;      // floats (256 B) of readable, zeroed memory in front of every library-owned activation tensor
 constexpr int ACT_TAIL_PAD = 16;       // floats of readable memory behind it: the 16-byte row loads of the Winograd kernels end up to two
                                        // columns beyond the last row of the last image (selected away, but the bytes must be mapped)
@@ -160,11 +162,26 @@ struct Network {
     uint8_t *d_u8 = nullptr;             // the same on the device
     size_t u8_stride = 0;                // bytes per slot
     std::vector<void *> u8_events;       // per slot: H2D of the slot's staging region has completed
+    // yl_network_predict's pipeline (runtime.hip): the batch runs as up to PREDICT_MAX_SPLIT sub-batches; input of sub-batch k+1
+    // travels on in_stream and the heads of sub-batch k-1 on out_stream while sub-batch k computes on `stream`
+    void *in_stream = nullptr, *out_stream = nullptr;   // hipStream_t
+    std::vector<void *> in_events;       // per sub-batch: its input has landed (in_stream)
+    std::vector<void *> head_events;     // [sub-batch][layer]: the tensor is complete on `stream` (heads / last layer only, else nullptr)
+    std::vector<void *> chunk_events;    // D2H chunks of the current predict call, in issue order
+    int head_event_base = -1;            // >= 0: forward() records head_events[base + layer] (set by yl_network_predict)
     void *ev0 = nullptr, *ev1 = nullptr; // hipEvent_t pair for profiling
     std::vector<void *> layer_events;
 };
 
 void set_error(const std::string &msg);
+
+// host_pool.cpp: pageable <-> pinned copies spread over a pool of host threads, overlapped with the DMA by the callers
+struct HostCopyJob {
+    std::atomic<int> pending{0};
+};
+void host_copy_async(HostCopyJob &job, void *dst, const void *src, size_t bytes);
+void host_copy_wait(HostCopyJob &job);
+unsigned host_copy_threads();
 
 // staging.hip: caller memory <-> device through library-owned pinned chunks; both return when the bytes have landed
 int stage_h2d(int device, void *dst_dev, const void *src_host, size_t bytes);
