@@ -271,3 +271,41 @@ def test_three_piece_kernels_at_the_edges_of_the_format(olib, size, tile):
     got3, ref3 = run(x3)
     assert np.all(np.isfinite(got3)) and float(np.max(np.abs(got3.astype(np.float64) - ref3))) < 1e-37
     net.close()
+
+
+def test_two_source_plan_with_pool_fusion_around_it():
+    """The planner orders: the two-source plan ([upsample] -> [route] -> conv 1x1 read from the two tensors) is made
+    BEFORE the [maxpool]-fusion plan.  A network with a pool-fused convolution as the route's second source and a [maxpool] BEHIND the
+    1x1 convolution: the two-source form is taken, the pooled / full tensors its neighbours need exist, and every materialised tensor
+    equals the unfused run bit for bit."""
+    B, W, H = 2, 16, 16
+    rng = np.random.default_rng(41)
+
+    def cw(c, m, k):
+        return rng.normal(0, np.sqrt(2.0 / (c * k * k)), m * c * k * k).astype(np.float32), rng.normal(0, 0.3, m).astype(np.float32)
+    w0, b0 = cw(16, 32, 3); w2, b2 = cw(32, 32, 3); w5, b5 = cw(64, 96, 1)
+    descs = [
+        D.conv(B, W, H, 16, 32, 3, 1, 1, D.LEAKY, w0, b0),               # 0: also the route's second source -> its full tensor stays
+        D.maxpool(B, W, H, 32, 2, 2),                                    # 1: foldable into layer 0 (K1w pooled form)
+        D.conv(B, W // 2, H // 2, 32, 32, 3, 1, 1, D.LEAKY, w2, b2),     # 2
+        D.upsample(B, W // 2, H // 2, 32, 2),                            # 3
+        D.route(B, [3, 0], [32 * W * H, 32 * W * H], (W, H, 64)),        # 4
+        D.conv(B, W, H, 64, 96, 1, 1, 0, D.LEAKY, w5, b5),               # 5: two-source candidate
+        D.maxpool(B, W, H, 96, 2, 2),                                    # 6: behind a 1x1 convolution: never folded
+    ]
+    x = rng.standard_normal((B, 16, H, W)).astype(np.float32)
+    nets = []
+    for fuse in (True, False):
+        net = Network.from_desc(descs, B, W, H, 16, 0)
+        net.set_fusion(fuse)
+        net.to_device(0)
+        net.predict(x)
+        nets.append(net)
+    a, b = nets
+    assert "up+route" in a.layer_kernel(5), a.layer_kernel(5)
+    assert not a.layer_materialised(3) and not a.layer_materialised(4) and b.layer_materialised(3) and b.layer_materialised(4)
+    assert a.layer_materialised(0) and a.layer_materialised(1) and a.layer_materialised(6)
+    for i in range(a.n):
+        if a.layer_materialised(i):
+            assert np.array_equal(a.layer_output(i).view(np.uint32), b.layer_output(i).view(np.uint32)), "layer %d" % i
+    a.close(); b.close()

@@ -42,6 +42,7 @@
 // Loads get a whole iteration (>= BK/2 * TM*TN * 64 cycles) of latency budget, waits are
 // counted vmcnt(N) (loads return in order), and no instruction burst separates MFMA blocks.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdio>
 
 #include "kernels.h"
@@ -535,6 +536,21 @@ static int launch_conv_f32_direct(const ConvF32Args &a, int cfg, int variant, vo
 }
 
 // The two branches of launch_conv_f32 below whose kernels have a pooled output (kept next to it on purpose).
+int device_cu_count()
+{
+    constexpr int MAX_DEV = 64;
+    static std::atomic<int> cache[MAX_DEV];          // zero-initialised; a racing first call stores the same value twice
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev >= 0 && dev < MAX_DEV) {
+        v = cache[dev].load(std::memory_order_relaxed);
+        if (v > 0) return v;
+    }
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    if (dev >= 0 && dev < MAX_DEV) cache[dev].store(v, std::memory_order_relaxed);
+    return v;
+}
+
 bool conv_f32_pool_fusable(const ConvF32Args &a0, const ConvF32Opts &o_in)
 {
     ConvF32Opts o = o_in;
@@ -586,8 +602,8 @@ int launch_conv_f32(const ConvF32Args &a, const ConvF32Opts &o_in, void *stream,
     // K1r: the 3x3 / stride-1 layers as row-wise Winograd F(2,3) on the BF16 matrix pipe with three-piece operands (variant bit
     // 11; force_tile 61..70 = its tiles); the layers with a pooled output keep the 2-D Winograd kernel (an F(2x2) tile is a window)
     if (a.row3_w && a.in_front_pad && !a.pool_out && !a.q_out && !a.bits_out && a.yolo_entries == 0 && (a.out || a.add) && o.force_tile == 0 &&
-        ((wino_takes && (o.variant & 2048)) || row3_tile))
-        return launch_conv_f32_row3(a, row3_tile, stream, name, name_len, (o.variant & 8192) != 0);
+        (row3_tile || row3_fits(a.B, a.C, a.M, a.H, a.W)) && ((wino_takes && (o.variant & 2048)) || row3_tile))
+        return launch_conv_f32_row3(a, row3_tile, stream, name, name_len, (o.variant & 8192) != 0);      // (a forced tile on a layer beyond its offsets fails there)
     if (!wino_takes && a.x3_w && (a.out || a.add) && !a.q_out && !a.pool_out && !a.bits_out && (a.yolo_entries == 0 || (a.size == 1 && !a.add)) &&
         ((o.force_tile == 0 && (o.variant & 1024) && a.M > 32) || (o.force_tile >= 51 && o.force_tile <= 55)))
         return launch_conv_f32_x3(a, o.force_tile >= 51 ? o.force_tile - 50 : 0, stream, name, name_len, (o.variant & 4096) != 0);

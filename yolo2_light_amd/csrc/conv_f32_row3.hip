@@ -866,6 +866,14 @@ bool row3_applicable(int C, int M, int size, int stride, int pad)
     return C >= 16 && (C % 16) == 0 && M >= 1 && size == 3 && stride == 1 && pad == 1;
 }
 
+// lane offsets are 32-bit byte offsets from the first image of a workgroup's tiles: 128 tiles span 128 / HTW + 2 images
+bool row3_fits(int B, int C, int M, int H, int W)
+{
+    const long long htw = (long long)H * ((W + 1) / 2);
+    const long long span = 128 / (htw > 0 ? htw : 1) + 2;
+    return htw > 0 && (long long)B * htw <= 0x7fffffffLL && (long long)C * H * W * 4 * span < 0xFFFFFFF0LL && (long long)M * H * W * 4 * span < 0xFFFFFFF0LL;
+}
+
 size_t row3_packed_bytes(int C, int M)
 {
     const size_t mpad = (size_t)(M + ROW3_MPAD - 1) / ROW3_MPAD * ROW3_MPAD;
@@ -928,10 +936,7 @@ int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *nam
     d.G = (a.C / 16) * 3;
     d.act = a.act;
     const long long nt = (long long)a.B * d.HTW;
-    // lane offsets are 32-bit byte offsets from the first image of a workgroup's tiles: 128 tiles span 128 / HTW + 2 images
-    if (nt > 0x7fffffffLL || (long long)a.C * a.H * a.W * 4 * (128 / d.HTW + 2) >= 0xFFFFFFF0LL ||
-        (long long)a.M * a.H * a.W * 4 * (128 / d.HTW + 2) >= 0xFFFFFFF0LL)
-        return (int)hipErrorInvalidValue;
+    if (!row3_fits(a.B, a.C, a.M, a.H, a.W)) return (int)hipErrorInvalidValue;
     d.Ntiles = (int)nt;
     d.tiles_m = 0;
     hipStream_t s = (hipStream_t)stream;
@@ -941,12 +946,7 @@ int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *nam
         // 128x64 0.850 | 0.831 | 0.859, 64x64 0.954 | 0.928 | 1.009; with 64 filters ([64,32,304^2]) 64x64 1.178, 64x128 1.287.
         // On grids that do not fill the chip the work of the busiest CU decides: workgroups per CU x tile area x the tile's
         // relative cost above.
-        static int n_cu = 0;
-        if (n_cu == 0) {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-            n_cu = v;
-        }
+        const int n_cu = device_cu_count();
         // cost of a tile in units of one 128 x 128 workgroup's life: W = a workgroup of that tile alone on a CU, f[k-1] = its slowdown
         // with k of them resident (128 x 64: two fit a CU, 64 x 64: three); beyond that, rounds.  Fitted on both regimes -- yolov3-608 at
         // batch 64 (3 ... 91 workgroups per CU: 128x128 wins everywhere) and grids below the chip (yolov3-tiny 416 at batch 32,

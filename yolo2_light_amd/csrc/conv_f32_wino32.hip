@@ -702,12 +702,7 @@ int launch_conv_f32_wino32(const ConvF32Args &a, const float *u_packed, int vari
     const bool ls = a.in_front_pad && (variant & 128) == 0;          // variant bit 7: A/B switch, keep the register-shift form
     if (persist) {
         // two workgroups per CU (what the kernel's registers and LDS allow), or one per tile on small layers
-        static int n_cu = 0;
-        if (n_cu == 0) {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-            n_cu = v;
-        }
+        const int n_cu = device_cu_count();
         const long long slots = 2LL * n_cu;
         const dim3 grid((unsigned)(blocks < slots ? blocks : slots)), block(256);
         if (ls && (a.W & 1)) {

@@ -555,12 +555,7 @@ int launch_conv_f32_x3(const ConvF32Args &a, int tile, void *stream, char *name,
     if (tile == 0) {
         tile = a.M <= 32 ? 3 : (a.M <= 64 ? 2 : 1);
         // grids far below the chip (8 images per GPU at 19 x 19: 92 workgroups of 128 x 128 for 256 CUs): 64 x 64 tiles
-        static int n_cu = 0;
-        if (n_cu == 0) {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-            n_cu = v;
-        }
+        const int n_cu = device_cu_count();
         if (tile == 1 && (long long)((a.M + 127) / 128) * ((nt + 127) / 128) < (long long)n_cu) tile = 4;
     }
     const char *t = "?";

@@ -79,6 +79,9 @@ struct ConvF32Opts {
     // profiles/r2_ab_fp32_variants.txt.)
     int variant = YL_VARIANT_DEFAULT;
 };
+// compute units of the CURRENT device, cached per device id with atomics (the tile heuristics of K1x / K1r / K1w ask per launch:
+// two networks on two GPUs or host threads share no mutable launch state, and a mixed node gets each device's own count)
+int device_cu_count();
 // would launch_conv_f32 send this layer (a.pool_out ignored) to a kernel that can fold a 2x2 / stride-2 [maxpool]?
 bool conv_f32_pool_fusable(const ConvF32Args &a, const ConvF32Opts &o);
 // writes the name of the kernel instance it launched into name[name_len]
@@ -97,6 +100,7 @@ bool conv_f32_two_source_now(const ConvF32Args &a, const ConvF32Opts &o);
 int launch_conv_f32_x3(const ConvF32Args &a, int tile, void *stream, char *name, size_t name_len, bool plain = false);
 // K1r (conv_f32_row3.hip): 3x3 / stride 1 / pad 1 as row-wise Winograd F(2,3) on the BF16 matrix pipe, three-piece operands
 bool row3_applicable(int C, int M, int size, int stride, int pad);
+bool row3_fits(int B, int C, int M, int H, int W);   // the 32-bit lane offsets of launch_conv_f32_row3 cover this layer (else: K1w / K1x / the direct kernel)
 size_t row3_packed_bytes(int C, int M);
 void row3_pack_weights(const float *w, int C, int M, void *dst);
 // tile: 0 = heuristic, 1..5 see conv_f32_row3.hip

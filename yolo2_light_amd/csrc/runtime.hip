@@ -9,6 +9,7 @@
 // there is no host synchronisation inside a forward, and no CPU fallback: every
 // device entry point fails with YL_ERR_DEVICE when HIP reports an error.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <cstdio>
 #include <cstdlib>
@@ -265,6 +266,8 @@ static int upload_conv(Network &net, Layer &l)
             }
         }
         // 3x3 / stride 1 / pad 1: the row-transformed weights U = G g as three bf16 pieces for K1r (conv_f32_row3.hip)
+        // (kept whenever Winograd packing is on, whatever variant bit 11 says now: yl_network_set_variant / _set_conv_tile may move a
+        //  layer to K1r after yl_network_to_device and must never fail a forward pass; the memory this costs is in INTEGRATION.md)
         if (wino && row3_applicable(l.c, M, l.size, l.stride, l.pad)) {
             const size_t rb = row3_packed_bytes(l.c, M);
             YL_HIP(hipMalloc(&l.d_weights_r3, rb));
@@ -711,15 +714,19 @@ static int to_device(Network &net, int device)
         //      nearest-neighbour index map, source 2 as it is -- so neither the upsampled tensor nor the concatenation is written
         //      (yolov3 layers 85-87 and 97-99: 0.51 ms of copies per step at 608 x 608, batch 64).  The same values in the same channel
         //      order: the same bits.  Whether the kernel of the moment can do it is asked per forward pass (conv_f32_two_source_now).
+        // (This plan runs BEFORE the [maxpool]-fusion plan below; nothing here depends on it: a 1x1 convolution is never
+        //  pool-fusable (K1f / K1w are 3x3 kernels), a [maxpool] written by the convolution in front of it still HAS its tensor, and
+        //  the pool plan drops a convolution's full-resolution tensor only where no other layer reads it -- a tensor this [route]
+        //  reads is referenced.  tests/test_gpu_row3.py::test_two_source_plan_with_pool_fusion_around_it pins that.)
         auto tensor_written = [&](const Layer &x) {
-            if (x.type == YL_MAXPOOL || x.type == YL_ROUTE || x.type == YL_UPSAMPLE) return !x.skip_f32_out && !x.fused_into_conv;
+            if (x.type == YL_MAXPOOL || x.type == YL_ROUTE || x.type == YL_UPSAMPLE) return !x.skip_f32_out;
             return !(x.type == YL_CONVOLUTIONAL && (x.fused_shortcut >= 0 || x.fused_yolo >= 0 || x.skip_f32_out));
         };
         for (int j = 2; j < nl; ++j) {
             Layer &cv = net.layers[j];
             Layer &rt = net.layers[j - 1];
             if (cv.type != YL_CONVOLUTIONAL || cv.conv_mode != CONV_F32 || cv.xnor || cv.binarize_input || !cv.d_weights_x3) continue;
-            if (cv.size != 1 || cv.stride != 1 || cv.pad != 0 || cv.fused_yolo >= 0 || cv.q_out_layer >= 0 || cv.bits_out_slot >= 0 || cv.fused_pool >= 0) continue;
+            if (cv.size != 1 || cv.stride != 1 || cv.pad != 0 || cv.fused_yolo >= 0 || cv.q_out_layer >= 0 || cv.bits_out_slot >= 0) continue;
             if (rt.type != YL_ROUTE || rt.n != 2 || rt.d_output_alias || rt.skip_f32_out || referenced_elsewhere(j - 1, j)) continue;
             const int u = rt.input_layers[0], o = rt.input_layers[1];
             Layer &up = net.layers[u];
@@ -1571,10 +1578,16 @@ float *yl_network_predict(yl_network *net, const float *input)
     const size_t nl = n.layers.size();
     std::vector<HeadPiece> pieces;
     size_t n_ev = 0;
+    const bool timing = getenv("YL_PREDICT_TIMING") != nullptr;       // host-side stage times on stderr (lab)
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
+    double t_stage = 0.0, t_enqueue = 0.0;
     // (h_pinned / h_heads of the previous call are free: every predict ends with its streams drained)
     for (int k = 0; k < split; ++k) {
         const int b0 = (int)((long long)B * k / split), nb = (int)((long long)B * (k + 1) / split) - b0;
+        const double t0 = now();
         if (stage_input_h2d(n, input, b0, nb, (hipEvent_t)n.in_events[k]) != YL_OK) return nullptr;
+        t_stage += now() - t0;
         if (hipStreamWaitEvent((hipStream_t)n.stream, (hipEvent_t)n.in_events[k], 0) != hipSuccess) { set_error("hipStreamWaitEvent failed"); return nullptr; }
         int frc;
         {
@@ -1585,8 +1598,13 @@ float *yl_network_predict(yl_network *net, const float *input)
         }
         if (frc != YL_OK) return nullptr;
         if (enqueue_head_pull(n, true, b0, nb, (int)(k * nl), pieces, n_ev) != YL_OK) return nullptr;
+        t_enqueue += now() - t0;
     }
+    const double t_pull = now();
     if (finish_head_pull(n, pieces) != YL_OK) return nullptr;
+    if (timing)
+        fprintf(stderr, "yl_network_predict: batch %d split %d: input staging %.2f ms (host), staging + enqueue %.2f ms, wait + copy-out %.2f ms, total %.2f ms; "
+                        "%u pool threads, %zu bounce pieces\n", B, split, t_stage, t_enqueue, now() - t_pull, now() - t_start, host_copy_threads(), pieces.size());
     // last non-COST layer (src/yolov2_forward_network.c:644-645); COST never parses here
     return n.layers.back().host_output;
 }

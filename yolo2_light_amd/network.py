@@ -249,6 +249,12 @@ class Network:
         last = self.layer_info(self.n - 1)
         return np.ctypeslib.as_array(p, shape=(self.batch * last["outputs"],)).copy()
 
+    def predict_raw(self, images: np.ndarray) -> None:
+        """yl_network_predict on a host batch without copying the returned tensor out (timing the boundary itself)"""
+        x = np.ascontiguousarray(images, dtype=np.float32)
+        if not lib.yl_network_predict(self._h, _fp(x)):
+            raise YoloHipError("yl_network_predict failed: " + _lib.last_error())
+
     def forward_device(self, input_dev_ptr: int) -> None:
         check(lib.yl_network_forward(self._h, C.c_void_p(input_dev_ptr)), "yl_network_forward")
 
