@@ -61,7 +61,18 @@ def _big_batch_equals_batch1(name, size, B, quantized, images, min_checked, dets
     cfg, wts = common.model_files(name, size, size)
     x = common.seeded_input(B, 3, size, size)
     big = Network.load(cfg, wts, B, quantized, device=0, fuse=True)
-    big.predict(x)
+    # ONE pass over the whole batch, as bench.py's timed step runs it (yl_network_predict would pipeline two sub-batches, whose
+    # grids -- and with them the tile heuristics the kernel names below are asserted on -- are those of B / 2 images;
+    # tests/test_gpu_dropin.py::test_pipelined_predict_equals_one_pass pins the pipelined form to the one-pass bits)
+    old_split = os.environ.get("YL_PREDICT_SPLIT")
+    os.environ["YL_PREDICT_SPLIT"] = "1"
+    try:
+        big.predict(x)
+    finally:
+        if old_split is None:
+            os.environ.pop("YL_PREDICT_SPLIT", None)
+        else:
+            os.environ["YL_PREDICT_SPLIT"] = old_split
     # the kernel instance bench.py's roofline block will call dominant at this configuration must have its committed
     # PMC traffic entry (profiles/pmc_traffic.json): a renamed or re-tiled kernel fails HERE, not as `traffic: null`
     import json

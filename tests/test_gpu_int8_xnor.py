@@ -211,33 +211,47 @@ def test_network_teacher_forced(olib, name, width, height, batch, quantized):
 
 
 def test_int8_network_vs_reference_library_batch1():
-    """-quantized yolov3-tiny 416 against network_predict_quantized of the reference itself
-    (which handles batch item 0 only): final detections agree."""
-    common.require_ref()
+    """-quantized yolov3-tiny 416 END TO END against network_predict_quantized of the reference itself (which handles batch
+    item 0 only) -- pinned where it is measured (profiles/r6_int8_end_to_end_diag.txt).
+
+    Quantisation is a step function of the FP32 first layer's output.  That layer here is gemm_nn's k-order chain of FUSED
+    multiply-adds; the reference's `make AVX=1` build runs the same chain (_mm256_fmadd_ps, src/additionally.c gemm_nn), its
+    scalar build rounds every product and every sum separately: against the scalar build 58 % of layer 0's outputs differ by
+    <= 1 ulp (7e-7), 66 of the 1.38 M int8 codes of the next layer flip, and the synthetic i.i.d. weights amplify that ~1.4 x
+    per layer to 5.5e-3 at the heads (1.3e-2 at yolov3-608).  So:
+      * against the reference's AVX build (bit-equal first layer, no flips): the heads agree to FP32 rounding of the linear
+        head convolutions -- asserted at 1e-4 relative RMS; a wrong dequantisation scale, clamp or /32 on any layer is orders
+        of magnitude above that;
+      * against the scalar build: the flip fraction at the first INT8 layer is asserted (< 2e-4 of its outputs differ at all),
+        the heads at 5e-2 -- the looser bound is the amplification of those few flips, not slack in a kernel."""
+    common.require_ref(fast=True)
     name, width, height = "yolov3-tiny", 416, 416
     cfg, wts = common.model_files(name, width, height)
-    ref = common.refbind.RefNetwork(cfg, wts, 1, 1)
-    net = Network.load(cfg, wts, 1, 1, device=0)
     x = common.seeded_input(1, 3, height, width)
-    ref.predict(x)
+    net = Network.load(cfg, wts, 1, 1, device=0)
     net.predict(x)
-    # Layer exactness is established by the teacher-forced tests above; END TO END the integer layers are bit-exact and the
-    # FP32 layers (first conv, linear heads) differ from the reference by FP32 rounding only, so the heads agree to ~1e-6
-    # relative RMS (measured at yolov3-608: 3e-7 ... 1e-6).  A wrong dequantisation scale, a flipped clamp or a skipped
-    # /32 on any one layer is orders of magnitude above the 1e-4 bound.
-    for i in range(net.n):
-        li = net.layer_info(i)
-        if li["type"] not in (common.YOLO,):
-            continue
-        g = net.layer_output(i).astype(np.float64); r = ref.layer_output(i).astype(np.float64)
-        rms = np.sqrt(np.mean(r * r))
-        rel_rms_err = np.sqrt(np.mean((g - r) ** 2)) / rms
-        print("yolo layer %d: INT8 end-to-end relative RMS error vs the reference %.3g" % (i, rel_rms_err))
-        assert rel_rms_err < 1e-4, "yolo layer %d: relative RMS error %.3g" % (i, rel_rms_err)
-        assert np.corrcoef(g, r)[0, 1] > 0.99999
-    r = ref.get_detections(0, width, height, 0.24, nms=0.4)
-    g = net.get_boxes(0, width, height, 0.24, nms=0.4)
-    assert abs(len(r) - len(g)) <= max(2, len(r) // 50)
+    first_i8 = next(i for i in range(net.n) if net.layer_kernel(i).startswith("conv_i8"))
+    for fast, bound in ((True, 1e-4), (False, 5e-2)):
+        ref = common.refbind.RefNetwork(cfg, wts, 1, 1, fast=fast)
+        ref.predict(x)
+        for i in range(net.n):
+            li = net.layer_info(i)
+            if li["type"] not in (common.YOLO,):
+                continue
+            g = net.layer_output(i).astype(np.float64); r = ref.layer_output(i).astype(np.float64)
+            rms = np.sqrt(np.mean(r * r))
+            rel_rms_err = np.sqrt(np.mean((g - r) ** 2)) / rms
+            print("yolo layer %d: INT8 end-to-end relative RMS error vs the reference's %s build %.3g" % (
+                i, "AVX" if fast else "scalar", rel_rms_err))
+            assert rel_rms_err < bound, "yolo layer %d vs the %s build: relative RMS error %.3g" % (i, "AVX" if fast else "scalar", rel_rms_err)
+        g2, r2 = net.layer_output(first_i8), ref.layer_output(first_i8)
+        flips = float(np.mean(g2 != r2))
+        print("first INT8 layer (%d): %.3g of its outputs differ from the %s build" % (first_i8, flips, "AVX" if fast else "scalar"))
+        assert flips < (1e-6 if fast else 2e-4)
+        if not fast:
+            r = ref.get_detections(0, width, height, 0.24, nms=0.4)
+            g = net.get_boxes(0, width, height, 0.24, nms=0.4)
+            assert abs(len(r) - len(g)) <= max(2, len(r) // 50)
     net.close()
 
 
