@@ -244,9 +244,12 @@ def test_int8_network_vs_reference_library_batch1():
             print("yolo layer %d: INT8 end-to-end relative RMS error vs the reference's %s build %.3g" % (
                 i, "AVX" if fast else "scalar", rel_rms_err))
             assert rel_rms_err < bound, "yolo layer %d vs the %s build: relative RMS error %.3g" % (i, "AVX" if fast else "scalar", rel_rms_err)
-        g2, r2 = net.layer_output(first_i8), ref.layer_output(first_i8)
-        flips = float(np.mean(g2 != r2))
-        print("first INT8 layer (%d): %.3g of its outputs differ from the %s build" % (first_i8, flips, "AVX" if fast else "scalar"))
+        # an int8 code that flipped moves an output by one quantisation step of one input (>= 1e-3 of the layer's RMS); FP32 rounding
+        # of the dequantise / bias / leaky tail (the AVX build runs it under -Ofast) stays far below that
+        g2, r2 = net.layer_output(first_i8).astype(np.float64), ref.layer_output(first_i8).astype(np.float64)
+        flips = float(np.mean(np.abs(g2 - r2) > 1e-3 * np.sqrt(np.mean(r2 * r2))))
+        print("first INT8 layer (%d): %.3g of its outputs differ from the %s build by more than 1e-3 of the layer RMS" % (
+            first_i8, flips, "AVX" if fast else "scalar"))
         assert flips < (1e-6 if fast else 2e-4)
         if not fast:
             r = ref.get_detections(0, width, height, 0.24, nms=0.4)
