@@ -68,6 +68,8 @@ HBM_PEAK_GBS = 8000.0               # HBM3E spec; 6.29 TB/s measured for a float
 # MISMATCHES with the full-rate v_xor_b32 instead: 2 + 4 = 6 clk nominal per 32 bit-MACs and lane = 839 T bit-MAC/s.
 # The two kinds do not overlap as the sum of their rates suggests: a kernel of nothing but 8 x v_xor then 8 x v_bcnt
 # reaches 3.89 clk per instruction (32-long runs: 3.76) = 647 T bit-MAC/s -- the measured ceiling of this mix.
+SPLIT_K_MAX_BATCH = 8               # images per GPU up to which the FP32 leg turns split K on (yl_network_set_split_k): the shards of a strong-scaled
+                                    # 8-GPU run, whose 19 x 19 layers are one workgroup's K loop long (measured: +5.6 % at 8 images, +-0 at 16)
 VALU_POPC_PEAK_TBITMAC = 839.0
 VALU_POPC_MEASURED_TBITMAC = 647.0
 
@@ -296,7 +298,7 @@ class Leg:
         # quantized: 0 FP32, 1 -quantized INT8, 2 the opt-in BF16 variant of the FP32 path
         self.net = Network.load(cfg, wts, b_local, 1 if quantized == 1 else 0, device=dev.index, fuse=not args.no_fuse,
                                 bf16=(quantized == 2), variant=(args.variant if args.variant >= 0 else None),
-                                winograd=not args.no_winograd)
+                                winograd=not args.no_winograd, split_k=(quantized == 0 and b_local <= SPLIT_K_MAX_BATCH))
         self.net.set_stream(stream.cuda_stream)
         if args.tile:
             self.net.set_conv_tile(args.tile)
@@ -860,7 +862,8 @@ def batch_sweep(args, torch, dev, stream, Network, cfg, wts, x, batches=(8, 16, 
     for b in batches:
         if b >= x.shape[0]:
             continue
-        net = Network.load(cfg, wts, b, 0, device=dev.index, fuse=not args.no_fuse)
+        # split K (yl_network_set_split_k) where a rank's shard leaves CUs idle: what a strong-scaled rank runs (Leg: b_local <= 16)
+        net = Network.load(cfg, wts, b, 0, device=dev.index, fuse=not args.no_fuse, split_k=b <= SPLIT_K_MAX_BATCH)
         net.set_stream(stream.cuda_stream)
         classes = net.layer_info(net.n - 1)["classes"]
         rec = torch.zeros((b, args.cap, 6 + classes), device=dev, dtype=torch.float32)
@@ -878,7 +881,8 @@ def batch_sweep(args, torch, dev, stream, Network, cfg, wts, x, batches=(8, 16, 
             one()
         torch.cuda.synchronize()
         t = (time.perf_counter() - t0) / steps
-        out[str(b)] = {"images_per_sec": b / t, "ms_per_step": t * 1e3,
+        out[str(b)] = {"images_per_sec": b / t, "ms_per_step": t * 1e3, "split_k": b <= SPLIT_K_MAX_BATCH,
+                       "split_layers": sum(",split" in net.layer_kernel(i) for i in range(net.n)),
                        "predicted_node_images_per_sec_at_%d_gpus" % (x.shape[0] // b): (x.shape[0] // b) * b / t}
         net.close()
     return out

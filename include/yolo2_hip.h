@@ -352,6 +352,15 @@ int yl_network_set_precision(yl_network *net, int precision);
 int yl_network_set_int8_tile(yl_network *net, int cfg);
 int yl_network_set_winograd(yl_network *net, int on);
 int yl_network_set_nms_mode(yl_network *net, int mode);
+/* Split K for grids below the chip (BEFORE yl_network_to_device; default 0 = off).  The reference runs one image on one device
+ * (src/main.c:653-661) and has no analogue; config 3 at 8 GPUs is 8 images per GPU, where yolov3's 19 x 19 and 38 x 38 layers launch
+ * fewer workgroups than the part has CUs and a layer's time is ONE workgroup's K loop.  With 1, an FP32 convolution on
+ * conv_f32_x3.hip / conv_f32_row3.hip whose grid would leave CUs idle cuts its input channels into 2-4 contiguous ranges, one
+ * workgroup set per range writes raw partial sums to a workspace, and a second kernel adds them IN RANGE ORDER, then bias,
+ * activation and the fused [shortcut]: deterministic (run-to-run bit-identical), a different summation order than the unsplit
+ * layer -- inside the FP32 contract (tests/test_gpu_splitk.py, against the oracle), but batch-B results are then no longer bit-equal
+ * to batch-1 results of the same image (the number of ranges follows the grid).  Layers whose grid fills the chip are untouched. */
+int yl_network_set_split_k(yl_network *net, int on);
 /* Kernel-layout weight packing at yl_network_to_device (the reference packs on one host core:
  * binary_align_weights src/additionally.c:196-302, init_gpu_int8x4 src/yolov2_forward_network_quantized.c:1489):
  * 1 (default) = the prepared weights are uploaded as they are and packed by kernels on the device (csrc/pack.hip),

@@ -111,6 +111,7 @@ _SIGS = {
     "yl_network_load_weights_upto": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "yl_network_prepare_on_device": (C.c_int, [_vp, C.c_int]),
     "yl_network_set_nms_mode": (C.c_int, [_vp, C.c_int]),
+    "yl_network_set_split_k": (C.c_int, [_vp, C.c_int]),
     "yl_network_set_device_pack": (C.c_int, [_vp, C.c_int]),
     "yl_debug_layer_packed": (C.c_longlong, [_vp, C.c_int, C.c_int, _vp, C.c_longlong]),
     "yl_network_set_quant_rule": (C.c_int, [_vp, C.c_int]),

@@ -98,9 +98,12 @@ struct ConvRow3Dev {
     int TW;                 // tiles per image row
     int HTW;                // tiles per image
     int Ntiles;             // B * HTW
-    int G;                  // groups = 3 * C / 16
+    int G;                  // groups = 3 * C / 16 (split K: of ONE channel range)
     int act;
     int tiles_m;
+    // split K (gridDim.y = ranges), as in conv_f32_x3.hip; Cpart = the channels of one range (C stays the tensor's: image stride)
+    int ksplit, Cpart;
+    size_t ks_in_off, ks_w_off, ks_out_off;
 };
 
 // two FP32 values -> their three bf16 pieces, packed (low half = x); conv_f32_x3.hip's split
@@ -252,6 +255,12 @@ __device__ __forceinline__ void row3_epilogue(const ConvRow3Dev &p, const f32x16
 template <int BM, int BT, int WM, int WN, int PP, bool MFULL, bool WEVEN, int SCHED, bool LOADX2>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) ? 3 : 2) void conv_f32_row3_kernel(ConvRow3Dev p)
 {
+    if (p.ksplit > 1) {                     // this workgroup's channel range
+        const size_t r = blockIdx.y;
+        p.in += r * p.ks_in_off;
+        p.wr = reinterpret_cast<const char *>(p.wr) + r * p.ks_w_off;
+        p.out += r * p.ks_out_off;
+    }
     static_assert(SCHED == 0 || PP == 2, "the mid-panel barrier needs two planes per panel");
     // (A ping-pong form -- the two waves of a SIMD alternating between a pure-MFMA slot and a staging slot -- was built and measured in
     //  round 5: bit-identical, 30 % slower, because without LDS-DMA the staging half's requests sit on every slot's critical path;
@@ -363,7 +372,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BT == 64 * 64) 
             return;
         }
         const int soff = (ld_c0 * HW + ld_ky * p.W) * 4;
-        const int tinv = __builtin_amdgcn_sbfe((int)nrowmask, ld_ky, 1) | (ld_c0 < p.C ? 0 : -1);
+        const int tinv = __builtin_amdgcn_sbfe((int)nrowmask, ld_ky, 1) | (ld_c0 < p.Cpart ? 0 : -1);
         if constexpr (LOADX2) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -848,7 +857,7 @@ int launch_row3_tile(ConvRow3Dev p, hipStream_t s)
     p.tiles_m = (p.M + BM - 1) / BM;
     const long long blocks = (long long)p.tiles_m * ((p.Ntiles + BT - 1) / BT);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    const dim3 grid((unsigned)blocks), block(WM * WN * 64);
+    const dim3 grid((unsigned)blocks, (unsigned)(p.ksplit > 1 ? p.ksplit : 1)), block(WM * WN * 64);
     const bool mfull = (p.M % BM) == 0, weven = (p.W & 1) == 0;
     if (mfull && weven) hipLaunchKernelGGL((conv_f32_row3_kernel<BM, BT, WM, WN, PP, true, true, SCHED, LOADX2>), grid, block, 0, s, p);
     else if (mfull) hipLaunchKernelGGL((conv_f32_row3_kernel<BM, BT, WM, WN, PP, true, false, SCHED, LOADX2>), grid, block, 0, s, p);
@@ -940,6 +949,21 @@ int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *nam
     d.Ntiles = (int)nt;
     d.tiles_m = 0;
     hipStream_t s = (hipStream_t)stream;
+    // split K (conv_f32_x3.hip has the same): whole channel blocks per range, partial passes bias-free and linear into the workspace
+    const int cblocks = a.C / 16;
+    int ksplit = (a.ksplit > 1 && a.ks_ws && a.ks_zeros) ? a.ksplit : 1;
+    while (ksplit > 1 && (cblocks % ksplit != 0 || cblocks / ksplit < 2)) --ksplit;
+    d.ksplit = ksplit; d.Cpart = a.C; d.ks_in_off = 0; d.ks_w_off = 0; d.ks_out_off = 0;
+    if (ksplit > 1) {
+        const int cb_part = cblocks / ksplit;
+        d.Cpart = cb_part * 16;
+        d.G = cb_part * 3;
+        d.ks_in_off = (size_t)d.Cpart * a.H * a.W;
+        d.ks_w_off = (size_t)d.G * 24 * d.Mpad * 16;
+        d.ks_out_off = (size_t)a.B * a.M * a.H * a.W;
+        d.out = a.ks_ws; d.add = nullptr; d.out_add = nullptr; d.bias = a.ks_zeros; d.act = YL_LINEAR;
+        if (tile == 10) tile = 1;                      // the view form has no range loop
+    }
     if (tile == 0) {
         // measured on MI355X at batch 64 (profiles/r5_sweep_row3_tiles_b64.txt, ms for [256,128,76^2] | [512,256,38^2] | [1024,512,19^2]):
         // 128x128 end-barrier 0.797 | 0.752 | 0.771, mid-barrier 0.837 | 0.773 | 0.809, one plane per panel 0.883 | 0.811 | 0.835,
@@ -953,7 +977,7 @@ int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *nam
         // yolov3 at 8 images: profiles/r5_sweep_row3_tiles_b64.txt, r5_small_grid_tiles_b8.txt, r5_sweep_tiny_416_b32_tiles.txt), where a
         // layer's time is ONE workgroup's K loop and the question is only how many of them share a CU.
         auto cost = [&](int bm, int bt, double W, int resident, const double *f) {
-            const long long nwg = (long long)((a.M + bm - 1) / bm) * ((nt + bt - 1) / bt);
+            const long long nwg = (long long)((a.M + bm - 1) / bm) * ((nt + bt - 1) / bt) * ksplit;     // (every range a workgroup set of 1 / ksplit the K loop: the same total)
             const long long per = (nwg + n_cu - 1) / n_cu;                  // workgroups on the busiest CU
             if (per <= resident) return W * f[per - 1];
             // more than fit at once: rounds -- whole ones for the busiest CU, fractional ones on average (the dispatcher refills a CU as
@@ -966,7 +990,7 @@ int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *nam
         else {
             const double c128 = cost(128, 128, 1.0, 1, f128), c64t = cost(128, 64, 0.79, 2, f128x64), c64 = cost(64, 64, 0.53, 3, f64);
             tile = (c128 <= c64t && c128 <= c64) ? 1 : (c64t <= c64 ? 4 : 7);
-            if (tile == 1 && view && d.TW <= 63) tile = 10;
+            if (tile == 1 && view && d.TW <= 63 && ksplit == 1) tile = 10;
             // (a finer 64x32 tile was measured at 8 images per GPU and gains nothing: below one workgroup per CU a layer's time
             //  is one workgroup's K loop -- 96 groups at 19 x 19 -- whatever the tile)
         }
@@ -989,7 +1013,11 @@ int launch_conv_f32_row3(const ConvF32Args &a, int tile, void *stream, char *nam
         break;
     default: return (int)hipErrorInvalidValue;
     }
-    if (name) snprintf(name, name_len, "conv_f32_row3<%s>", t);
+    char sp[16] = "";
+    if (ksplit > 1) snprintf(sp, sizeof(sp), ",split%d", ksplit);
+    if (name) snprintf(name, name_len, "conv_f32_row3<%s%s>", t, sp);
+    if (rc == 0 && ksplit > 1)
+        rc = launch_splitk_finish(a.ks_ws, ksplit, d.ks_out_off, a.bias, a.B, a.M, a.H * a.W, a.act, a.add, a.out, a.out_add, stream);
     return rc;
 }
 

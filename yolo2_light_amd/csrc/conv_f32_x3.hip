@@ -97,6 +97,10 @@ struct ConvX3Dev {
     // channels C1 .. C - 1 = `in2` at H x W: [upsample] -> [route] -> conv of yolov3 (forward_upsample_layer_cpu / forward_route_layer_cpu)
     const float *in2;
     int C1, up;
+    // split K (gridDim.y = ranges): range r reads channels from r * ks_in_off floats on, weights from r * ks_w_off bytes on, and writes
+    // its partial sums r * ks_out_off floats into the workspace `out` points at; nkb = the panels of ONE range, C stays the tensor's
+    int ksplit;
+    size_t ks_in_off, ks_w_off, ks_out_off;
 };
 
 // two FP32 values -> their three bf16 pieces, packed (low half = x)
@@ -122,6 +126,12 @@ template <int BM, int BN, int WM, int WN, int KS, bool MFULL, bool YOLO = false,
 // computes all 64 outputs of a block at once and takes 192-244 registers)
 __global__ __launch_bounds__(WM * WN * 64, (BM == 128 && BN == 128) ? 3 : (BM == 64 ? (BN == 64 ? 3 : 4) : 2)) void conv_f32_x3_kernel(ConvX3Dev p)
 {
+    if (p.ksplit > 1) {                     // this workgroup's channel range (uniform: scalar arithmetic on the kernel arguments)
+        const size_t r = blockIdx.y;
+        p.in += r * p.ks_in_off;
+        p.w3 = reinterpret_cast<const char *>(p.w3) + r * p.ks_w_off;
+        p.out += r * p.ks_out_off;
+    }
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / (WM * 32);
     constexpr int TN = BN / (WN * 32);
@@ -455,7 +465,7 @@ int launch_x3_tile(ConvX3Dev p, hipStream_t s)
     p.tiles_m = (p.M + BM - 1) / BM;
     const long long blocks = (long long)p.tiles_m * ((p.Ntotal + BN - 1) / BN);
     if (blocks <= 0 || blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
-    const dim3 grid((unsigned)blocks), block(WM * WN * 64);
+    const dim3 grid((unsigned)blocks, (unsigned)(p.ksplit > 1 ? p.ksplit : 1)), block(WM * WN * 64);
     const bool mfull = (p.M % BM) == 0;
 #define X3_GO(KS)                                                                                  \
     {                                                                                              \
@@ -552,11 +562,25 @@ int launch_conv_f32_x3(const ConvF32Args &a, int tile, void *stream, char *name,
     d.Ntotal = (int)nt;
     d.tiles_m = 0;
     hipStream_t s = (hipStream_t)stream;
+    // split K: whole channel blocks per range; the partial passes run bias-free and linear into the workspace, the second stage
+    // (launch_splitk_finish) applies bias, activation and the fused [shortcut]
+    const int cblocks = a.C / 16;
+    int ksplit = (a.ksplit > 1 && a.ks_ws && a.ks_zeros && !a.in2 && a.yolo_entries == 0) ? a.ksplit : 1;
+    while (ksplit > 1 && cblocks % ksplit != 0) --ksplit;
+    d.ksplit = ksplit; d.ks_in_off = 0; d.ks_w_off = 0; d.ks_out_off = 0;
+    if (ksplit > 1) {
+        const int cb_part = cblocks / ksplit;
+        d.nkb = cb_part * d.taps;
+        d.ks_in_off = (size_t)cb_part * 16 * a.H * a.W;
+        d.ks_w_off = (size_t)d.nkb * 6 * d.Mpad * 16;
+        d.ks_out_off = (size_t)a.B * a.M * d.OHW;
+        d.out = a.ks_ws; d.add = nullptr; d.out_add = nullptr; d.bias = a.ks_zeros; d.act = YL_LINEAR;
+    }
     if (tile == 0) {
         tile = a.M <= 32 ? 3 : (a.M <= 64 ? 2 : 1);
         // grids far below the chip (8 images per GPU at 19 x 19: 92 workgroups of 128 x 128 for 256 CUs): 64 x 64 tiles
         const int n_cu = device_cu_count();
-        if (tile == 1 && (long long)((a.M + 127) / 128) * ((nt + 127) / 128) < (long long)n_cu) tile = 4;
+        if (tile == 1 && (long long)((a.M + 127) / 128) * ((nt + 127) / 128) * ksplit < (long long)n_cu) tile = 4;
     }
     const char *t = "?";
     int rc;
@@ -571,7 +595,11 @@ int launch_conv_f32_x3(const ConvF32Args &a, int tile, void *stream, char *name,
     case 5: t = "128x128,plain"; rc = launch_x3_tile<128, 128, 2, 2>(d, s); break;
     default: return (int)hipErrorInvalidValue;
     }
-    if (name) snprintf(name, name_len, "conv_f32_x3<%s,ks%d%s>", t, a.size, a.yolo_entries > 0 ? ",yolo" : (a.in2 ? ",up+route" : ""));
+    char sp[16] = "";
+    if (ksplit > 1) snprintf(sp, sizeof(sp), ",split%d", ksplit);
+    if (name) snprintf(name, name_len, "conv_f32_x3<%s,ks%d%s%s>", t, a.size, a.yolo_entries > 0 ? ",yolo" : (a.in2 ? ",up+route" : ""), sp);
+    if (rc == 0 && ksplit > 1)
+        rc = launch_splitk_finish(a.ks_ws, ksplit, d.ks_out_off, a.bias, a.B, a.M, d.OHW, a.act, a.add, a.out, a.out_add, stream);
     return rc;
 }
 

@@ -55,6 +55,13 @@ struct ConvF32Args {
     const void *x3_w = nullptr; // the weights as three bf16 pieces (x3_pack_weights, conv_f32_x3.hip) or nullptr
     const void *row3_w = nullptr; // 3x3 / 1 / 1 layers: the row-transformed weights U = G g as three bf16 pieces (row3_pack_weights,
                           // conv_f32_row3.hip) or nullptr
+    // split K (yl_network_set_split_k; K1x / K1r only, every other kernel ignores it): the channel blocks are cut into `ksplit`
+    // contiguous ranges, one workgroup set per range (gridDim.y), each writing its raw partial sums to ks_ws + range * B * M * OH * OW;
+    // a second kernel adds the partials IN RANGE ORDER, then bias, activation and the fused [shortcut] (launch_splitk_finish):
+    // run-to-run bit-stable, a different summation order than the unsplit layer (inside the FP32 contract, not bit-equal to it)
+    int ksplit = 1;
+    float *ks_ws = nullptr;        // ksplit * B * M * OH * OW floats
+    const float *ks_zeros = nullptr;   // >= M zero floats (the partial passes' bias)
     bool in_front_pad = false;     // `in` has >= 4 readable bytes in front of it holding a FINITE value (library-owned tensors:
                            // yl_internal.h ACT_FRONT_PAD); the Winograd kernel then fetches left-edge patches one column early
                            // and folds the column masks into the transform instead of shifting registers
@@ -215,6 +222,9 @@ int launch_region(const float *in, float *out, int B, int n, int classes, int co
 int launch_binarize(const float *in, float *out, size_t n, void *stream);
 // x = activate(x, act) in place: activate_array_cpu_custom for activations other than LINEAR / LEAKY (activations.h)
 int launch_activate(float *x, size_t n, int act, void *stream);
+// second stage of a split-K convolution: out = act(ws[0] + ws[1] + ... (in this order) + bias) [, out_add = out + add]
+int launch_splitk_finish(const float *ws, int parts, size_t part_stride, const float *bias, int B, int M, int OHW, int act,
+                         const float *add, float *out, float *out_add, void *stream);
 int launch_reorg(const float *in, float *out, int B, int out_c, int out_h, int out_w, int stride, void *stream);
 
 // ---- K10: detection compaction ----

@@ -555,4 +555,40 @@ int launch_compact(const HeadDesc *heads, int n_heads, int B, int netw, int neth
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------ split-K second stage
+// partial sums of `parts` channel ranges (conv_f32_x3.hip / conv_f32_row3.hip with ConvF32Args::ksplit > 1) -> the layer's tensor.
+// The partials are added in range order, then the bias, then the activation with the convolution kernels' arithmetic
+// (leaky as (float)(.1 * (double)x)), then the fused [shortcut] operand: a fixed order, the same bits on every run.
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float *__restrict__ ws, int parts, size_t part_stride,
+                                                            const float *__restrict__ bias, int M, int OHW, size_t total, int act,
+                                                            const float *__restrict__ add, float *__restrict__ out,
+                                                            float *__restrict__ out_add)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float v = ws[i];
+        for (int s = 1; s < parts; ++s) v = __fadd_rn(v, ws[(size_t)s * part_stride + i]);
+        const int m = (int)((i / (size_t)OHW) % (size_t)M);
+        v = __fadd_rn(v, bias[m]);
+        if (act == YL_LEAKY) {
+            const float t = (float)(.1 * (double)v);
+            v = (v > 0.f) ? v : t;
+        }
+        if (out) out[i] = v;
+        if (add) out_add[i] = __fadd_rn(v, add[i]);
+    }
+}
+
+int launch_splitk_finish(const float *ws, int parts, size_t part_stride, const float *bias, int B, int M, int OHW, int act,
+                         const float *add, float *out, float *out_add, void *stream)
+{
+    if (!ws || parts < 2 || !bias || (!out && !add) || (add && !out_add) || (act != YL_LEAKY && act != YL_LINEAR)) return (int)hipErrorInvalidValue;
+    const size_t total = (size_t)B * M * OHW;
+    size_t g = (total + 255) / 256;
+    if (g > 256 * 8) g = 256 * 8;
+    if (g == 0) g = 1;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ws, parts, part_stride, bias, M, OHW,
+                       total, act, add, out, out_add);
+    return (int)hipGetLastError();
+}
+
 }  // namespace yl

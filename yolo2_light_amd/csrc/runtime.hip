@@ -9,6 +9,7 @@
 // there is no host synchronisation inside a forward, and no CPU fallback: every
 // device entry point fails with YL_ERR_DEVICE when HIP reports an error.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <chrono>
 
 #include <cstdio>
@@ -56,6 +57,33 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // LINEAR and LEAKY live in the convolution kernels' epilogues; every other activation of activate()
 // (src/additionally.h:132-165) is applied by a pass of its own behind a linear epilogue (layers.hip: activate_kernel)
 static inline bool hot_activation(int a) { return a == YL_LINEAR || a == YL_LEAKY; }
+
+// K ranges of an FP32 convolution on K1x / K1r (yl_network_set_split_k).  Measured on yolov3-608 at 8 images per GPU
+// (profiles/r6_split_k_b8.txt): a split pays where ONE workgroup's K loop is the layer's time -- a grid of less than four 64 x 64
+// workgroups per CU AND a deep K (>= 64 panels of 16 channels x taps: the 19 x 19 1x1 and 3x3 layers, the 3x3 / stride-2 layer in
+// front of them), or a grid below one workgroup per CU from 32 panels on -- and costs where the second stage's pass over the
+// partial sums outweighs it (the 38 x 38 and 76 x 76 layers: left alone).  2 .. 4 ranges, a divisor of the channel blocks, >= 4
+// blocks (64 channels) each, as many as bring the grid to ~8 workgroups per CU.  A function of the layer and the batch only: the
+// same network at the same batch always splits the same way.
+static int split_k_parts(int B, int C, int M, int size, int OH, int OW, int n_cu)
+{
+    if ((C % 16) != 0 || C < 128 || M <= 32 || (size != 1 && size != 3)) return 1;
+    const long long px = (long long)B * OH * OW;
+    const long long nwg = (long long)((M + 63) / 64) * ((px + 63) / 64);
+    const int cblocks = C / 16;
+    const int depth = cblocks * size * size;
+    if (nwg >= 4LL * n_cu) return 1;
+    if (!(depth >= 64 || (nwg < n_cu && depth >= 32))) return 1;
+    int want = (int)((8LL * n_cu + nwg - 1) / nwg);
+    if (want > 4) want = 4;
+    if (want < 2) want = 2;
+    auto fits = [&](int s) { return s >= 2 && s <= 4 && cblocks % s == 0 && cblocks / s >= 4; };
+    // (rounding DOWN where the wanted count does not divide the blocks: four ranges instead of two on the 19 x 19 3x3 layers measured
+    //  0.150 vs 0.138 ms -- the second stage reads every range)
+    for (int s = want; s >= 2; --s)
+        if (fits(s)) return s;
+    return 1;
+}
 // the shapes conv_f32_smallk.hip accepts (smallk_applicable, minus what only the launch knows)
 // `batch`: both first-layer kernels address the input with 32-bit byte offsets (input tensor < 4 GiB) -- a batch
 // beyond that must not get the sign-word plan, whose only producers they are (launch_conv_f32 would fail instead of
@@ -137,6 +165,9 @@ static void free_device(Network &net)
     if (net.d_det_counts) (void)hipFree(net.d_det_counts);
     if (net.d_det_meta) (void)hipFree(net.d_det_meta);
     net.d_det_meta = nullptr; net.det_meta_bytes = 0;
+    if (net.d_ks_ws) (void)hipFree(net.d_ks_ws);
+    if (net.d_ks_zeros) (void)hipFree(net.d_ks_zeros);
+    net.d_ks_ws = nullptr; net.d_ks_zeros = nullptr; net.ks_ws_floats = 0;
     net.d_det_scratch = nullptr; net.d_det_out = nullptr; net.d_det_counts = nullptr;
     net.det_scratch_bytes = net.det_out_bytes = 0;
     net.d_input = nullptr; net.d_qbuf = nullptr; net.d_bitbuf = nullptr; net.h_pinned = nullptr;
@@ -523,6 +554,21 @@ static int to_device(Network &net, int device)
         YL_HIP(hipMemsetAsync(net.d_bitbuf, 0, 3 * net.bitbuf_bytes, (hipStream_t)net.stream));       // pad bits start out 0; every writer stores whole 64-bit words (conv_xnor.hip), the ring is reused across layers
     }
     if (net.binbuf_bytes) YL_HIP(hipMalloc((void **)&net.d_binbuf, net.binbuf_bytes));
+    // ---- split-K workspace (yl_network_set_split_k): 4 ranges of the largest tensor a split layer can have + a zero bias ----
+    if (net.split_k) {
+        size_t mx = 0, mfil = 0;
+        for (const Layer &l : net.layers)
+            if (l.type == YL_CONVOLUTIONAL && l.conv_mode == CONV_F32 && split_k_parts(net.batch, l.c, l.n, l.size, l.out_h, l.out_w, device_cu_count()) > 1) {
+                mx = std::max(mx, (size_t)net.batch * l.outputs);
+                mfil = std::max(mfil, (size_t)l.n);
+            }
+        if (mx) {
+            net.ks_ws_floats = 4 * mx;
+            YL_HIP(hipMalloc((void **)&net.d_ks_ws, net.ks_ws_floats * sizeof(float)));
+            YL_HIP(hipMalloc((void **)&net.d_ks_zeros, (mfil + 256) * sizeof(float)));
+            YL_HIP(hipMemsetAsync(net.d_ks_zeros, 0, (mfil + 256) * sizeof(float), (hipStream_t)net.stream));
+        }
+    }
     // ---- optional conv+shortcut fusion plan ----
     for (Layer &l : net.layers) { l.fused_shortcut = -1; l.fused_yolo = -1; l.fused_pool = -1; l.fused_into_conv = false;
                                   l.two_src_up = -1; l.two_src_other = -1; l.two_src_conv = -1; l.two_src_skipped = false; }
@@ -883,6 +929,10 @@ static int forward_layer(Network &net, size_t i, const float *input)
                         } else a.bits_pooled = false;
                     }
                 }
+            }
+            if (net.split_k && net.d_ks_ws && !a.in2 && !a.q_out && !a.bits_out && !a.pool_out && a.yolo_entries == 0 && hot_activation(kernel_act)) {
+                const int parts = split_k_parts(B, l.c, l.n, l.size, l.out_h, l.out_w, device_cu_count());
+                if (parts > 1 && (size_t)parts * B * l.outputs <= net.ks_ws_floats) { a.ksplit = parts; a.ks_ws = net.d_ks_ws; a.ks_zeros = net.d_ks_zeros; }
             }
             YL_LAUNCH(launch_conv_f32(a, net.conv_opts, s, l.kernel_name, sizeof(l.kernel_name)), "conv_f32");
             if (pool_after) {
@@ -1905,6 +1955,14 @@ long long yl_debug_layer_packed(yl_network *net, int i, int which, void *dst_hos
     YL_HIP(hipStreamSynchronize((hipStream_t)net->net.stream));
     YL_STAGE(stage_d2h(net->net.device, dst_host, src, (size_t)need));
     return need;
+}
+
+int yl_network_set_split_k(yl_network *net, int on)
+{
+    if (!net) { set_error("null argument"); return YL_ERR_ARG; }
+    if (net->net.on_device) { set_error("set_split_k must precede to_device"); return YL_ERR_STATE; }
+    net->net.split_k = on != 0;
+    return YL_OK;
 }
 
 int yl_network_set_nms_mode(yl_network *net, int mode)

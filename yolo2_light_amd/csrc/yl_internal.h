@@ -127,6 +127,10 @@ struct Network {
     ConvF32Opts conv_opts;               // K1 kernel-selection knobs of THIS network (no process-global launch state)
     int i8_tile = 0;                     // K2 tile (0 = heuristic; yl_network_set_int8_tile)
     int nms_mode = 1;                    // 1 = one workgroup per (image, class), 0 = one per image
+    bool split_k = false;                // yl_network_set_split_k: K ranges for FP32 convolutions whose grid leaves CUs idle
+    float *d_ks_ws = nullptr;            //   partial sums: up to 4 ranges of the largest eligible layer's tensor
+    size_t ks_ws_floats = 0;
+    float *d_ks_zeros = nullptr;         //   the partial passes' bias (zeros, >= the widest layer's filters)
     unsigned long long forward_seq = 0;  // bumped by every forward: detection cache key
     void *stream = nullptr;              // hipStream_t
     bool own_stream = false;

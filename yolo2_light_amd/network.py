@@ -64,7 +64,8 @@ class Network:
     def load(cls, cfg_path: str, weights_path: str, batch: int = 1, quantized: int = 0,
              device: Optional[int] = None, debug: bool = False, fuse: bool = False,
              quant_rule: int = 0, winograd: bool = True, bf16: bool = False, device_prep: bool = False,
-             variant: Optional[int] = None, device_pack: Optional[bool] = None, strict: bool = False) -> "Network":
+             variant: Optional[int] = None, device_pack: Optional[bool] = None, strict: bool = False,
+             split_k: bool = False) -> "Network":
         """The full prep sequence of test_detector_cpu (src/main.c:160-171)."""
         net = cls.from_cfg(cfg_path, batch, quantized)
         if quant_rule:
@@ -75,6 +76,8 @@ class Network:
             net.set_precision(1)
         if strict:
             net.set_precision(2)
+        if split_k:
+            check(lib.yl_network_set_split_k(net._h, 1), "yl_network_set_split_k")
         if variant is not None:
             net.set_variant(variant)       # before to_device: bit 5 selects the Winograd weight packing
         if device_pack is not None:
@@ -219,6 +222,10 @@ class Network:
 
     def set_int8_tile(self, cfg: int) -> None:
         check(lib.yl_network_set_int8_tile(self._h, cfg), "yl_network_set_int8_tile")
+
+    def set_split_k(self, on: bool = True) -> None:
+        """K ranges for FP32 convolutions whose grid leaves CUs idle (deterministic two-stage sum); before to_device"""
+        check(lib.yl_network_set_split_k(self._h, 1 if on else 0), "yl_network_set_split_k")
 
     def set_nms_mode(self, mode: int) -> None:
         check(lib.yl_network_set_nms_mode(self._h, mode), "yl_network_set_nms_mode")
