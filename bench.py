@@ -1048,7 +1048,7 @@ def compact_line(out: dict) -> dict:
     line = {k: _r(out.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
                                         "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
     cfg = out.get("config") or {}
-    line["config"] = {"workload": str(cfg.get("workload", ""))[:240], "global_batch": cfg.get("global_batch"),
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:300], "global_batch": cfg.get("global_batch"),
                       "parallelism": cfg.get("parallelism"), "gflop_per_image": _r(cfg.get("gflop_per_image"))}
     line["roofline"] = _pick(out.get("roofline"), _ROOFLINE_KEYS)
     cpu = out.get("cpu_baseline")
@@ -1399,7 +1399,9 @@ def main():
                                    "HBM, forward + on-device detection decode/compaction + NMS%s; `value` = the %s leg" % (
                                        args.model, args.size, args.size, args.global_batch, b_local, modes,
                                        " + RCCL all-gather of detections" if use_dist else "",
-                                       ("BIT1-XNOR" if xnor_model else "FP32") if do_fp32 else ("INT8" if do_int8 else "BF16")),
+                                       ("BIT1-XNOR" if xnor_model else "FP32") if do_fp32 else ("INT8" if do_int8 else "BF16"))
+                                   + ("; INT8 input_calibration recomputed for the synthetic weights" if (do_int8 and cfg_q != cfg) else
+                                      ("; INT8 on the cfg's shipped input_calibration" if do_int8 else "")),
                        "global_batch": args.global_batch,
                        "parallelism": "image-batch sharding x%d (%s scaling)" % (world, args.scaling),
                        "gflop_per_image": head.get("gflop_per_image"),
