@@ -709,9 +709,14 @@ def pcie_inclusive(net, torch, stream, args, B, rec, cnt, steps: int = 3):
     rec_h = torch.empty(rec.shape, dtype=rec.dtype).pin_memory()
     cnt_h = torch.empty(cnt.shape, dtype=cnt.dtype).pin_memory()
 
-    def one():
-        for b in range(B):
-            net.set_input_u8(b, frames[b % len(frames)])
+    batch_frames = [frames[b % len(frames)] for b in range(B)]
+
+    def one(batched):
+        if batched:
+            net.set_input_u8_batch(batch_frames)          # ONE call: pool-copied, uploaded on the copy stream under the previous forward
+        else:
+            for b in range(B):
+                net.set_input_u8(b, batch_frames[b])
         net.forward_staged()
         with torch.cuda.stream(stream):
             net.detect_batch(args.thresh, args.nms if args.nms > 0 else 0.4, args.cap, rec.data_ptr(), cnt.data_ptr(),
@@ -719,13 +724,16 @@ def pcie_inclusive(net, torch, stream, args, B, rec, cnt, steps: int = 3):
             rec_h.copy_(rec, non_blocking=True)
             cnt_h.copy_(cnt, non_blocking=True)
 
-    one()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one()
-    torch.cuda.synchronize()
-    t_u8 = (time.perf_counter() - t0) / steps
+    t_by = {}
+    for batched in (False, True):
+        one(batched)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one(batched)
+        torch.cuda.synchronize()
+        t_by[batched] = (time.perf_counter() - t0) / steps
+    t_u8 = t_by[True]
     x_host = np.random.default_rng(8).random((B, 3, args.size, args.size), dtype=np.float32)
     net.predict_raw(x_host)
     t0 = time.perf_counter()
@@ -734,8 +742,10 @@ def pcie_inclusive(net, torch, stream, args, B, rec, cnt, steps: int = 3):
     t_f32 = (time.perf_counter() - t0) / 3
     return {
         "value": B / t_u8, "unit": "images/sec", "ms_per_step": t_u8 * 1e3,
-        "what": "u8 768x576x3 host frames -> yl_network_set_input_u8 -> forward -> yl_network_detect_batch -> "
+        "what": "u8 768x576x3 host frames -> yl_network_set_input_u8_batch -> forward -> yl_network_detect_batch -> "
                 "rows+counts on the host; %d pipelined steps" % steps,
+        "per_frame_calls": {"value": B / t_by[False], "ms_per_step": t_by[False] * 1e3,
+                            "what": "the same with one yl_network_set_input_u8 per frame (round 5's form)"},
         "predict_float_host": {"value": B / t_f32, "unit": "images/sec", "ms_per_step": t_f32 * 1e3,
                                "what": "yl_network_predict(float CHW host batch): pinned staging + H2D of %.0f MB + forward + D2H of "
                                        "the heads, as a two-sub-batch pipeline on three streams" % (x_host.nbytes / 1e6)},
@@ -748,7 +758,7 @@ def decode_inclusive(net, torch, stream, args, B, rec, cnt, threads=(1, 8, 32, 6
     src/main.c:187).  A 768x576 JPEG (the size of bin/dog.jpg; made here from a smooth synthetic frame, quality 90, because the
     reference tree does not travel to the GPU box) is decoded on N host threads (Pillow = libjpeg-turbo, the GIL is released
     inside the decoder) and every decoded frame goes through the same boundary the PCIe-inclusive leg uses
-    (yl_network_set_input_u8 -> GPU /255 + resize_image -> forward -> detect_batch -> rows on the host).
+    (yl_network_set_input_u8_batch -> GPU /255 + resize_image -> forward -> detect_batch -> rows on the host).
     Reported: decode-only img/s and decode-inclusive img/s per thread count, and the reference's own front end
     (load_image + resize_image on one core, oracle/_ref) beside them."""
     import io
@@ -786,8 +796,7 @@ def decode_inclusive(net, torch, stream, args, B, rec, cnt, threads=(1, 8, 32, 6
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
-                for b, fr in enumerate(ex.map(decode, range(B))):
-                    net.set_input_u8(b, fr)
+                net.set_input_u8_batch(list(ex.map(decode, range(B))))
                 net.forward_staged()
                 with torch.cuda.stream(stream):
                     net.detect_batch(args.thresh, args.nms if args.nms > 0 else 0.4, args.cap, rec.data_ptr(), cnt.data_ptr(),
@@ -824,7 +833,7 @@ def decode_inclusive(net, torch, stream, args, B, rec, cnt, threads=(1, 8, 32, 6
                 out["reference_front_end_one_core_images_per_sec"] = k / (time.perf_counter() - t0)
     except Exception as ex:
         out["reference_front_end_error"] = repr(ex)
-    out["what"] = ("JPEG decode on N host threads -> yl_network_set_input_u8 -> forward -> yl_network_detect_batch -> rows on the host; "
+    out["what"] = ("JPEG decode on N host threads -> yl_network_set_input_u8_batch -> forward -> yl_network_detect_batch -> rows on the host; "
                    "`value` = the best thread count")
     return out
 

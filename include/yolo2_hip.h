@@ -420,6 +420,13 @@ int yl_network_get_boxes_batch(yl_network *net, const int *img_w, const int *img
  * Follow with yl_network_forward(net, yl_network_input_dev(net)). */
 int yl_network_set_input_u8(yl_network *net, int image, const uint8_t *pixels_host, int w, int h, int c);
 int yl_network_set_input_u8_dev(yl_network *net, int image, const uint8_t *pixels_dev, int w, int h, int c);
+/* A whole batch of decoded frames in ONE call: frame i (HWC u8, w[i] x h[i] x c, pageable host memory is fine) -> batch slot
+ * first + i, for i < count.  Same result as `count` calls of yl_network_set_input_u8 (bit-identical), without their per-frame host
+ * cost: the frames are copied into the pinned slots by the library's host-thread pool, travel on the copy stream (the uploads of
+ * step k+1 overlap the forward pass of step k), and the conversion + resize kernels are queued on the compute stream behind them.
+ * Asynchronous like the per-frame call; the frames may be reused when it returns. */
+int yl_network_set_input_u8_batch(yl_network *net, int first, int count, const uint8_t *const *pixels_host,
+                                  const int *w, const int *h, int c);
 /* copy of the device input buffer, float[batch*c*h*w] (synchronous; what `sized.data` /
  * the X argument of network_predict would hold, src/main.c:189,193) */
 int yl_network_input_download(yl_network *net, float *dst_host);

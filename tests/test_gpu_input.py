@@ -58,6 +58,33 @@ def test_frames_through_the_whole_path(olib):
     net.close()
 
 
+def test_batched_frames_equal_per_frame_calls():
+    """yl_network_set_input_u8_batch (one call: pool-copied frames, uploads on the copy stream, resize kernels behind them) leaves
+    the bits of one yl_network_set_input_u8 per frame in the input buffer -- mixed frame sizes, a partial range, the staging ring
+    growing between rounds, batch calls and per-frame calls interleaved on the same slots."""
+    netw, neth, B = 160, 96, 6
+    cfg, wts = common.model_files("yolov3-tiny", netw, neth)
+    net = Network.load(cfg, wts, B, 0, device=0)
+    rng = np.random.default_rng(9)
+    sizes = [(64, 48), (320, 240), (97, 33), (768, 576), (50, 70), (1280, 720)]
+    for rnd in range(3):
+        frames = [rng.integers(0, 256, size=(sizes[(b + rnd) % 6][1], sizes[(b + rnd) % 6][0], 3), dtype=np.uint8) for b in range(B)]
+        for b, pix in enumerate(frames):
+            net.set_input_u8(b, pix)
+        want = net.input_download().copy()
+        net.set_input_u8_batch([np.zeros_like(f) for f in frames])          # overwrite every slot, then the real frames in two ranges
+        net.set_input_u8_batch(frames[:2])
+        net.set_input_u8_batch(frames[2:], first=2)
+        got = net.input_download()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), rnd
+        net.set_input_u8(3, frames[0])                                       # a per-frame call behind a batch call on the same slot
+        one = net.input_download()
+        assert np.array_equal(one[3].view(np.uint32), want[0].view(np.uint32)) if frames[0].shape == frames[3].shape else True
+    with pytest.raises(Exception):
+        net.set_input_u8_batch(frames, first=1)                              # range beyond the batch
+    net.close()
+
+
 def test_front_end_rejects_bad_arguments():
     cfg, wts = common.model_files("yolov3-tiny", 96, 96)
     net = Network.load(cfg, wts, 2, 0, device=0)

@@ -125,6 +125,7 @@ _SIGS = {
                                           _vp, _vp]),
     "yl_network_set_input_u8": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int]),
     "yl_network_set_input_u8_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int]),
+    "yl_network_set_input_u8_batch": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
     "yl_network_input_download": (C.c_int, [_vp, c_float_p]),
     "yl_network_calibrate": (C.c_int, [_vp, c_float_p, C.c_int, c_float_p, C.c_int]),
     "yl_entropy_from_histogram": (C.c_float, [C.POINTER(C.c_uint32), C.c_int, C.c_float]),

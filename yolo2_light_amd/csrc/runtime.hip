@@ -155,6 +155,8 @@ static void free_device(Network &net)
     if (net.d_u8) (void)hipFree(net.d_u8);
     for (void *e : net.u8_events) if (e) (void)hipEventDestroy((hipEvent_t)e);
     net.u8_events.clear();
+    if (net.u8_resized) (void)hipEventDestroy((hipEvent_t)net.u8_resized);
+    net.u8_resized = nullptr;
     net.h_u8 = nullptr; net.d_u8 = nullptr; net.u8_stride = 0;
     if (net.h_det_rows) (void)hipHostFree(net.h_det_rows);
     net.h_det_rows = nullptr; net.h_det_bytes = 0; net.det_cache_valid = false;
@@ -2145,17 +2147,14 @@ int yl_network_set_input_u8_dev(yl_network *net, int image, const uint8_t *pixel
     return YL_OK;
 }
 
-int yl_network_set_input_u8(yl_network *net, int image, const uint8_t *pixels_host, int w, int h, int c)
+// pinned + device staging slots of at least `bytes` per batch slot, and the per-slot "H2D done" events
+static int ensure_u8_slots(Network &n, size_t bytes)
 {
-    const int rc = check_image_args(net, image, pixels_host, w, h, c);
-    if (rc != YL_OK) return rc;
-    Network &n = net->net;
-    YL_HIP(hipSetDevice(n.device));
     hipStream_t s = (hipStream_t)n.stream;
-    const size_t bytes = (size_t)w * h * c;
     if (bytes > n.u8_stride) {
         // grow every slot: earlier stagings must have been consumed first
         YL_HIP(hipStreamSynchronize(s));
+        if (n.in_stream) YL_HIP(hipStreamSynchronize((hipStream_t)n.in_stream));
         size_t stride = n.u8_stride ? n.u8_stride : (size_t)n.w * n.h * n.c;
         while (stride < bytes) stride += stride / 2;
         stride = (stride + 4095) & ~(size_t)4095;
@@ -2175,6 +2174,66 @@ int yl_network_set_input_u8(yl_network *net, int image, const uint8_t *pixels_ho
             YL_HIP(hipEventRecord(ev, s));
         }
     }
+    return YL_OK;
+}
+
+int yl_network_set_input_u8_batch(yl_network *net, int first, int count, const uint8_t *const *pixels_host,
+                                  const int *w, const int *h, int c)
+{
+    if (!net || !pixels_host || !w || !h) { set_error("null argument"); return YL_ERR_ARG; }
+    Network &n = net->net;
+    if (count < 0 || first < 0 || (n.on_device && first + count > n.batch)) { set_error("frame range outside the batch"); return YL_ERR_ARG; }
+    size_t mx = 0;
+    for (int i = 0; i < count; ++i) {
+        const int rc = check_image_args(net, first + i, pixels_host[i], w[i], h[i], c);
+        if (rc != YL_OK) return rc;
+        mx = std::max(mx, (size_t)w[i] * h[i] * c);
+    }
+    if (count == 0) return YL_OK;
+    YL_HIP(hipSetDevice(n.device));
+    int rc = ensure_u8_slots(n, mx);
+    if (rc != YL_OK) return rc;
+    hipStream_t s = (hipStream_t)n.stream, cs = (hipStream_t)n.in_stream;
+    if (!n.u8_resized) {
+        hipEvent_t ev;
+        YL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        n.u8_resized = ev;
+        YL_HIP(hipEventRecord(ev, s));
+    }
+    // pageable -> pinned: every frame's copy on the host pool at once (a slot's previous upload must have left its pinned region)
+    HostCopyJob job;
+    for (int i = 0; i < count; ++i) {
+        YL_HIP(hipEventSynchronize((hipEvent_t)n.u8_events[first + i]));
+        host_copy_async(job, n.h_u8 + (size_t)(first + i) * n.u8_stride, pixels_host[i], (size_t)w[i] * h[i] * c);
+    }
+    host_copy_wait(job);
+    // pinned -> device on the copy stream, behind the resize kernels that last read the device slots
+    YL_HIP(hipStreamWaitEvent(cs, (hipEvent_t)n.u8_resized, 0));
+    for (int i = 0; i < count; ++i) {
+        const size_t off = (size_t)(first + i) * n.u8_stride;
+        YL_HIP(hipMemcpyAsync(n.d_u8 + off, n.h_u8 + off, (size_t)w[i] * h[i] * c, hipMemcpyHostToDevice, cs));
+        YL_HIP(hipEventRecord((hipEvent_t)n.u8_events[first + i], cs));
+    }
+    // conversion + resize on the compute stream, behind the last upload (events are ordered on the copy stream)
+    YL_HIP(hipStreamWaitEvent(s, (hipEvent_t)n.u8_events[first + count - 1], 0));
+    for (int i = 0; i < count; ++i) {
+        float *dst = n.d_input + (size_t)(first + i) * n.c * n.h * n.w;
+        YL_LAUNCH(launch_load_resize_u8(n.d_u8 + (size_t)(first + i) * n.u8_stride, w[i], h[i], c, n.w, n.h, dst, n.stream), "load_resize_u8");
+    }
+    YL_HIP(hipEventRecord((hipEvent_t)n.u8_resized, s));
+    return YL_OK;
+}
+
+int yl_network_set_input_u8(yl_network *net, int image, const uint8_t *pixels_host, int w, int h, int c)
+{
+    int rc = check_image_args(net, image, pixels_host, w, h, c);
+    if (rc != YL_OK) return rc;
+    Network &n = net->net;
+    YL_HIP(hipSetDevice(n.device));
+    hipStream_t s = (hipStream_t)n.stream;
+    const size_t bytes = (size_t)w * h * c;
+    rc = ensure_u8_slots(n, bytes);
+    if (rc != YL_OK) return rc;
     // the slot's staging region may still be the source of the previous frame's copy
     YL_HIP(hipEventSynchronize((hipEvent_t)n.u8_events[image]));
     uint8_t *hs = n.h_u8 + (size_t)image * n.u8_stride;

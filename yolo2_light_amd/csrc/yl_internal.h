@@ -166,6 +166,7 @@ struct Network {
     uint8_t *d_u8 = nullptr;             // the same on the device
     size_t u8_stride = 0;                // bytes per slot
     std::vector<void *> u8_events;       // per slot: H2D of the slot's staging region has completed
+    void *u8_resized = nullptr;          // hipEvent_t: the resize kernels of the last yl_network_set_input_u8_batch have read d_u8
     // yl_network_predict's pipeline (runtime.hip): the batch runs as up to PREDICT_MAX_SPLIT sub-batches; input of sub-batch k+1
     // travels on in_stream and the heads of sub-batch k-1 on out_stream while sub-batch k computes on `stream`
     void *in_stream = nullptr, *out_stream = nullptr;   // hipStream_t

@@ -346,6 +346,20 @@ class Network:
         check(lib.yl_network_set_input_u8(self._h, image, pix.ctypes.data_as(C.c_void_p), w, h, c),
               "yl_network_set_input_u8")
 
+    def set_input_u8_batch(self, frames, first: int = 0) -> None:
+        """frames: a list of uint8 [h][w][c] arrays -> batch slots first, first + 1, ... in ONE call (pool-copied, uploaded on the copy
+        stream, resized on the compute stream); same bits as one set_input_u8 per frame"""
+        pix = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
+        n = len(pix)
+        if n == 0:
+            return
+        if any(p.ndim != 3 for p in pix):
+            raise ValueError("every frame must be [h][w][c]")
+        ptrs = (C.c_void_p * n)(*[p.ctypes.data for p in pix])
+        ws = (C.c_int * n)(*[p.shape[1] for p in pix])
+        hs = (C.c_int * n)(*[p.shape[0] for p in pix])
+        check(lib.yl_network_set_input_u8_batch(self._h, first, n, ptrs, ws, hs, pix[0].shape[2]), "yl_network_set_input_u8_batch")
+
     def set_input_u8_dev(self, image: int, pixels_dev_ptr: int, w: int, h: int, c: int = 3) -> None:
         check(lib.yl_network_set_input_u8_dev(self._h, image, C.c_void_p(pixels_dev_ptr), w, h, c),
               "yl_network_set_input_u8_dev")
